@@ -1,0 +1,647 @@
+/*
+ * oracle/mjl_collide.c -- TEST INFRASTRUCTURE ONLY (CPU oracle, fp64).  See mjl_core.h.
+ *
+ * Collision detection for the geom-pair types that occur in the 36 Meta-World
+ * scenes.  Analytic routines for plane-X, sphere-X,
+ * capsule-capsule and box-box (SAT + face clipping); every other convex pair
+ * (cylinder, mesh hulls, capsule-box) goes through one Minkowski-portal-
+ * refinement routine on support functions with the MuJoCo convention of
+ * inflating both shapes by margin/2.  Contact convention (MuJoCo): frame[0..2]
+ * is the normal pointing from geom1 to geom2, dist<0 is penetration, pos is the
+ * midpoint between the two surfaces.  "parity unpinned": see mjl_core.h.
+ */
+#include <math.h>
+#include <string.h>
+
+#include "mjl_core.h"
+
+#define MINVAL 1e-15
+#define CCD_TOL 1e-6
+#define CCD_ITER 50
+
+typedef struct { int type; const double *pos, *mat, *size; const double* vert; int nvert; double margin; } Shape;
+typedef struct { double dist, pos[3], normal[3]; } Hit;
+
+static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(double* r, const double* a, const double* b) {
+    double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void sub3(double* r, const double* a, const double* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static inline void add3(double* r, const double* a, const double* b) { r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; }
+static inline void addscl3(double* r, const double* a, const double* b, double s) { r[0] = a[0] + s * b[0]; r[1] = a[1] + s * b[1]; r[2] = a[2] + s * b[2]; }
+static inline void copy3(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+static inline void scl3(double* r, const double* a, double s) { r[0] = a[0] * s; r[1] = a[1] * s; r[2] = a[2] * s; }
+static inline double norm3(const double* a) { return sqrt(dot3(a, a)); }
+static inline double normalize3(double* a) {
+    double n = norm3(a);
+    if (n < MINVAL) { a[0] = 1; a[1] = a[2] = 0; return 0; }
+    a[0] /= n; a[1] /= n; a[2] /= n;
+    return n;
+}
+static inline void col3(double* r, const double* mat, int k) { r[0] = mat[k]; r[1] = mat[3 + k]; r[2] = mat[6 + k]; }
+/* r = mat^T v  (world -> local) */
+static inline void mulT(double* r, const double* mat, const double* v) {
+    double x = mat[0] * v[0] + mat[3] * v[1] + mat[6] * v[2];
+    double y = mat[1] * v[0] + mat[4] * v[1] + mat[7] * v[2];
+    double z = mat[2] * v[0] + mat[5] * v[1] + mat[8] * v[2];
+    r[0] = x; r[1] = y; r[2] = z;
+}
+static inline void mul(double* r, const double* mat, const double* v) {
+    double x = mat[0] * v[0] + mat[1] * v[1] + mat[2] * v[2];
+    double y = mat[3] * v[0] + mat[4] * v[1] + mat[5] * v[2];
+    double z = mat[6] * v[0] + mat[7] * v[1] + mat[8] * v[2];
+    r[0] = x; r[1] = y; r[2] = z;
+}
+
+/* ------------------------------------------------------------ plane - X */
+static int plane_sphere(const Shape* p, const Shape* s, double margin, Hit* h) {
+    double n[3], t[3];
+    col3(n, p->mat, 2);
+    sub3(t, s->pos, p->pos);
+    double dist = dot3(t, n) - s->size[0];
+    if (dist > margin) return 0;
+    h->dist = dist;
+    copy3(h->normal, n);
+    addscl3(h->pos, s->pos, n, -(s->size[0] + 0.5 * dist));
+    return 1;
+}
+static int plane_capsule(const Shape* p, const Shape* c, double margin, Hit* h) {
+    double ax[3], n[3], t[3];
+    int cnt = 0;
+    col3(ax, c->mat, 2);
+    col3(n, p->mat, 2);
+    for (int sgn = -1; sgn <= 1; sgn += 2) {
+        double e[3];
+        addscl3(e, c->pos, ax, sgn * c->size[1]);
+        sub3(t, e, p->pos);
+        double dist = dot3(t, n) - c->size[0];
+        if (dist > margin) continue;
+        h[cnt].dist = dist;
+        copy3(h[cnt].normal, n);
+        addscl3(h[cnt].pos, e, n, -(c->size[0] + 0.5 * dist));
+        cnt++;
+    }
+    return cnt;
+}
+static int plane_point(const double* n, const double* p0, const double* pt, double margin, Hit* h) {
+    double t[3];
+    sub3(t, pt, p0);
+    double dist = dot3(t, n);
+    if (dist > margin) return 0;
+    h->dist = dist;
+    copy3(h->normal, n);
+    addscl3(h->pos, pt, n, -0.5 * dist);
+    return 1;
+}
+static int plane_cylinder(const Shape* p, const Shape* c, double margin, Hit* h) {
+    double n[3], ax[3], vec[3], pt[3], r = c->size[0], hh = c->size[1];
+    int cnt = 0;
+    col3(n, p->mat, 2);
+    col3(ax, c->mat, 2);
+    double prj = dot3(n, ax);
+    if (prj > 0) { scl3(ax, ax, -1); prj = -prj; }      /* axis now points toward the plane */
+    /* radial direction toward the plane */
+    addscl3(vec, ax, ax, 0);
+    scl3(vec, ax, prj);
+    sub3(vec, vec, n);
+    double len = norm3(vec);
+    if (len < 1e-12) { col3(vec, c->mat, 0); scl3(vec, vec, r); }
+    else scl3(vec, vec, r / len);
+    /* deepest rim point (near disk) */
+    addscl3(pt, c->pos, ax, hh); add3(pt, pt, vec);
+    cnt += plane_point(n, p->pos, pt, margin, h + cnt);
+    if (!cnt) return 0;
+    /* rim point of the far disk on the same side */
+    addscl3(pt, c->pos, ax, -hh); add3(pt, pt, vec);
+    cnt += plane_point(n, p->pos, pt, margin, h + cnt);
+    /* near disk: two more rim points at +-120 degrees (stabilises a cylinder standing on its cap) */
+    double vec1[3];
+    cross3(vec1, vec, ax);
+    normalize3(vec1);
+    scl3(vec1, vec1, r * sqrt(3.0) / 2);
+    for (int sgn = -1; sgn <= 1; sgn += 2) {
+        addscl3(pt, c->pos, ax, hh);
+        addscl3(pt, pt, vec, -0.5);
+        addscl3(pt, pt, vec1, sgn);
+        cnt += plane_point(n, p->pos, pt, margin, h + cnt);
+    }
+    return cnt;
+}
+static int plane_box(const Shape* p, const Shape* b, double margin, Hit* h) {
+    double n[3];
+    int cnt = 0;
+    col3(n, p->mat, 2);
+    for (int i = 0; i < 8 && cnt < 4; i++) {
+        double loc[3] = { (i & 1 ? 1 : -1) * b->size[0], (i & 2 ? 1 : -1) * b->size[1], (i & 4 ? 1 : -1) * b->size[2] }, pt[3];
+        mul(pt, b->mat, loc);
+        add3(pt, pt, b->pos);
+        cnt += plane_point(n, p->pos, pt, margin, h + cnt);
+    }
+    return cnt;
+}
+static int plane_mesh(const Shape* p, const Shape* s, double margin, Hit* h) {
+    /* up to 4 deepest hull vertices below the margin */
+    double n[3], nl[3], t[3];
+    col3(n, p->mat, 2);
+    mulT(nl, s->mat, n);
+    sub3(t, s->pos, p->pos);
+    double base = dot3(t, n);
+    int cnt = 0, idx[4];
+    double dd[4];
+    for (int i = 0; i < s->nvert; i++) {
+        double dist = base + dot3(s->vert + 3 * i, nl);
+        if (dist > margin) continue;
+        int k = cnt < 4 ? cnt++ : -1;
+        if (k < 0) {
+            int worst = 0;
+            for (int j = 1; j < 4; j++) if (dd[j] > dd[worst]) worst = j;
+            if (dist < dd[worst]) k = worst; else continue;
+        }
+        idx[k] = i; dd[k] = dist;
+    }
+    for (int k = 0; k < cnt; k++) {
+        double pt[3];
+        mul(pt, s->mat, s->vert + 3 * idx[k]);
+        add3(pt, pt, s->pos);
+        h[k].dist = dd[k];
+        copy3(h[k].normal, n);
+        addscl3(h[k].pos, pt, n, -0.5 * dd[k]);
+    }
+    return cnt;
+}
+
+/* ------------------------------------------------------------ sphere - X */
+static int sphere_sphere_raw(const double* c1, double r1, const double* c2, double r2, double margin, Hit* h) {
+    double d[3];
+    sub3(d, c2, c1);
+    double len = norm3(d), dist = len - r1 - r2;
+    if (dist > margin) return 0;
+    if (len < MINVAL) { d[0] = 1; d[1] = d[2] = 0; } else scl3(d, d, 1 / len);
+    h->dist = dist;
+    copy3(h->normal, d);
+    addscl3(h->pos, c1, d, r1 + 0.5 * dist);
+    return 1;
+}
+static int sphere_sphere(const Shape* a, const Shape* b, double margin, Hit* h) {
+    return sphere_sphere_raw(a->pos, a->size[0], b->pos, b->size[0], margin, h);
+}
+static int sphere_capsule(const Shape* s, const Shape* c, double margin, Hit* h) {
+    double ax[3], t[3], pt[3];
+    col3(ax, c->mat, 2);
+    sub3(t, s->pos, c->pos);
+    double x = fmax(-c->size[1], fmin(c->size[1], dot3(t, ax)));
+    addscl3(pt, c->pos, ax, x);
+    return sphere_sphere_raw(s->pos, s->size[0], pt, c->size[0], margin, h);
+}
+static int sphere_cylinder(const Shape* s, const Shape* c, double margin, Hit* h) {
+    double ax[3], t[3], perp[3], R = c->size[0], hh = c->size[1], rs = s->size[0];
+    col3(ax, c->mat, 2);
+    sub3(t, s->pos, c->pos);
+    double x = dot3(t, ax);
+    addscl3(perp, t, ax, -x);
+    double r = norm3(perp);
+    if (fabs(x) <= hh && r >= R * 0 + MINVAL && (R - r) < (hh - fabs(x)) ) {
+        /* nearest feature is the side: sphere vs sphere on the axis */
+        double pt[3];
+        addscl3(pt, c->pos, ax, x);
+        return sphere_sphere_raw(s->pos, rs, pt, R, margin, h);
+    }
+    if (r <= R) {
+        /* nearest feature is a cap */
+        double sg = x >= 0 ? 1 : -1, dist = fabs(x) - hh - rs;
+        if (dist > margin) return 0;
+        h->dist = dist;
+        scl3(h->normal, ax, -sg);                 /* from sphere toward cylinder */
+        addscl3(h->pos, s->pos, h->normal, rs + 0.5 * dist);
+        return 1;
+    }
+    /* rim */
+    double sg = x >= 0 ? 1 : -1, pt[3];
+    addscl3(pt, c->pos, ax, sg * hh);
+    addscl3(pt, pt, perp, R / r);
+    return sphere_sphere_raw(s->pos, rs, pt, 0, margin, h);
+}
+static int sphere_box(const Shape* s, const Shape* b, double margin, Hit* h) {
+    double t[3], loc[3], cl[3], rs = s->size[0];
+    sub3(t, s->pos, b->pos);
+    mulT(loc, b->mat, t);
+    int inside = 1;
+    for (int k = 0; k < 3; k++) {
+        cl[k] = fmax(-b->size[k], fmin(b->size[k], loc[k]));
+        if (cl[k] != loc[k]) inside = 0;
+    }
+    if (!inside) {
+        double pt[3];
+        mul(pt, b->mat, cl);
+        add3(pt, pt, b->pos);
+        return sphere_sphere_raw(s->pos, rs, pt, 0, margin, h);
+    }
+    /* centre inside the box: push out through the nearest face */
+    int best = 0;
+    double bd = 1e30;
+    for (int k = 0; k < 3; k++) {
+        double dd = b->size[k] - fabs(loc[k]);
+        if (dd < bd) { bd = dd; best = k; }
+    }
+    double nl[3] = { 0, 0, 0 }, n[3];
+    nl[best] = loc[best] >= 0 ? -1 : 1;           /* from sphere toward box interior */
+    mul(n, b->mat, nl);
+    h->dist = -bd - rs;
+    copy3(h->normal, n);
+    addscl3(h->pos, s->pos, n, rs + 0.5 * h->dist);
+    return 1;
+}
+
+/* ------------------------------------------------------- capsule - capsule */
+static int capsule_capsule(const Shape* a, const Shape* b, double margin, Hit* h) {
+    double ua[3], ub[3], w[3];
+    col3(ua, a->mat, 2);
+    col3(ub, b->mat, 2);
+    sub3(w, a->pos, b->pos);
+    double la = a->size[1], lb = b->size[1];
+    double ab = dot3(ua, ub), aw = dot3(ua, w), bw = dot3(ub, w), det = 1 - ab * ab;
+    if (fabs(det) < 1e-10) {
+        /* parallel axes: contacts at the ends of the overlap interval */
+        double lo = fmax(-la, (ab > 0 ? -lb : -lb) - 0), s0, s1;
+        /* project b's end points onto a's axis */
+        double e0 = -aw + ab * (-lb), e1 = -aw + ab * lb;
+        if (e0 > e1) { double tt = e0; e0 = e1; e1 = tt; }
+        s0 = fmax(-la, e0); s1 = fmin(la, e1);
+        (void)lo;
+        int cnt = 0;
+        if (s0 > s1) { s0 = s1 = fmax(-la, fmin(la, 0.5 * (e0 + e1))); }
+        double ss[2] = { s0, s1 };
+        for (int k = 0; k < (s1 - s0 > 1e-9 ? 2 : 1); k++) {
+            double pa[3], pb[3], t[3];
+            addscl3(pa, a->pos, ua, ss[k]);
+            sub3(t, pa, b->pos);
+            double tb = fmax(-lb, fmin(lb, dot3(t, ub)));
+            addscl3(pb, b->pos, ub, tb);
+            cnt += sphere_sphere_raw(pa, a->size[0], pb, b->size[0], margin, h + cnt);
+        }
+        return cnt;
+    }
+    double s = (ab * bw - aw) / det, t = (bw - ab * aw) / det;
+    /* clamp with re-projection */
+    if (s < -la) s = -la; else if (s > la) s = la;
+    t = bw + ab * s;
+    if (t < -lb) { t = -lb; s = fmax(-la, fmin(la, -aw + ab * t)); }
+    else if (t > lb) { t = lb; s = fmax(-la, fmin(la, -aw + ab * t)); }
+    double pa[3], pb[3];
+    addscl3(pa, a->pos, ua, s);
+    addscl3(pb, b->pos, ub, t);
+    return sphere_sphere_raw(pa, a->size[0], pb, b->size[0], margin, h);
+}
+
+/* ----------------------------------------------------------- box - box */
+static int clip_poly(double (*poly)[3], int n, const double* pn, double pd) {
+    /* keep the part with pn.x <= pd */
+    double out[16][3];
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const double *a = poly[i], *b = poly[(i + 1) % n];
+        double da = dot3(pn, a) - pd, db = dot3(pn, b) - pd;
+        if (da <= 0) { copy3(out[m++], a); }
+        if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+            double t = da / (da - db);
+            for (int k = 0; k < 3; k++) out[m][k] = a[k] + t * (b[k] - a[k]);
+            m++;
+        }
+        if (m >= 15) break;
+    }
+    for (int i = 0; i < m; i++) copy3(poly[i], out[i]);
+    return m;
+}
+static int box_box(const Shape* A, const Shape* B, double margin, Hit* h, int maxh) {
+    double axA[3][3], axB[3][3], t[3];
+    for (int k = 0; k < 3; k++) { col3(axA[k], A->mat, k); col3(axB[k], B->mat, k); }
+    sub3(t, B->pos, A->pos);
+    double bestsep = -1e30, bestn[3] = { 1, 0, 0 };
+    int bestcode = -1;
+    /* face axes */
+    for (int i = 0; i < 6; i++) {
+        const double* L = i < 3 ? axA[i] : axB[i - 3];
+        double ra = 0, rb = 0;
+        for (int k = 0; k < 3; k++) { ra += A->size[k] * fabs(dot3(axA[k], L)); rb += B->size[k] * fabs(dot3(axB[k], L)); }
+        double tl = dot3(t, L), sep = fabs(tl) - ra - rb;
+        if (sep > margin) return 0;
+        if (sep > bestsep) { bestsep = sep; bestcode = i; scl3(bestn, L, tl >= 0 ? 1 : -1); }
+    }
+    /* edge-edge axes (only if clearly better than the best face axis) */
+    double edgesep = -1e30, edgen[3];
+    int ei = -1, ej = -1;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double L[3];
+            cross3(L, axA[i], axB[j]);
+            double len = norm3(L);
+            if (len < 1e-6) continue;
+            scl3(L, L, 1 / len);
+            double ra = 0, rb = 0;
+            for (int k = 0; k < 3; k++) { ra += A->size[k] * fabs(dot3(axA[k], L)); rb += B->size[k] * fabs(dot3(axB[k], L)); }
+            double tl = dot3(t, L), sep = fabs(tl) - ra - rb;
+            if (sep > margin) return 0;
+            if (sep > edgesep) { edgesep = sep; ei = i; ej = j; scl3(edgen, L, tl >= 0 ? 1 : -1); }
+        }
+    if (ei >= 0 && edgesep > bestsep + 1e-6 + 0.05 * fabs(bestsep)) {
+        /* edge-edge contact: pick the supporting edges and take their closest points */
+        double pa[3], pb[3];
+        copy3(pa, A->pos); copy3(pb, B->pos);
+        for (int k = 0; k < 3; k++) {
+            if (k != ei) addscl3(pa, pa, axA[k], (dot3(axA[k], edgen) > 0 ? 1 : -1) * A->size[k]);
+            if (k != ej) addscl3(pb, pb, axB[k], (dot3(axB[k], edgen) > 0 ? -1 : 1) * B->size[k]);
+        }
+        const double *ua = axA[ei], *ub = axB[ej];
+        double w[3];
+        sub3(w, pa, pb);
+        double ab = dot3(ua, ub), aw = dot3(ua, w), bw = dot3(ub, w), det = 1 - ab * ab;
+        double s = (ab * bw - aw) / det, u = (bw - ab * aw) / det;
+        s = fmax(-A->size[ei], fmin(A->size[ei], s));
+        u = fmax(-B->size[ej], fmin(B->size[ej], u));
+        double qa[3], qb[3];
+        addscl3(qa, pa, ua, s);
+        addscl3(qb, pb, ub, u);
+        h->dist = edgesep;
+        copy3(h->normal, edgen);
+        for (int k = 0; k < 3; k++) h->pos[k] = 0.5 * (qa[k] + qb[k]);
+        return 1;
+    }
+    /* face contact: reference = owner of the best face axis */
+    const Shape *R = bestcode < 3 ? A : B, *I = bestcode < 3 ? B : A;
+    double (*axR)[3] = bestcode < 3 ? axA : axB, (*axI)[3] = bestcode < 3 ? axB : axA;
+    int ra_ = bestcode % 3;
+    double n[3];   /* reference face normal, pointing toward the incident box */
+    if (bestcode < 3) copy3(n, bestn); else scl3(n, bestn, -1);
+    /* incident face: most anti-parallel to n */
+    int ia = 0;
+    double bd = 0;
+    for (int k = 0; k < 3; k++) { double dd = fabs(dot3(axI[k], n)); if (dd > bd) { bd = dd; ia = k; } }
+    double sgn = dot3(axI[ia], n) > 0 ? -1 : 1, fc[3];
+    addscl3(fc, I->pos, axI[ia], sgn * I->size[ia]);
+    int i1 = (ia + 1) % 3, i2 = (ia + 2) % 3;
+    double poly[16][3];
+    for (int c = 0; c < 4; c++) {
+        double s1 = (c == 0 || c == 3) ? -1 : 1, s2 = c < 2 ? -1 : 1;
+        addscl3(poly[c], fc, axI[i1], s1 * I->size[i1]);
+        addscl3(poly[c], poly[c], axI[i2], s2 * I->size[i2]);
+    }
+    int np = 4, r1 = (ra_ + 1) % 3, r2 = (ra_ + 2) % 3;
+    for (int side = 0; side < 4 && np > 0; side++) {
+        int ax = side < 2 ? r1 : r2;
+        double sg = (side & 1) ? -1 : 1, pn[3];
+        scl3(pn, axR[ax], sg);
+        np = clip_poly(poly, np, pn, dot3(pn, R->pos) + R->size[ax]);
+    }
+    double rc[3];
+    addscl3(rc, R->pos, n, R->size[ra_]);
+    int cnt = 0;
+    for (int i = 0; i < np && cnt < maxh; i++) {
+        double d_[3];
+        sub3(d_, poly[i], rc);
+        double dist = dot3(d_, n);
+        if (dist > margin) continue;
+        h[cnt].dist = dist;
+        if (bestcode < 3) copy3(h[cnt].normal, n); else scl3(h[cnt].normal, n, -1);
+        addscl3(h[cnt].pos, poly[i], n, -0.5 * dist);
+        cnt++;
+    }
+    return cnt;
+}
+
+/* ------------------------------------------- generic convex pair via MPR */
+static void support(const Shape* s, const double* dir, double* out) {
+    double dl[3], pl[3];
+    mulT(dl, s->mat, dir);
+    switch (s->type) {
+    case MJL_SPHERE:
+        scl3(pl, dl, s->size[0]);
+        break;
+    case MJL_CAPSULE:
+        scl3(pl, dl, s->size[0]);
+        pl[2] += dl[2] >= 0 ? s->size[1] : -s->size[1];
+        break;
+    case MJL_CYLINDER: {
+        double r = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+        if (r > MINVAL) { pl[0] = dl[0] / r * s->size[0]; pl[1] = dl[1] / r * s->size[0]; } else pl[0] = pl[1] = 0;
+        pl[2] = dl[2] >= 0 ? s->size[1] : -s->size[1];
+        break;
+    }
+    case MJL_BOX:
+        for (int k = 0; k < 3; k++) pl[k] = dl[k] >= 0 ? s->size[k] : -s->size[k];
+        break;
+    case MJL_MESH: {
+        int best = 0;
+        double bd = -1e30;
+        for (int i = 0; i < s->nvert; i++) {
+            double dd = dot3(s->vert + 3 * i, dl);
+            if (dd > bd) { bd = dd; best = i; }
+        }
+        copy3(pl, s->vert + 3 * best);
+        break;
+    }
+    default:
+        pl[0] = pl[1] = pl[2] = 0;
+    }
+    mul(out, s->mat, pl);
+    add3(out, out, s->pos);
+    addscl3(out, out, dir, s->margin);
+}
+typedef struct { double v[3], a[3], b[3]; } SV;   /* v = b - a */
+static void msupport(const Shape* A, const Shape* B, const double* dir, SV* o) {
+    double nd[3] = { -dir[0], -dir[1], -dir[2] };
+    support(B, dir, o->b);
+    support(A, nd, o->a);
+    sub3(o->v, o->b, o->a);
+}
+/* closest point on triangle to the origin, with barycentric weights */
+static void tri_closest_origin(const double* a, const double* b, const double* c, double* w) {
+    double ab[3], ac[3], ap[3] = { -a[0], -a[1], -a[2] };
+    sub3(ab, b, a); sub3(ac, c, a);
+    double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    if (d1 <= 0 && d2 <= 0) { w[0] = 1; w[1] = w[2] = 0; return; }
+    double bp[3] = { -b[0], -b[1], -b[2] };
+    double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { w[1] = 1; w[0] = w[2] = 0; return; }
+    double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { double v = d1 / (d1 - d3); w[0] = 1 - v; w[1] = v; w[2] = 0; return; }
+    double cp[3] = { -c[0], -c[1], -c[2] };
+    double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { w[2] = 1; w[0] = w[1] = 0; return; }
+    double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { double v = d2 / (d2 - d6); w[0] = 1 - v; w[1] = 0; w[2] = v; return; }
+    double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { double v = (d4 - d3) / ((d4 - d3) + (d5 - d6)); w[0] = 0; w[1] = 1 - v; w[2] = v; return; }
+    double den = 1 / (va + vb + vc);
+    w[1] = vb * den; w[2] = vc * den; w[0] = 1 - w[1] - w[2];
+}
+static int mpr(const Shape* A, const Shape* B, double margin, Hit* h) {
+    SV v0, v1, v2, v3, v4;
+    double dir[3], t[3], t2[3];
+    /* interior point of B-A */
+    copy3(v0.a, A->pos); copy3(v0.b, B->pos);
+    sub3(v0.v, v0.b, v0.a);
+    if (norm3(v0.v) < 1e-10) v0.v[0] = 1e-5;
+    scl3(dir, v0.v, -1); normalize3(dir);
+    msupport(A, B, dir, &v1);
+    if (dot3(v1.v, dir) <= 0) return 0;
+    cross3(dir, v1.v, v0.v);
+    if (norm3(dir) < 1e-12) {
+        /* origin on the v0-v1 ray: penetration along it */
+        double d_[3]; copy3(d_, v1.v);
+        double depth = normalize3(d_);
+        h->dist = -depth + margin;
+        scl3(h->normal, d_, -1);
+        for (int k = 0; k < 3; k++) h->pos[k] = 0.5 * (v1.a[k] + v1.b[k]);
+        return h->dist <= margin - 0 ? 1 : 0;
+    }
+    normalize3(dir);
+    msupport(A, B, dir, &v2);
+    if (dot3(v2.v, dir) <= 0) return 0;
+    sub3(t, v1.v, v0.v); sub3(t2, v2.v, v0.v);
+    cross3(dir, t, t2); normalize3(dir);
+    if (dot3(dir, v0.v) > 0) { SV tmp = v1; v1 = v2; v2 = tmp; scl3(dir, dir, -1); }
+    for (int it = 0;; it++) {
+        if (it > 100) return 0;
+        msupport(A, B, dir, &v3);
+        if (dot3(v3.v, dir) <= 0) return 0;
+        cross3(t, v1.v, v3.v);
+        if (dot3(t, v0.v) < 0) { v2 = v3; sub3(t, v1.v, v0.v); sub3(t2, v3.v, v0.v); cross3(dir, t, t2); normalize3(dir); continue; }
+        cross3(t, v3.v, v2.v);
+        if (dot3(t, v0.v) < 0) { v1 = v3; sub3(t, v3.v, v0.v); sub3(t2, v2.v, v0.v); cross3(dir, t, t2); normalize3(dir); continue; }
+        break;
+    }
+    /* portal refinement */
+    int hit = 0;
+    for (int it = 0; it < CCD_ITER * 4; it++) {
+        sub3(t, v2.v, v1.v); sub3(t2, v3.v, v1.v);
+        cross3(dir, t, t2);
+        if (normalize3(dir) == 0) break;
+        if (dot3(dir, v1.v) >= 0) hit = 1;
+        msupport(A, B, dir, &v4);
+        double dv4 = dot3(v4.v, dir);
+        if (dv4 < 0 && !hit) return 0;
+        double reach = dv4 - dot3(v1.v, dir);
+        if (reach <= CCD_TOL || it == CCD_ITER * 4 - 1) break;
+        cross3(t, v4.v, v0.v);
+        if (dot3(v1.v, t) > 0) {
+            if (dot3(v2.v, t) > 0) v1 = v4; else v3 = v4;
+        } else {
+            if (dot3(v3.v, t) > 0) v2 = v4; else v1 = v4;
+        }
+    }
+    if (!hit) return 0;
+    double w[3], cp[3];
+    tri_closest_origin(v1.v, v2.v, v3.v, w);
+    for (int k = 0; k < 3; k++) cp[k] = w[0] * v1.v[k] + w[1] * v2.v[k] + w[2] * v3.v[k];
+    double depth = norm3(cp);
+    if (depth > 1e-12) scl3(h->normal, cp, -1 / depth);
+    else scl3(h->normal, dir, -1);
+    h->dist = -depth + margin;
+    for (int k = 0; k < 3; k++)
+        h->pos[k] = 0.5 * (w[0] * (v1.a[k] + v1.b[k]) + w[1] * (v2.a[k] + v2.b[k]) + w[2] * (v3.a[k] + v3.b[k]));
+    return 1;
+}
+
+/* ------------------------------------------------------------ dispatch */
+static void make_shape(const MjlModel* m, const MjlData* d, int g, Shape* s) {
+    s->type = m->geom_type[g];
+    s->pos = d->geom_xpos + 3 * g;
+    s->mat = d->geom_xmat + 9 * g;
+    s->size = m->geom_size + 3 * g;
+    s->margin = 0;
+    s->vert = NULL; s->nvert = 0;
+    if (s->type == MJL_MESH) {
+        int mi = m->geom_meshid[g];
+        s->vert = m->mesh_vert + 3 * m->mesh_vertadr[mi];
+        s->nvert = m->mesh_vertnum[mi];
+    }
+}
+
+int mjl_collide_pair(const MjlModel* m, const MjlData* d, int g1, int g2, double margin, MjlContact* out, int maxout) {
+    Shape a, b;
+    Hit h[16];
+    make_shape(m, d, g1, &a);
+    make_shape(m, d, g2, &b);
+    int n = 0, t1 = a.type, t2 = b.type;
+    if (t1 == MJL_PLANE) {
+        if (t2 == MJL_SPHERE) n = plane_sphere(&a, &b, margin, h);
+        else if (t2 == MJL_CAPSULE) n = plane_capsule(&a, &b, margin, h);
+        else if (t2 == MJL_CYLINDER) n = plane_cylinder(&a, &b, margin, h);
+        else if (t2 == MJL_BOX) n = plane_box(&a, &b, margin, h);
+        else if (t2 == MJL_MESH) n = plane_mesh(&a, &b, margin, h);
+    } else if (t1 == MJL_SPHERE && t2 == MJL_SPHERE) n = sphere_sphere(&a, &b, margin, h);
+    else if (t1 == MJL_SPHERE && t2 == MJL_CAPSULE) n = sphere_capsule(&a, &b, margin, h);
+    else if (t1 == MJL_SPHERE && t2 == MJL_CYLINDER) n = sphere_cylinder(&a, &b, margin, h);
+    else if (t1 == MJL_SPHERE && t2 == MJL_BOX) n = sphere_box(&a, &b, margin, h);
+    else if (t1 == MJL_CAPSULE && t2 == MJL_CAPSULE) n = capsule_capsule(&a, &b, margin, h);
+    else if (t1 == MJL_BOX && t2 == MJL_BOX) n = box_box(&a, &b, margin, h, 8);
+    else {
+        a.margin = b.margin = 0.5 * margin;
+        n = mpr(&a, &b, margin, h);
+        if (n && h[0].dist > margin) n = 0;
+    }
+    if (n > maxout) n = maxout;
+    for (int i = 0; i < n; i++) {
+        memset(out + i, 0, sizeof(MjlContact));
+        out[i].geom1 = g1; out[i].geom2 = g2;
+        out[i].dist = h[i].dist;
+        memcpy(out[i].pos, h[i].pos, sizeof(double) * 3);
+        memcpy(out[i].frame, h[i].normal, sizeof(double) * 3);
+    }
+    return n;
+}
+
+static void make_frame(double* f) {
+    normalize3(f);
+    f[3] = f[4] = f[5] = 0;
+    if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+    double t = dot3(f, f + 3);
+    addscl3(f + 3, f + 3, f, -t);
+    normalize3(f + 3);
+    cross3(f + 6, f, f + 3);
+}
+
+void mjl_collision(const MjlModel* m, MjlData* d) {
+    d->ncon = 0;
+    for (int p = 0; p < m->npair; p++) {
+        int g1 = m->pair_geom[2 * p], g2 = m->pair_geom[2 * p + 1];
+        double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
+        double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+        /* bounding-sphere cull (planes have no bound) */
+        if (m->geom_type[g1] != MJL_PLANE) {
+            double t[3];
+            sub3(t, d->geom_xpos + 3 * g1, d->geom_xpos + 3 * g2);
+            double bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
+            if (dot3(t, t) > bound * bound) continue;
+        } else {
+            double n[3], t[3];
+            col3(n, d->geom_xmat + 9 * g1, 2);
+            sub3(t, d->geom_xpos + 3 * g2, d->geom_xpos + 3 * g1);
+            if (dot3(t, n) > m->geom_rbound[g2] + margin) continue;
+        }
+        int room = MJL_MAXCON - d->ncon;
+        if (room <= 0) { d->warning_overflow++; break; }
+        MjlContact* c = d->contact + d->ncon;
+        int n = mjl_collide_pair(m, d, g1, g2, margin, c, room < 8 ? room : 8);
+        for (int i = 0; i < n; i++) {
+            make_frame(c[i].frame);
+            c[i].includemargin = margin - gap;
+            /* parameter mixing (equal priorities): max condim / friction, solmix-weighted solref & solimp */
+            c[i].dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+            double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2], mix;
+            if (s1 >= MINVAL && s2 >= MINVAL) mix = s1 / (s1 + s2);
+            else if (s1 < MINVAL && s2 < MINVAL) mix = 0.5;
+            else mix = s1 < MINVAL ? 0 : 1;
+            const double *r1 = m->geom_solref + 2 * g1, *r2 = m->geom_solref + 2 * g2;
+            if (r1[0] > 0 && r2[0] > 0) for (int k = 0; k < 2; k++) c[i].solref[k] = mix * r1[k] + (1 - mix) * r2[k];
+            else for (int k = 0; k < 2; k++) c[i].solref[k] = fmin(r1[k], r2[k]);
+            for (int k = 0; k < 5; k++) c[i].solimp[k] = mix * m->geom_solimp[5 * g1 + k] + (1 - mix) * m->geom_solimp[5 * g2 + k];
+            double f[3];
+            for (int k = 0; k < 3; k++) f[k] = fmax(m->geom_friction[3 * g1 + k], m->geom_friction[3 * g2 + k]);
+            c[i].friction[0] = c[i].friction[1] = f[0]; c[i].friction[2] = f[1]; c[i].friction[3] = c[i].friction[4] = f[2];
+            c[i].efc_address = -1;
+        }
+        d->ncon += n;
+    }
+}
