@@ -1,0 +1,95 @@
+/*
+ * mwgpu.h -- C ABI of libmwgpu.so, the MI355X-native batched Meta-World runtime.
+ *
+ * The reference has no FFI for this path: its hot path sits behind the Gymnasium
+ * VectorEnv object returned by `metaworld.make_mt_envs` (metaworld/__init__.py:460-513).
+ * The entry points below are what a binding for that object needs; each cites the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions: every function returns 0 on success or a negative code; the message is
+ * available through mw_last_error().  One context per GPU, single caller thread, not
+ * re-entrant.  All host buffers are owned by the caller; device memory by the library.
+ */
+#ifndef MWGPU_H
+#define MWGPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mw_model mw_model;   /* one compiled MJCF scene (tables built by metaworld_amd/mjcf.py) */
+typedef struct mw_ctx mw_ctx;       /* device state of all environments on one GPU */
+
+#define MW_NPROBE 16
+
+typedef struct mw_config {
+    int32_t precision;             /* 0 = fp32 state/solver (throughput), 1 = fp64 (parity) */
+    int32_t device_id;             /* HIP device ordinal */
+    int32_t rank, world_size;      /* data-parallel shard of the env batch (one process per GPU) */
+    int32_t max_episode_steps;     /* gymnasium TimeLimit, metaworld/__init__.py:430 */
+    int32_t terminate_on_success;  /* AutoTerminateOnSuccessWrapper, metaworld/wrappers.py:207-230 */
+    int32_t one_hot;               /* OneHotWrapper, metaworld/wrappers.py:14-32 */
+    int32_t num_tasks;             /* one-hot width */
+} mw_config;
+
+/* Per-task constants: what the reference keeps in each SawyerXYZEnv subclass
+ * (metaworld/envs/sawyer_*_v3.py __init__ + _get_pos_objects/_get_quat_objects). */
+typedef struct mw_task {
+    int32_t kind;                  /* MT50 id (metaworld/env_dict.py:217-270) selecting reward/reset code */
+    int32_t model;                 /* index returned by mw_add_model */
+    int32_t onehot_id;             /* position in the benchmark (enumerate order, metaworld/__init__.py:504-506) */
+    int32_t probe[MW_NPROBE];      /* frames read by obs/reward, see metaworld_amd/csrc/mw_tasks.hpp */
+    int32_t nobj, quat_mode[2];
+    int32_t qadr[4], dadr[4], geom[4], reloc[2];
+    int32_t partially_observable;  /* SawyerXYZEnv._partially_observable, sawyer_xyz_env.py:217 */
+    int32_t max_path_length;       /* SawyerXYZEnv.max_path_length = 500, sawyer_xyz_env.py:153 */
+    double hand_init[3], mocap_low[3], mocap_high[3], goal_low[3], goal_high[3];
+    double obj_off[2][3];
+    double c[15];
+} mw_task;
+
+/* ---- model tables (replaces mujoco.MjModel.from_xml_path; reference call: gymnasium MujocoEnv.__init__) ---- */
+mw_model* mw_model_new(void);
+int mw_model_set_int(mw_model* m, const char* field, const int32_t* v, int n);
+int mw_model_set_real(mw_model* m, const char* field, const double* v, int n);
+int mw_model_set_option(mw_model* m, const char* name, double value);
+void mw_model_free(mw_model* m);
+
+/* ---- context (replaces make_mt_envs / SyncVectorEnv construction, metaworld/__init__.py:460-513) ---- */
+int mw_create(const mw_config* cfg, mw_ctx** out);
+int mw_add_model(mw_ctx* c, const mw_model* m);                    /* returns model index >= 0 */
+int mw_add_task(mw_ctx* c, const mw_task* t, const double* goals /*[ngoals][6] rand_vec*/, int ngoals); /* task index */
+int mw_set_envs(mw_ctx* c, const int32_t* env_task /*[n] task index per env*/, int n);
+int mw_finalize(mw_ctx* c);   /* allocates device state; runs the faithful reset once per (task, goal) -> snapshots */
+void mw_destroy(mw_ctx* c);
+const char* mw_last_error(const mw_ctx* c);
+int mw_num_envs(const mw_ctx* c);
+int mw_obs_dim(const mw_ctx* c);
+
+/* ---- VectorEnv.reset (SawyerXYZEnv.reset, sawyer_xyz_env.py:664-682; RandomTaskSelectWrapper.reset,
+ *      wrappers.py:116-119: goal_idx[i] is the task index drawn by the caller's per-env generator) ---- */
+int mw_reset(mw_ctx* c, const uint8_t* mask /*[N] or NULL = all*/, const int32_t* goal_idx /*[N]*/, double* obs_out /*[N][D]*/);
+
+/* ---- VectorEnv.step with SAME_STEP autoreset (SawyerXYZEnv.step, sawyer_xyz_env.py:579-642 + wrapper stack
+ *      metaworld/__init__.py:430-454).  next_goal[i] = goal index env i uses if it finishes in this step. ---- */
+int mw_step(mw_ctx* c, const float* actions /*[N][4]*/, const int32_t* next_goal /*[N] or NULL*/, double* obs /*[N][D]*/,
+            double* reward /*[N]*/, uint8_t* terminated, uint8_t* truncated, uint8_t* success /*[N] each*/,
+            float* info /*[N][6] near_object, grasp_success, grasp_reward, in_place_reward, obj_to_target, unscaled_reward; or NULL*/,
+            double* final_obs /*[N][D] or NULL*/, double* episode_return /*[N] or NULL*/, int32_t* episode_length /*[N] or NULL*/);
+
+/* ---- throughput path: actions resident in HBM, outputs left in HBM (bench.py) ---- */
+int mw_upload_actions(mw_ctx* c, const float* actions /*[nsteps][N][4]*/, int nsteps);
+int mw_step_resident(mw_ctx* c, int nsteps, int action_steps, float* kernel_ms /*HIP-event time of the nsteps launches*/);
+
+/* ---- state access for parity tests (mujoco data.qpos / qvel / mocap_pos, MujocoEnv.set_state) ---- */
+int mw_column_size(mw_ctx* c, int env, const char* what);
+int mw_read(mw_ctx* c, int env, const char* what, double* out, int n);
+int mw_write(mw_ctx* c, int env, const char* what, const double* in, int n);
+int mw_read_int(mw_ctx* c, int env, const char* what, int32_t* out, int n);
+int mw_debug(mw_ctx* c, int what /*0 forward, 1 n substeps, 2 resetData, 3 kinematics*/, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

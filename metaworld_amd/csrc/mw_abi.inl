@@ -1,0 +1,104 @@
+// mw_abi.inl -- C ABI implementation shared by the device library (mwgpu.hip, prefix mw_) and
+// the CPU test harness (tests/host_harness.cpp, prefix mwh_).  Requires `Backend` and MW_API(name).
+#include <cstring>
+
+struct mw_model { mw::ModelData d; };
+struct mw_ctx {
+    mw::Config cfg{};
+    std::unique_ptr<mw::ContextBase> impl;
+    std::vector<std::shared_ptr<mw::ModelData>> models;
+    std::vector<mw::TaskSpec> tasks;
+    std::vector<int> env_task;
+    std::string error;
+};
+
+#define MW_TRY(ctx, body)                                                   \
+    try { body; return 0; }                                                 \
+    catch (const std::exception& ex) { if (ctx) (ctx)->error = ex.what(); return -1; } \
+    catch (...) { if (ctx) (ctx)->error = "unknown error"; return -1; }
+
+extern "C" {
+
+mw_model* MW_API(model_new)(void) { return new mw_model(); }
+void MW_API(model_free)(mw_model* m) { delete m; }
+int MW_API(model_set_int)(mw_model* m, const char* f, const int32_t* v, int n) { m->d.ints[f].assign(v, v + n); return 0; }
+int MW_API(model_set_real)(mw_model* m, const char* f, const double* v, int n) { m->d.reals[f].assign(v, v + n); return 0; }
+int MW_API(model_set_option)(mw_model* m, const char* name, double v) {
+    std::string k = name;
+    if (k == "timestep") m->d.timestep = v; else if (k == "tolerance") m->d.tolerance = v;
+    else if (k == "meaninertia") m->d.meaninertia = v; else if (k == "gravity_z") m->d.gravity[2] = v;
+    else if (k == "iterations") m->d.sz.iterations = (int)v; else if (k == "ls_iterations") m->d.sz.ls_iterations = (int)v;
+    else if (k == "maxcon") m->d.sz.maxcon = (int)v; else if (k == "maxefc") m->d.sz.maxefc = (int)v;
+    else if (k == "nreloc") m->d.sz.nreloc = (int)v;
+    else return -1;
+    return 0;
+}
+
+int MW_API(create)(const mw_config* cfg, mw_ctx** out) {
+    mw_ctx* c = new mw_ctx();
+    c->cfg.precision = cfg->precision; c->cfg.device_id = cfg->device_id; c->cfg.rank = cfg->rank; c->cfg.world_size = cfg->world_size;
+    c->cfg.max_episode_steps = cfg->max_episode_steps; c->cfg.terminate_on_success = cfg->terminate_on_success;
+    c->cfg.one_hot = cfg->one_hot; c->cfg.num_tasks = cfg->num_tasks;
+    *out = c;
+    MW_TRY(c, Backend::init(cfg->device_id));
+}
+int MW_API(add_model)(mw_ctx* c, const mw_model* m) {
+    try {
+        auto d = std::make_shared<mw::ModelData>(m->d);
+        d->finalize();
+        if (d->sz.maxcon <= 0 || d->sz.maxefc <= 0 || d->sz.iterations <= 0) throw std::runtime_error("model options maxcon/maxefc/iterations not set");
+        if (d->sz.ls_iterations <= 0) d->sz.ls_iterations = 50;
+        c->models.push_back(d);
+        return (int)c->models.size() - 1;
+    } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
+}
+int MW_API(add_task)(mw_ctx* c, const mw_task* t, const double* goals, int ngoals) {
+    try {
+        if (t->model < 0 || t->model >= (int)c->models.size()) throw std::runtime_error("bad model index");
+        mw::TaskSpec s{};
+        s.kind = t->kind; s.model = t->model; s.nobj = t->nobj; s.partially_observable = t->partially_observable; s.max_path_length = t->max_path_length;
+        for (int k = 0; k < mw::P_COUNT; k++) s.probe[k] = t->probe[k];
+        for (int k = 0; k < 2; k++) { s.quat_mode[k] = t->quat_mode[k]; s.reloc[k] = t->reloc[k]; for (int j = 0; j < 3; j++) s.obj_off[k][j] = t->obj_off[k][j]; }
+        for (int k = 0; k < 4; k++) { s.qadr[k] = t->qadr[k]; s.dadr[k] = t->dadr[k]; s.geom[k] = t->geom[k]; }
+        for (int k = 0; k < 3; k++) { s.hand_init[k] = t->hand_init[k]; s.mocap_low[k] = t->mocap_low[k]; s.mocap_high[k] = t->mocap_high[k]; s.goal_low[k] = t->goal_low[k]; s.goal_high[k] = t->goal_high[k]; }
+        for (int k = 0; k < 15; k++) s.c[k] = t->c[k];
+        s.c[15] = t->onehot_id;
+        s.goals.assign(goals, goals + 6 * (size_t)ngoals);
+        c->tasks.push_back(s);
+        return (int)c->tasks.size() - 1;
+    } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
+}
+int MW_API(set_envs)(mw_ctx* c, const int32_t* env_task, int n) { c->env_task.assign(env_task, env_task + n); return 0; }
+int MW_API(finalize)(mw_ctx* c) {
+    MW_TRY(c, {
+        for (int t : c->env_task) if (t < 0 || t >= (int)c->tasks.size()) throw std::runtime_error("env refers to unknown task");
+        if (c->cfg.precision == 1) c->impl.reset(new mw::Context<double, Backend>());
+        else c->impl.reset(new mw::Context<float, Backend>());
+        c->impl->cfg = c->cfg; c->impl->models = c->models; c->impl->tasks = c->tasks; c->impl->env_task = c->env_task;
+        c->impl->finalize();
+    });
+}
+void MW_API(destroy)(mw_ctx* c) { delete c; }
+const char* MW_API(last_error)(const mw_ctx* c) { return c ? c->error.c_str() : "null context"; }
+int MW_API(num_envs)(const mw_ctx* c) { return (int)c->env_task.size(); }
+int MW_API(obs_dim)(const mw_ctx* c) { return 39 + (c->cfg.one_hot ? c->cfg.num_tasks : 0); }
+
+#define MW_NEED_IMPL(c) if (!(c)->impl) throw std::runtime_error("context not finalized")
+int MW_API(reset)(mw_ctx* c, const uint8_t* mask, const int32_t* goal_idx, double* obs_out) {
+    MW_TRY(c, { MW_NEED_IMPL(c); c->impl->reset(mask, goal_idx, obs_out); });
+}
+int MW_API(step)(mw_ctx* c, const float* a, const int32_t* ng, double* obs, double* rew, uint8_t* te, uint8_t* tr, uint8_t* su,
+                 float* info, double* fo, double* er, int32_t* el) {
+    MW_TRY(c, { MW_NEED_IMPL(c); c->impl->step(a, ng, obs, rew, te, tr, su, info, fo, er, el); });
+}
+int MW_API(upload_actions)(mw_ctx* c, const float* a, int nsteps) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->upload_actions(a, nsteps); }); }
+int MW_API(step_resident)(mw_ctx* c, int nsteps, int asteps, float* ms) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->step_device_only(nullptr, nsteps, asteps, ms); }); }
+int MW_API(column_size)(mw_ctx* c, int env, const char* what) {
+    try { MW_NEED_IMPL(c); return c->impl->layout_size(env, what); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
+}
+int MW_API(read)(mw_ctx* c, int env, const char* what, double* out, int n) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->read_col(env, what, n, out); }); }
+int MW_API(write)(mw_ctx* c, int env, const char* what, const double* in, int n) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->write_col(env, what, n, in); }); }
+int MW_API(read_int)(mw_ctx* c, int env, const char* what, int32_t* out, int n) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->read_icol(env, what, n, out); }); }
+int MW_API(debug)(mw_ctx* c, int what, int n) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->debug(what, n); }); }
+
+}  // extern "C"

@@ -1,0 +1,550 @@
+// mw_collide.hpp -- per-lane narrow phase for the Meta-World scenes.
+//
+// Pair list, type ordering and parameter mixing follow MuJoCo's conventions
+// (SURVEY.md Appendix B.3 / C.1 step 3): contact normal points from geom1 to
+// geom2, dist < 0 is penetration, pos is midway between the surfaces, condim and
+// friction take the max, solref/solimp are solmix-weighted, margin = max.
+// Analytic routines: plane-X, sphere-X, capsule-capsule, box-box (SAT + face
+// clipping).  Everything else (cylinders, mesh hulls, capsule-box) is one
+// Minkowski-portal-refinement routine on support functions with both shapes
+// inflated by margin/2.
+#pragma once
+#include "mw_common.hpp"
+#include "mw_phys.hpp"
+
+namespace mw {
+
+template <typename T>
+struct Shape {
+    int type;
+    V3<T> pos;
+    M3<T> mat;
+    T size[3];
+    const T* vert;
+    int nvert;
+    T margin;
+};
+template <typename T> struct Hit { T dist; V3<T> pos, normal; };
+
+template <typename T>
+MW_HD int hit_sphere_sphere(V3<T> c1, T r1, V3<T> c2, T r2, T margin, Hit<T>* h) {
+    V3<T> d = c2 - c1;
+    T len;
+    V3<T> n = normalized(d, &len);
+    const T dist = len - r1 - r2;
+    if (dist > margin) return 0;
+    h->dist = dist; h->normal = n; h->pos = c1 + n * (r1 + T(0.5) * dist);
+    return 1;
+}
+template <typename T>
+MW_HD int hit_plane_point(V3<T> n, V3<T> p0, V3<T> pt, T margin, Hit<T>* h) {
+    const T dist = dot(pt - p0, n);
+    if (dist > margin) return 0;
+    h->dist = dist; h->normal = n; h->pos = pt - n * (T(0.5) * dist);
+    return 1;
+}
+
+template <typename T>
+MW_HD int plane_x(const Shape<T>& p, const Shape<T>& s, T margin, Hit<T>* h) {
+    const V3<T> n = col(p.mat, 2);
+    int cnt = 0;
+    if (s.type == G_SPHERE) {
+        const T dist = dot(s.pos - p.pos, n) - s.size[0];
+        if (dist > margin) return 0;
+        h->dist = dist; h->normal = n; h->pos = s.pos - n * (s.size[0] + T(0.5) * dist);
+        return 1;
+    }
+    if (s.type == G_CAPSULE) {
+        const V3<T> ax = col(s.mat, 2);
+        for (int sg = -1; sg <= 1; sg += 2) {
+            const V3<T> c = s.pos + ax * (T(sg) * s.size[1]);
+            const T dist = dot(c - p.pos, n) - s.size[0];
+            if (dist > margin) continue;
+            h[cnt].dist = dist; h[cnt].normal = n; h[cnt].pos = c - n * (s.size[0] + T(0.5) * dist);
+            cnt++;
+        }
+        return cnt;
+    }
+    if (s.type == G_CYLINDER) {
+        V3<T> ax = col(s.mat, 2);
+        T prj = dot(n, ax);
+        if (prj > 0) { ax = -ax; prj = -prj; }
+        V3<T> vec = ax * prj - n;
+        const T len = norm(vec), r = s.size[0], hh = s.size[1];
+        if (len < T(1e-12)) vec = col(s.mat, 0) * r; else vec = vec * (r / len);
+        cnt += hit_plane_point(n, p.pos, s.pos + ax * hh + vec, margin, h + cnt);
+        if (!cnt) return 0;
+        cnt += hit_plane_point(n, p.pos, s.pos - ax * hh + vec, margin, h + cnt);
+        V3<T> v1 = normalized(cross(vec, ax)) * (r * T(0.86602540378443865));
+        for (int sg = -1; sg <= 1; sg += 2)
+            cnt += hit_plane_point(n, p.pos, s.pos + ax * hh - vec * T(0.5) + v1 * T(sg), margin, h + cnt);
+        return cnt;
+    }
+    if (s.type == G_BOX) {
+        for (int i = 0; i < 8 && cnt < 4; i++) {
+            V3<T> loc{(i & 1 ? 1 : -1) * s.size[0], (i & 2 ? 1 : -1) * s.size[1], (i & 4 ? 1 : -1) * s.size[2]};
+            cnt += hit_plane_point(n, p.pos, s.pos + s.mat * loc, margin, h + cnt);
+        }
+        return cnt;
+    }
+    if (s.type == G_MESH) {
+        const V3<T> nl = mulT(s.mat, n);
+        const T base = dot(s.pos - p.pos, n);
+        int idx[4];
+        T dd[4];
+        for (int i = 0; i < s.nvert; i++) {
+            const T dist = base + dot(mv3(s.vert + 3 * i), nl);
+            if (dist > margin) continue;
+            int k = cnt < 4 ? cnt++ : -1;
+            if (k < 0) {
+                int worst = 0;
+                for (int j = 1; j < 4; j++) if (dd[j] > dd[worst]) worst = j;
+                if (dist < dd[worst]) k = worst; else continue;
+            }
+            idx[k] = i; dd[k] = dist;
+        }
+        for (int k = 0; k < cnt; k++) {
+            const V3<T> pt = s.pos + s.mat * mv3(s.vert + 3 * idx[k]);
+            h[k].dist = dd[k]; h[k].normal = n; h[k].pos = pt - n * (T(0.5) * dd[k]);
+        }
+        return cnt;
+    }
+    return 0;
+}
+
+template <typename T>
+MW_HD int sphere_x(const Shape<T>& s, const Shape<T>& o, T margin, Hit<T>* h) {
+    const T rs = s.size[0];
+    if (o.type == G_SPHERE) return hit_sphere_sphere(s.pos, rs, o.pos, o.size[0], margin, h);
+    if (o.type == G_CAPSULE) {
+        const V3<T> ax = col(o.mat, 2);
+        const T x = mw_clamp(dot(s.pos - o.pos, ax), -o.size[1], o.size[1]);
+        return hit_sphere_sphere(s.pos, rs, o.pos + ax * x, o.size[0], margin, h);
+    }
+    if (o.type == G_CYLINDER) {
+        const V3<T> ax = col(o.mat, 2), t = s.pos - o.pos;
+        const T x = dot(t, ax), R = o.size[0], hh = o.size[1];
+        const V3<T> perp = t - ax * x;
+        const T r = norm(perp);
+        if (mw_abs(x) <= hh && r >= T(1e-15) && (R - r) < (hh - mw_abs(x)))
+            return hit_sphere_sphere(s.pos, rs, o.pos + ax * x, R, margin, h);
+        const T sg = x >= 0 ? T(1) : T(-1);
+        if (r <= R) {
+            const T dist = mw_abs(x) - hh - rs;
+            if (dist > margin) return 0;
+            h->dist = dist; h->normal = ax * (-sg); h->pos = s.pos + h->normal * (rs + T(0.5) * dist);
+            return 1;
+        }
+        return hit_sphere_sphere(s.pos, rs, o.pos + ax * (sg * hh) + perp * (R / r), T(0), margin, h);
+    }
+    if (o.type == G_BOX) {
+        const V3<T> loc = mulT(o.mat, s.pos - o.pos);
+        T l[3] = {loc.x, loc.y, loc.z}, cl[3];
+        bool inside = true;
+        for (int k = 0; k < 3; k++) { cl[k] = mw_clamp(l[k], -o.size[k], o.size[k]); inside &= cl[k] == l[k]; }
+        if (!inside) return hit_sphere_sphere(s.pos, rs, o.pos + o.mat * v3(cl[0], cl[1], cl[2]), T(0), margin, h);
+        int best = 0;
+        T bd = T(1e30);
+        for (int k = 0; k < 3; k++) { const T dd = o.size[k] - mw_abs(l[k]); if (dd < bd) { bd = dd; best = k; } }
+        T nl[3] = {0, 0, 0};
+        nl[best] = l[best] >= 0 ? T(-1) : T(1);
+        h->normal = o.mat * v3(nl[0], nl[1], nl[2]);
+        h->dist = -bd - rs;
+        h->pos = s.pos + h->normal * (rs + T(0.5) * h->dist);
+        return 1;
+    }
+    return -1;  // not analytic: caller falls back to MPR
+}
+
+template <typename T>
+MW_HD int capsule_capsule(const Shape<T>& a, const Shape<T>& b, T margin, Hit<T>* h) {
+    const V3<T> ua = col(a.mat, 2), ub = col(b.mat, 2), w = a.pos - b.pos;
+    const T la = a.size[1], lb = b.size[1];
+    const T ab = dot(ua, ub), aw = dot(ua, w), bw = dot(ub, w), det = 1 - ab * ab;
+    if (mw_abs(det) < T(1e-10)) {
+        T e0 = -aw - ab * lb, e1 = -aw + ab * lb;
+        if (e0 > e1) { const T t = e0; e0 = e1; e1 = t; }
+        T s0 = mw_max(-la, e0), s1 = mw_min(la, e1);
+        if (s0 > s1) s0 = s1 = mw_clamp(T(0.5) * (e0 + e1), -la, la);
+        const T ss[2] = {s0, s1};
+        int cnt = 0;
+        for (int k = 0; k < (s1 - s0 > T(1e-9) ? 2 : 1); k++) {
+            const V3<T> pa = a.pos + ua * ss[k];
+            const T tb = mw_clamp(dot(pa - b.pos, ub), -lb, lb);
+            cnt += hit_sphere_sphere(pa, a.size[0], b.pos + ub * tb, b.size[0], margin, h + cnt);
+        }
+        return cnt;
+    }
+    T s = mw_clamp((ab * bw - aw) / det, -la, la);
+    T t = bw + ab * s;
+    if (t < -lb) { t = -lb; s = mw_clamp(-aw + ab * t, -la, la); }
+    else if (t > lb) { t = lb; s = mw_clamp(-aw + ab * t, -la, la); }
+    return hit_sphere_sphere(a.pos + ua * s, a.size[0], b.pos + ub * t, b.size[0], margin, h);
+}
+
+// keep the part of the polygon with pn.x <= pd
+template <typename T>
+MW_HD int clip_poly(V3<T>* poly, int n, V3<T> pn, T pd) {
+    V3<T> out[16];
+    int mcount = 0;
+    for (int i = 0; i < n; i++) {
+        const V3<T> a = poly[i], b = poly[(i + 1) % n];
+        const T da = dot(pn, a) - pd, db = dot(pn, b) - pd;
+        if (da <= 0) out[mcount++] = a;
+        if ((da < 0 && db > 0) || (da > 0 && db < 0)) { out[mcount++] = a + (b - a) * (da / (da - db)); }
+        if (mcount >= 15) break;
+    }
+    for (int i = 0; i < mcount; i++) poly[i] = out[i];
+    return mcount;
+}
+
+template <typename T>
+MW_HD int box_box(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, int maxh) {
+    V3<T> axA[3], axB[3];
+    for (int k = 0; k < 3; k++) { axA[k] = col(A.mat, k); axB[k] = col(B.mat, k); }
+    const V3<T> t = B.pos - A.pos;
+    T bestsep = T(-1e30);
+    V3<T> bestn{1, 0, 0};
+    int bestcode = -1;
+    for (int i = 0; i < 6; i++) {
+        const V3<T> Lx = i < 3 ? axA[i] : axB[i - 3];
+        T ra = 0, rb = 0;
+        for (int k = 0; k < 3; k++) { ra += A.size[k] * mw_abs(dot(axA[k], Lx)); rb += B.size[k] * mw_abs(dot(axB[k], Lx)); }
+        const T tl = dot(t, Lx), sep = mw_abs(tl) - ra - rb;
+        if (sep > margin) return 0;
+        if (sep > bestsep) { bestsep = sep; bestcode = i; bestn = Lx * (tl >= 0 ? T(1) : T(-1)); }
+    }
+    T edgesep = T(-1e30);
+    V3<T> edgen{1, 0, 0};
+    int ei = -1, ej = -1;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            V3<T> Lx = cross(axA[i], axB[j]);
+            const T len = norm(Lx);
+            if (len < T(1e-6)) continue;
+            Lx = Lx * (1 / len);
+            T ra = 0, rb = 0;
+            for (int k = 0; k < 3; k++) { ra += A.size[k] * mw_abs(dot(axA[k], Lx)); rb += B.size[k] * mw_abs(dot(axB[k], Lx)); }
+            const T tl = dot(t, Lx), sep = mw_abs(tl) - ra - rb;
+            if (sep > margin) return 0;
+            if (sep > edgesep) { edgesep = sep; ei = i; ej = j; edgen = Lx * (tl >= 0 ? T(1) : T(-1)); }
+        }
+    if (ei >= 0 && edgesep > bestsep + T(1e-6) + T(0.05) * mw_abs(bestsep)) {
+        V3<T> pa = A.pos, pb = B.pos;
+        for (int k = 0; k < 3; k++) {
+            if (k != ei) pa = pa + axA[k] * ((dot(axA[k], edgen) > 0 ? T(1) : T(-1)) * A.size[k]);
+            if (k != ej) pb = pb + axB[k] * ((dot(axB[k], edgen) > 0 ? T(-1) : T(1)) * B.size[k]);
+        }
+        const V3<T> ua = axA[ei], ub = axB[ej], w = pa - pb;
+        const T ab = dot(ua, ub), aw = dot(ua, w), bw = dot(ub, w), det = 1 - ab * ab;
+        const T s = mw_clamp((ab * bw - aw) / det, -A.size[ei], A.size[ei]);
+        const T u = mw_clamp((bw - ab * aw) / det, -B.size[ej], B.size[ej]);
+        h->dist = edgesep; h->normal = edgen; h->pos = ((pa + ua * s) + (pb + ub * u)) * T(0.5);
+        return 1;
+    }
+    const bool refA = bestcode < 3;
+    const Shape<T>& Rf = refA ? A : B;
+    const Shape<T>& In = refA ? B : A;
+    const V3<T>* axR = refA ? axA : axB;
+    const V3<T>* axI = refA ? axB : axA;
+    const int ra_ = bestcode % 3;
+    const V3<T> n = refA ? bestn : -bestn;   // reference-face normal toward the incident box
+    int ia = 0;
+    T bd = 0;
+    for (int k = 0; k < 3; k++) { const T dd = mw_abs(dot(axI[k], n)); if (dd > bd) { bd = dd; ia = k; } }
+    const T sgn = dot(axI[ia], n) > 0 ? T(-1) : T(1);
+    const V3<T> fc = In.pos + axI[ia] * (sgn * In.size[ia]);
+    const int i1 = (ia + 1) % 3, i2 = (ia + 2) % 3;
+    V3<T> poly[16];
+    for (int c = 0; c < 4; c++) {
+        const T s1 = (c == 0 || c == 3) ? T(-1) : T(1), s2 = c < 2 ? T(-1) : T(1);
+        poly[c] = fc + axI[i1] * (s1 * In.size[i1]) + axI[i2] * (s2 * In.size[i2]);
+    }
+    int np = 4;
+    const int r1 = (ra_ + 1) % 3, r2 = (ra_ + 2) % 3;
+    for (int side = 0; side < 4 && np > 0; side++) {
+        const int ax = side < 2 ? r1 : r2;
+        const V3<T> pn = axR[ax] * ((side & 1) ? T(-1) : T(1));
+        np = clip_poly(poly, np, pn, dot(pn, Rf.pos) + Rf.size[ax]);
+    }
+    const V3<T> rc = Rf.pos + n * Rf.size[ra_];
+    int cnt = 0;
+    for (int i = 0; i < np && cnt < maxh; i++) {
+        const T dist = dot(poly[i] - rc, n);
+        if (dist > margin) continue;
+        h[cnt].dist = dist; h[cnt].normal = refA ? n : -n; h[cnt].pos = poly[i] - n * (T(0.5) * dist);
+        cnt++;
+    }
+    return cnt;
+}
+
+// ------------------------------------------------------------ MPR on support functions
+template <typename T>
+MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
+    const V3<T> dl = mulT(s.mat, dir);
+    V3<T> pl{0, 0, 0};
+    switch (s.type) {
+    case G_SPHERE: pl = dl * s.size[0]; break;
+    case G_CAPSULE: pl = dl * s.size[0]; pl.z += dl.z >= 0 ? s.size[1] : -s.size[1]; break;
+    case G_CYLINDER: {
+        const T r = mw_sqrt(dl.x * dl.x + dl.y * dl.y);
+        if (r > T(1e-15)) { pl.x = dl.x / r * s.size[0]; pl.y = dl.y / r * s.size[0]; }
+        pl.z = dl.z >= 0 ? s.size[1] : -s.size[1];
+        break;
+    }
+    case G_BOX:
+        pl = v3(dl.x >= 0 ? s.size[0] : -s.size[0], dl.y >= 0 ? s.size[1] : -s.size[1], dl.z >= 0 ? s.size[2] : -s.size[2]);
+        break;
+    case G_MESH: {
+        int best = 0;
+        T bd = T(-1e30);
+        for (int i = 0; i < s.nvert; i++) {
+            const T dd = s.vert[3 * i] * dl.x + s.vert[3 * i + 1] * dl.y + s.vert[3 * i + 2] * dl.z;
+            if (dd > bd) { bd = dd; best = i; }
+        }
+        pl = mv3(s.vert + 3 * best);
+        break;
+    }
+    default: break;
+    }
+    return s.pos + s.mat * pl + dir * s.margin;
+}
+template <typename T> struct SV { V3<T> v, a, b; };
+template <typename T>
+MW_HD SV<T> msupport(const Shape<T>& A, const Shape<T>& B, V3<T> dir) {
+    SV<T> o;
+    o.b = support(B, dir);
+    o.a = support(A, -dir);
+    o.v = o.b - o.a;
+    return o;
+}
+template <typename T>
+MW_HD void tri_closest_origin(V3<T> a, V3<T> b, V3<T> c, T* w) {
+    const V3<T> ab = b - a, ac = c - a, ap = -a;
+    const T d1 = dot(ab, ap), d2 = dot(ac, ap);
+    if (d1 <= 0 && d2 <= 0) { w[0] = 1; w[1] = w[2] = 0; return; }
+    const V3<T> bp = -b;
+    const T d3 = dot(ab, bp), d4 = dot(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { w[1] = 1; w[0] = w[2] = 0; return; }
+    const T vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { const T v = d1 / (d1 - d3); w[0] = 1 - v; w[1] = v; w[2] = 0; return; }
+    const V3<T> cp = -c;
+    const T d5 = dot(ab, cp), d6 = dot(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { w[2] = 1; w[0] = w[1] = 0; return; }
+    const T vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { const T v = d2 / (d2 - d6); w[0] = 1 - v; w[1] = 0; w[2] = v; return; }
+    const T va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const T v = (d4 - d3) / ((d4 - d3) + (d5 - d6)); w[0] = 0; w[1] = 1 - v; w[2] = v; return; }
+    const T den = 1 / (va + vb + vc);
+    w[1] = vb * den; w[2] = vc * den; w[0] = 1 - w[1] - w[2];
+}
+template <typename T>
+MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V3<T>* v0_override = nullptr) {
+    const T tol = sizeof(T) == 8 ? T(1e-6) : T(1e-5);
+    SV<T> v0, v1, v2, v3_, v4;
+    v0.a = A.pos; v0.b = B.pos; v0.v = v0.b - v0.a;
+    if (v0_override) v0.v = *v0_override;
+    if (norm(v0.v) < T(1e-10)) v0.v.x = T(1e-5);
+    V3<T> dir = normalized(-v0.v);
+    v1 = msupport(A, B, dir);
+    if (dot(v1.v, dir) <= 0) return 0;
+    dir = cross(v1.v, v0.v);
+    if (norm(dir) < T(1e-12)) {
+        T depth;
+        const V3<T> d_ = normalized(v1.v, &depth);
+        h->dist = -depth + margin; h->normal = -d_; h->pos = (v1.a + v1.b) * T(0.5);
+        return 1;
+    }
+    dir = normalized(dir);
+    v2 = msupport(A, B, dir);
+    if (dot(v2.v, dir) <= 0) return 0;
+    dir = normalized(cross(v1.v - v0.v, v2.v - v0.v));
+    if (dot(dir, v0.v) > 0) { const SV<T> tmp = v1; v1 = v2; v2 = tmp; dir = -dir; }
+    for (int it = 0;; it++) {
+        if (it > 100) return 0;
+        v3_ = msupport(A, B, dir);
+        if (dot(v3_.v, dir) <= 0) return 0;
+        if (dot(cross(v1.v, v3_.v), v0.v) < 0) { v2 = v3_; dir = normalized(cross(v1.v - v0.v, v3_.v - v0.v)); continue; }
+        if (dot(cross(v3_.v, v2.v), v0.v) < 0) { v1 = v3_; dir = normalized(cross(v3_.v - v0.v, v2.v - v0.v)); continue; }
+        break;
+    }
+    bool hit = false;
+    const int maxit = 200;
+    for (int it = 0; it < maxit; it++) {
+        T len;
+        dir = normalized(cross(v2.v - v1.v, v3_.v - v1.v), &len);
+        if (len == 0) break;
+        if (dot(dir, v1.v) >= 0) hit = true;
+        v4 = msupport(A, B, dir);
+        const T dv4 = dot(v4.v, dir);
+        if (dv4 < 0 && !hit) return 0;
+        if (dv4 - dot(v1.v, dir) <= tol || it == maxit - 1) break;
+        const V3<T> t = cross(v4.v, v0.v);
+        if (dot(v1.v, t) > 0) { if (dot(v2.v, t) > 0) v1 = v4; else v3_ = v4; }
+        else { if (dot(v3_.v, t) > 0) v2 = v4; else v1 = v4; }
+    }
+    if (!hit) return 0;
+    T w[3];
+    tri_closest_origin(v1.v, v2.v, v3_.v, w);
+    const V3<T> cp = v1.v * w[0] + v2.v * w[1] + v3_.v * w[2];
+    const T depth = norm(cp);
+    h->normal = depth > T(1e-12) ? cp * (T(-1) / depth) : -dir;
+    h->dist = -depth + margin;
+    h->pos = ((v1.a + v1.b) * w[0] + (v2.a + v2.b) * w[1] + (v3_.a + v3_.b) * w[2]) * T(0.5);
+    return 1;
+}
+
+// MPR's penetration direction depends on the interior ray (centre to centre): re-shoot the ray along the
+// normal just found until the depth stops decreasing (local minimum-translation direction).
+template <typename T>
+MW_HD int mpr_refined(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h) {
+    if (!mpr(A, B, margin, h)) return 0;
+    for (int it = 0; it < 4; it++) {
+        const T depth = margin - h->dist;
+        if (depth <= T(1e-9)) break;
+        const V3<T> v0 = h->normal * (T(0.02) * depth);
+        Hit<T> h2;
+        if (!mpr(A, B, margin, &h2, &v0)) break;
+        const T d2 = margin - h2.dist;
+        if (d2 >= depth * (1 - T(1e-6))) break;
+        *h = h2;
+    }
+    return 1;
+}
+
+// A cylinder / capsule touching the interior of a box face: replace the single MPR point by the multi-point
+// plane-cylinder / plane-capsule contact against that face (well-conditioned resting and grasp contacts).
+template <typename T>
+MW_HD int face_upgrade(const Shape<T>& c, const Shape<T>& box, Hit<T>* h, T margin) {
+    const V3<T> n = h[0].normal;
+    int k = -1;
+    T best = 0;
+    for (int i = 0; i < 3; i++) {
+        const T cth = dot(col(box.mat, i), n);
+        if (mw_abs(cth) > mw_abs(best)) { best = cth; k = i; }
+    }
+    if (mw_abs(best) < 1 - T(1e-4)) return 0;
+    const V3<T> nf = col(box.mat, k) * (best > 0 ? T(-1) : T(1));
+    V3<T> fy = (nf.y < T(0.5) && nf.y > T(-0.5)) ? v3<T>(0, 1, 0) : v3<T>(0, 0, 1);
+    fy = normalized(fy - nf * dot(nf, fy));
+    const V3<T> fz = cross(nf, fy);
+    Shape<T> pl;
+    pl.type = G_PLANE; pl.pos = box.pos + nf * box.size[k];
+    pl.mat.m[0] = fy.x; pl.mat.m[1] = fz.x; pl.mat.m[2] = nf.x;
+    pl.mat.m[3] = fy.y; pl.mat.m[4] = fz.y; pl.mat.m[5] = nf.y;
+    pl.mat.m[6] = fy.z; pl.mat.m[7] = fz.z; pl.mat.m[8] = nf.z;
+    pl.size[0] = pl.size[1] = pl.size[2] = 0; pl.vert = nullptr; pl.nvert = 0; pl.margin = 0;
+    Hit<T> t[8];
+    const int cnt = plane_x(pl, c, margin, t);
+    int mcount = 0;
+    for (int i = 0; i < cnt; i++) {
+        const V3<T> d_ = t[i].pos - box.pos;
+        bool inside = true;
+        for (int j = 0; j < 3; j++)
+            if (j != k && mw_abs(dot(d_, col(box.mat, j))) > box.size[j] + T(1e-9)) inside = false;
+        if (!inside) { if (i == 0) return 0; continue; }
+        t[mcount] = t[i];
+        t[mcount].normal = -nf;
+        mcount++;
+    }
+    for (int i = 0; i < mcount; i++) h[i] = t[i];
+    return mcount;
+}
+
+template <typename T>
+MW_HD Shape<T> make_shape(const Env<T>& e, int g) {
+    const Model<T>& m = *e.m;
+    Shape<T> s;
+    s.type = m.geom_type[g];
+    s.pos = ld3(e, e.L.geom_xpos + 3 * g);
+    s.mat = ld9(e, e.L.geom_xmat + 9 * g);
+    for (int k = 0; k < 3; k++) s.size[k] = m.geom_size[3 * g + k];
+    s.margin = 0; s.vert = nullptr; s.nvert = 0;
+    if (s.type == G_MESH) {
+        const int mi = m.geom_meshid[g];
+        s.vert = m.mesh_vert + 3 * m.mesh_vertadr[mi];
+        s.nvert = m.mesh_vertnum[mi];
+    }
+    return s;
+}
+
+template <typename T>
+MW_HD int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h) {
+    const int t1 = a_.type, t2 = b_.type;
+    int n = -1;
+    if (t1 == G_PLANE) n = plane_x(a_, b_, margin, h);
+    else if (t1 == G_SPHERE) n = sphere_x(a_, b_, margin, h);
+    else if (t1 == G_CAPSULE && t2 == G_CAPSULE) n = capsule_capsule(a_, b_, margin, h);
+    else if (t1 == G_BOX && t2 == G_BOX) n = box_box(a_, b_, margin, h, 8);
+    if (n < 0) {
+        Shape<T> a = a_, b = b_;
+        a.margin = b.margin = T(0.5) * margin;
+        n = mpr_refined(a, b, margin, h);
+        if (n && (t1 == G_CYLINDER || t1 == G_CAPSULE) && t2 == G_BOX) {
+            const int k = face_upgrade(a_, b_, h, margin);
+            if (k) n = k;
+        }
+    }
+    return n;
+}
+
+template <typename T>
+MW_HD void collision(const Env<T>& e) {
+    const Model<T>& m = *e.m;
+    const Layout& L = e.L;
+    int ncon = 0;
+    for (int p = 0; p < m.sz.npair; p++) {
+        const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+        const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
+        const V3<T> p1 = ld3(e, L.geom_xpos + 3 * g1), p2 = ld3(e, L.geom_xpos + 3 * g2);
+        if (m.geom_type[g1] != G_PLANE) {
+            const T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
+            const V3<T> t = p1 - p2;
+            if (dot(t, t) > bound * bound) continue;
+        } else {
+            const V3<T> n{e.R(L.geom_xmat + 9 * g1 + 2), e.R(L.geom_xmat + 9 * g1 + 5), e.R(L.geom_xmat + 9 * g1 + 8)};
+            if (dot(p2 - p1, n) > m.geom_rbound[g2] + margin) continue;
+        }
+        if (ncon >= m.sz.maxcon) { e.I(L.icount + 3) |= 2; break; }
+        Hit<T> h[16];
+        int n = collide_pair(make_shape(e, g1), make_shape(e, g2), margin, h);
+        if (n > m.sz.maxcon - ncon) { n = m.sz.maxcon - ncon; e.I(L.icount + 3) |= 2; }
+        if (n <= 0) continue;
+        // mixed contact parameters (equal priorities)
+        const T gap = mw_max(m.geom_gap[g1], m.geom_gap[g2]);
+        const int dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
+        const T s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
+        T mix;
+        if (s1 >= T(1e-15) && s2 >= T(1e-15)) mix = s1 / (s1 + s2);
+        else if (s1 < T(1e-15) && s2 < T(1e-15)) mix = T(0.5);
+        else mix = s1 < T(1e-15) ? T(0) : T(1);
+        T solref[2], solimp[5], fr[3];
+        const T *r1 = m.geom_solref + 2 * g1, *r2 = m.geom_solref + 2 * g2;
+        for (int k = 0; k < 2; k++) solref[k] = (r1[0] > 0 && r2[0] > 0) ? mix * r1[k] + (1 - mix) * r2[k] : mw_min(r1[k], r2[k]);
+        for (int k = 0; k < 5; k++) solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
+        for (int k = 0; k < 3; k++) fr[k] = mw_max(m.geom_friction[3 * g1 + k], m.geom_friction[3 * g2 + k]);
+        for (int i = 0; i < n; i++) {
+            const int c = ncon + i;
+            // frame: normal, then the MuJoCo tangent construction
+            V3<T> nx = normalized(h[i].normal);
+            V3<T> ny = (nx.y < T(0.5) && nx.y > T(-0.5)) ? v3<T>(0, 1, 0) : v3<T>(0, 0, 1);
+            ny = normalized(ny - nx * dot(nx, ny));
+            const V3<T> nz = cross(nx, ny);
+            CON(e, c, 0) = h[i].dist;
+            CON(e, c, 1) = h[i].pos.x; CON(e, c, 2) = h[i].pos.y; CON(e, c, 3) = h[i].pos.z;
+            CON(e, c, 4) = nx.x; CON(e, c, 5) = nx.y; CON(e, c, 6) = nx.z;
+            CON(e, c, 7) = ny.x; CON(e, c, 8) = ny.y; CON(e, c, 9) = ny.z;
+            CON(e, c, 10) = nz.x; CON(e, c, 11) = nz.y; CON(e, c, 12) = nz.z;
+            CON(e, c, 13) = margin - gap;
+            CON(e, c, 14) = fr[0]; CON(e, c, 15) = fr[1]; CON(e, c, 16) = fr[2];
+            CON(e, c, 17) = solref[0]; CON(e, c, 18) = solref[1];
+            for (int k = 0; k < 5; k++) CON(e, c, 19 + k) = solimp[k];
+            CON(e, c, 24) = fr[0];
+            ICON(e, c, 0) = g1; ICON(e, c, 1) = g2; ICON(e, c, 2) = dim; ICON(e, c, 3) = -1;
+        }
+        ncon += n;
+    }
+    e.I(L.icount) = ncon;
+}
+
+}  // namespace mw

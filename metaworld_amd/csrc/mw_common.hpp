@@ -1,0 +1,195 @@
+// mw_common.hpp -- shared definitions for the MI355X batched Meta-World runtime.
+//
+// Execution model: ONE ENVIRONMENT PER LANE.  All per-environment data (persistent
+// state and scratch) lives in a struct-of-arrays "column store": element `i` of
+// environment `e` of a group is at  col[i * stride + e]  so that the 64 lanes of a
+// wavefront touch 64 consecutive words (fully coalesced 256 B / 512 B requests).
+// Every wavefront is model-uniform (groups are per compiled model), so the
+// model tables below are read at wave-uniform addresses (scalar/broadcast loads).
+//
+// The same headers compile for the device (hipcc, gfx950) and -- for tests only --
+// for the host (g++), where a plain loop over lanes replaces the wavefront.  The
+// host build is a test harness (tests/host_harness.cpp); the product path is the
+// HIP library and nothing falls back to the CPU.
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MW_HD __host__ __device__ inline
+#else
+#define MW_HD inline
+#endif
+
+namespace mw {
+
+enum { G_PLANE = 0, G_HFIELD, G_SPHERE, G_CAPSULE, G_ELLIPSOID, G_CYLINDER, G_BOX, G_MESH };
+enum { J_FREE = 0, J_BALL, J_SLIDE, J_HINGE };
+enum { C_EQUALITY = 0, C_LIMIT = 3, C_CONTACT = 7 };
+enum { S_SATISFIED = 0, S_QUADRATIC = 1, S_CONE = 4 };
+
+constexpr int MAX_NV = 24;       // per-lane register vectors are sized by this
+constexpr int CON_STRIDE = 26;   // reals per contact record
+constexpr int CON_ISTRIDE = 4;   // ints per contact record
+constexpr int EFC_EXTRA = 8;     // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv
+constexpr int EFC_ISTRIDE = 3;   // type, id, state
+
+struct Sizes {
+    int nq, nv, nbody, njnt, ngeom, nsite, nmesh, nmeshvert, npair, nu, neq, nprobe, nreloc;
+    int maxcon, maxefc, iterations, ls_iterations;
+};
+
+// Device-resident model tables (one per compiled MJCF scene).  Field names follow
+// metaworld_amd/mjcf.py (which follows MuJoCo's mjModel).
+template <typename T>
+struct Model {
+    Sizes sz;
+    T timestep, tolerance, meaninertia, gravity[3];
+    // ints
+    const int *body_parentid, *body_mocap, *body_jntadr, *body_jntnum, *body_lastdof, *body_relocid;
+    const int *jnt_type, *jnt_bodyid, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
+    const int *dof_bodyid, *dof_jntid, *dof_parentid;
+    const int *geom_type, *geom_bodyid, *geom_meshid, *geom_condim;
+    const int *mesh_vertadr, *mesh_vertnum, *pair_geom;
+    const int *act_dofid, *act_qposid, *eq_body1, *eq_body2, *probe_body;
+    // reals
+    const T *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia;
+    const T *jnt_pos, *jnt_axis, *jnt_range, *jnt_stiffness, *jnt_springref, *jnt_solref, *jnt_solimp, *jnt_margin;
+    const T *dof_armature, *dof_damping, *dof_invweight0, *qpos0;
+    const T *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solref, *geom_solimp, *geom_solmix;
+    const T *geom_margin, *geom_gap, *geom_rbound, *geom_invweight0;
+    const T *mesh_vert, *act_kp, *act_ctrlrange, *eq_solref, *eq_solimp, *eq_data, *eq_invweight0;
+    const T *probe_pos, *probe_quat;
+};
+
+// Offsets (in elements) of every per-environment array inside the column store.
+struct Layout {
+    // persistent state
+    int qpos, qvel, warm, ctrl, mocap, reloc, time, task;   // task: TASK_NREAL reals of task/episode state
+    int nstate;                                              // number of persistent reals
+    // scratch
+    int xpos, xquat, xmat, xipos, cinert, crb, geom_xpos, geom_xmat, cdof, qM, qL, qH;
+    int cvel, cacc, cfrc, bias, smooth, qacc_smooth, qfrc_c, qacc, Ma, grad, search, Mv;
+    int con, efcJ, efcX;
+    int nreal;
+    // int columns
+    int icon, iefc, icount;   // icount: ncon, nefc, niter, flags
+    int nint;
+};
+
+constexpr int TASK_NREAL = 96;   // per-env task/episode block, see mw_tasks.hpp
+
+inline Layout make_layout(const Sizes& s) {
+    Layout L;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += n; return r; };
+    L.qpos = take(s.nq); L.qvel = take(s.nv); L.warm = take(s.nv); L.ctrl = take(s.nu > 0 ? s.nu : 1);
+    L.mocap = take(3); L.reloc = take(3 * (s.nreloc > 0 ? s.nreloc : 1)); L.time = take(1); L.task = take(TASK_NREAL);
+    L.nstate = o;
+    L.xpos = take(3 * s.nbody); L.xquat = take(4 * s.nbody); L.xmat = take(9 * s.nbody); L.xipos = take(3 * s.nbody);
+    L.cinert = take(10 * s.nbody); L.crb = take(10 * s.nbody);
+    L.geom_xpos = take(3 * s.ngeom); L.geom_xmat = take(9 * s.ngeom);
+    L.cdof = take(6 * s.nv); L.qM = take(s.nv * s.nv); L.qL = take(s.nv * s.nv); L.qH = take(s.nv * s.nv);
+    L.cvel = take(6 * s.nbody); L.cacc = take(6 * s.nbody); L.cfrc = take(6 * s.nbody);
+    L.bias = take(s.nv); L.smooth = take(s.nv); L.qacc_smooth = take(s.nv); L.qfrc_c = take(s.nv); L.qacc = take(s.nv);
+    L.Ma = take(s.nv); L.grad = take(s.nv); L.search = take(s.nv); L.Mv = take(s.nv);
+    L.con = take(CON_STRIDE * s.maxcon);
+    L.efcJ = take(s.nv * s.maxefc);
+    L.efcX = take(EFC_EXTRA * s.maxefc);
+    L.nreal = o;
+    o = 0;
+    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(4);
+    L.nint = o;
+    return L;
+}
+
+// Per-lane view of one environment.
+template <typename T>
+struct Env {
+    const Model<T>* m;
+    Layout L;
+    T* col;        // real column store, already offset by the lane
+    int* icol;     // int column store, already offset by the lane
+    size_t stride;
+    MW_HD T& R(int i) const { return col[(size_t)i * stride]; }
+    MW_HD int& I(int i) const { return icol[(size_t)i * stride]; }
+};
+
+// ----------------------------------------------------------------------------- small math
+template <typename T> MW_HD T mw_sqrt(T x) { return sqrt(x); }
+template <typename T> MW_HD T mw_abs(T x) { return x < 0 ? -x : x; }
+template <typename T> MW_HD T mw_min(T a, T b) { return a < b ? a : b; }
+template <typename T> MW_HD T mw_max(T a, T b) { return a > b ? a : b; }
+template <typename T> MW_HD T mw_clamp(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+template <typename T> struct V3 { T x, y, z; };
+template <typename T> MW_HD V3<T> v3(T x, T y, T z) { return V3<T>{x, y, z}; }
+template <typename T> MW_HD V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> MW_HD V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> MW_HD V3<T> operator-(V3<T> a) { return {-a.x, -a.y, -a.z}; }
+template <typename T> MW_HD V3<T> operator*(V3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename T> MW_HD V3<T> operator*(T s, V3<T> a) { return {a.x * s, a.y * s, a.z * s}; }
+template <typename T> MW_HD T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> MW_HD V3<T> cross(V3<T> a, V3<T> b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+template <typename T> MW_HD T norm(V3<T> a) { return mw_sqrt(dot(a, a)); }
+template <typename T> MW_HD V3<T> normalized(V3<T> a, T* len = nullptr) {
+    T n = norm(a);
+    if (len) *len = n;
+    if (n < T(1e-15)) { if (len) *len = 0; return {T(1), T(0), T(0)}; }
+    T s = T(1) / n;
+    return {a.x * s, a.y * s, a.z * s};
+}
+template <typename T> MW_HD T comp(V3<T> a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+
+template <typename T> struct Q4 { T w, x, y, z; };
+template <typename T> MW_HD Q4<T> qmul(Q4<T> a, Q4<T> b) {
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+template <typename T> MW_HD Q4<T> qnormalized(Q4<T> q) {
+    T n = mw_sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    if (n < T(1e-15)) return {T(1), T(0), T(0), T(0)};
+    T s = T(1) / n;
+    return {q.w * s, q.x * s, q.y * s, q.z * s};
+}
+template <typename T> MW_HD Q4<T> qconj(Q4<T> q) { return {q.w, -q.x, -q.y, -q.z}; }
+
+// 3x3 rotation, row-major
+template <typename T> struct M3 { T m[9]; };
+template <typename T> MW_HD M3<T> q2mat(Q4<T> q) {
+    T w = q.w, x = q.x, y = q.y, z = q.z;
+    M3<T> r;
+    r.m[0] = w * w + x * x - y * y - z * z; r.m[1] = 2 * (x * y - w * z); r.m[2] = 2 * (x * z + w * y);
+    r.m[3] = 2 * (x * y + w * z); r.m[4] = w * w - x * x + y * y - z * z; r.m[5] = 2 * (y * z - w * x);
+    r.m[6] = 2 * (x * z - w * y); r.m[7] = 2 * (y * z + w * x); r.m[8] = w * w - x * x - y * y + z * z;
+    return r;
+}
+template <typename T> MW_HD V3<T> operator*(const M3<T>& a, V3<T> v) {
+    return {a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z,
+            a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z};
+}
+template <typename T> MW_HD V3<T> mulT(const M3<T>& a, V3<T> v) {
+    return {a.m[0] * v.x + a.m[3] * v.y + a.m[6] * v.z, a.m[1] * v.x + a.m[4] * v.y + a.m[7] * v.z,
+            a.m[2] * v.x + a.m[5] * v.y + a.m[8] * v.z};
+}
+template <typename T> MW_HD V3<T> col(const M3<T>& a, int k) { return {a.m[k], a.m[3 + k], a.m[6 + k]}; }
+
+// column-store load/store helpers
+template <typename T> MW_HD V3<T> ld3(const Env<T>& e, int i) { return {e.R(i), e.R(i + 1), e.R(i + 2)}; }
+template <typename T> MW_HD void st3(const Env<T>& e, int i, V3<T> v) { e.R(i) = v.x; e.R(i + 1) = v.y; e.R(i + 2) = v.z; }
+template <typename T> MW_HD Q4<T> ld4(const Env<T>& e, int i) { return {e.R(i), e.R(i + 1), e.R(i + 2), e.R(i + 3)}; }
+template <typename T> MW_HD void st4(const Env<T>& e, int i, Q4<T> q) { e.R(i) = q.w; e.R(i + 1) = q.x; e.R(i + 2) = q.y; e.R(i + 3) = q.z; }
+template <typename T> MW_HD M3<T> ld9(const Env<T>& e, int i) {
+    M3<T> r;
+    for (int k = 0; k < 9; k++) r.m[k] = e.R(i + k);
+    return r;
+}
+template <typename T> MW_HD void st9(const Env<T>& e, int i, const M3<T>& a) {
+    for (int k = 0; k < 9; k++) e.R(i + k) = a.m[k];
+}
+template <typename T> MW_HD V3<T> mv3(const T* p) { return {p[0], p[1], p[2]}; }
+template <typename T> MW_HD Q4<T> mq4(const T* p) { return {p[0], p[1], p[2], p[3]}; }
+
+}  // namespace mw

@@ -1,0 +1,745 @@
+// mw_phys.hpp -- per-lane rigid-body dynamics for the batched Sawyer scenes.
+//
+// Replaces, for one environment per lane, what the reference obtains from
+// MuJoCo through `do_simulation(ctrl, 5)` -> mj_step x5 and `mj_forward`
+// (reference: metaworld/sawyer_xyz_env.py:595, :620; pipeline restated in
+// SURVEY.md Appendix C.1):  kinematics -> composite-rigid-body mass matrix ->
+// Cholesky -> collision -> constraint rows (weld, joint limits, elliptic
+// contacts) -> RNE bias / passive / position actuators -> Newton solver with
+// exact line search -> semi-implicit Euler with implicit joint damping.
+//
+// All arrays are addressed through Env<T>::R(i) (column store, one lane = one env).
+#pragma once
+#include "mw_common.hpp"
+
+namespace mw {
+
+template <typename T> MW_HD void collision(const Env<T>& e);  // mw_collide.hpp
+
+// ------------------------------------------------------------------ kinematics
+template <typename T>
+MW_HD void kinematics(const Env<T>& e) {
+    const Model<T>& m = *e.m;
+    const Layout& L = e.L;
+    const int nb = m.sz.nbody;
+    st3(e, L.xpos, v3<T>(0, 0, 0));
+    st4(e, L.xquat, Q4<T>{1, 0, 0, 0});
+    st9(e, L.xmat, q2mat(Q4<T>{1, 0, 0, 0}));
+    st3(e, L.xipos, v3<T>(0, 0, 0));
+    for (int k = 0; k < 10; k++) e.R(L.cinert + k) = 0;
+    for (int b = 1; b < nb; b++) {
+        const int p = m.body_parentid[b];
+        V3<T> pos;
+        Q4<T> quat;
+        if (m.body_mocap[b]) {
+            pos = ld3(e, L.mocap);
+            quat = Q4<T>{T(0.70710678118654752), 0, T(0.70710678118654752), 0};  // reference always commands [1,0,1,0]
+        } else {
+            const int rl = m.body_relocid[b];
+            V3<T> bp = rl >= 0 ? ld3(e, L.reloc + 3 * rl) : mv3(m.body_pos + 3 * b);
+            pos = ld3(e, L.xpos + 3 * p) + ld9(e, L.xmat + 9 * p) * bp;
+            quat = qmul(ld4(e, L.xquat + 4 * p), mq4(m.body_quat + 4 * b));
+        }
+        const int j0 = m.body_jntadr[b], jn = m.body_jntnum[b];
+        for (int k = 0; k < jn; k++) {
+            const int j = j0 + k, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j], jt = m.jnt_type[j];
+            if (jt == J_FREE) {
+                Q4<T> q = qnormalized(ld4(e, L.qpos + qa + 3));
+                st4(e, L.qpos + qa + 3, q);
+                pos = ld3(e, L.qpos + qa);
+                quat = q;
+                M3<T> R = q2mat(quat);
+                for (int c = 0; c < 3; c++) {
+                    const int o = L.cdof + 6 * (da + c);
+                    for (int r = 0; r < 6; r++) e.R(o + r) = (r == 3 + c) ? T(1) : T(0);
+                    V3<T> ax = col(R, c);
+                    st3(e, L.cdof + 6 * (da + 3 + c), ax);
+                    st3(e, L.cdof + 6 * (da + 3 + c) + 3, cross(pos, ax));
+                }
+            } else {
+                M3<T> R = q2mat(quat);
+                V3<T> anchor = pos + R * mv3(m.jnt_pos + 3 * j);
+                V3<T> axis = R * mv3(m.jnt_axis + 3 * j);
+                const T q = e.R(L.qpos + qa);
+                if (jt == J_SLIDE) {
+                    pos = pos + axis * q;
+                    st3(e, L.cdof + 6 * da, v3<T>(0, 0, 0));
+                    st3(e, L.cdof + 6 * da + 3, axis);
+                } else {
+                    const T h = T(0.5) * q, s = sin(h);
+                    const T* a = m.jnt_axis + 3 * j;
+                    quat = qmul(quat, Q4<T>{cos(h), s * a[0], s * a[1], s * a[2]});
+                    pos = anchor - q2mat(quat) * mv3(m.jnt_pos + 3 * j);
+                    st3(e, L.cdof + 6 * da, axis);
+                    st3(e, L.cdof + 6 * da + 3, cross(anchor, axis));
+                }
+            }
+        }
+        quat = qnormalized(quat);
+        M3<T> R = q2mat(quat);
+        st3(e, L.xpos + 3 * b, pos);
+        st4(e, L.xquat + 4 * b, quat);
+        st9(e, L.xmat + 9 * b, R);
+        // inertial frame and spatial inertia about the world origin: {m, m*c, J(xx,yy,zz,xy,xz,yz)}
+        V3<T> c = pos + R * mv3(m.body_ipos + 3 * b);
+        st3(e, L.xipos + 3 * b, c);
+        const T mass = m.body_mass[b];
+        M3<T> Ri = q2mat(qmul(quat, mq4(m.body_iquat + 4 * b)));
+        const T* di = m.body_inertia + 3 * b;
+        T Ic[6];  // xx yy zz xy xz yz
+        const int ia[6] = {0, 1, 2, 0, 0, 1}, ib[6] = {0, 1, 2, 1, 2, 2};
+        for (int k = 0; k < 6; k++)
+            Ic[k] = Ri.m[3 * ia[k]] * di[0] * Ri.m[3 * ib[k]] + Ri.m[3 * ia[k] + 1] * di[1] * Ri.m[3 * ib[k] + 1] +
+                    Ri.m[3 * ia[k] + 2] * di[2] * Ri.m[3 * ib[k] + 2];
+        const T cc = dot(c, c);
+        const int o = L.cinert + 10 * b;
+        e.R(o) = mass;
+        e.R(o + 1) = mass * c.x; e.R(o + 2) = mass * c.y; e.R(o + 3) = mass * c.z;
+        e.R(o + 4) = Ic[0] + mass * (cc - c.x * c.x);
+        e.R(o + 5) = Ic[1] + mass * (cc - c.y * c.y);
+        e.R(o + 6) = Ic[2] + mass * (cc - c.z * c.z);
+        e.R(o + 7) = Ic[3] - mass * c.x * c.y;
+        e.R(o + 8) = Ic[4] - mass * c.x * c.z;
+        e.R(o + 9) = Ic[5] - mass * c.y * c.z;
+    }
+    for (int g = 0; g < m.sz.ngeom; g++) {
+        const int b = m.geom_bodyid[g];
+        st3(e, L.geom_xpos + 3 * g, ld3(e, L.xpos + 3 * b) + ld9(e, L.xmat + 9 * b) * mv3(m.geom_pos + 3 * g));
+        st9(e, L.geom_xmat + 9 * g, q2mat(qmul(ld4(e, L.xquat + 4 * b), mq4(m.geom_quat + 4 * g))));
+    }
+}
+
+// world pose of probe `p` (named body / geom / site frames the task layer reads)
+template <typename T>
+MW_HD V3<T> probe_pos(const Env<T>& e, int p) {
+    const Model<T>& m = *e.m;
+    const int b = m.probe_body[p];
+    return ld3(e, e.L.xpos + 3 * b) + ld9(e, e.L.xmat + 9 * b) * mv3(m.probe_pos + 3 * p);
+}
+template <typename T>
+MW_HD Q4<T> probe_quat(const Env<T>& e, int p) {
+    const Model<T>& m = *e.m;
+    return qmul(ld4(e, e.L.xquat + 4 * m.probe_body[p]), mq4(m.probe_quat + 4 * p));
+}
+
+// f[6] = I10 * s[6]  (spatial inertia about origin times motion vector [w; v])
+template <typename T>
+MW_HD void inertia_mul(T* f, const T* I, const T* s) {
+    V3<T> w{s[0], s[1], s[2]}, v{s[3], s[4], s[5]}, h{I[1], I[2], I[3]};
+    V3<T> p = v * I[0] + cross(w, h);
+    V3<T> t = cross(h, v);
+    f[0] = I[4] * w.x + I[7] * w.y + I[8] * w.z + t.x;
+    f[1] = I[7] * w.x + I[5] * w.y + I[9] * w.z + t.y;
+    f[2] = I[8] * w.x + I[9] * w.y + I[6] * w.z + t.z;
+    f[3] = p.x; f[4] = p.y; f[5] = p.z;
+}
+
+// in-place Cholesky of the lower triangle of the n x n matrix at offset A (row-major, stride n)
+template <typename T>
+MW_HD void chol_factor(const Env<T>& e, int A, int n) {
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j <= i; j++) {
+            T s = e.R(A + i * n + j);
+            for (int k = 0; k < j; k++) s -= e.R(A + i * n + k) * e.R(A + j * n + k);
+            if (i == j) e.R(A + i * n + i) = mw_sqrt(s < T(1e-15) ? T(1e-15) : s);
+            else e.R(A + i * n + j) = s / e.R(A + j * n + j);
+        }
+    }
+}
+template <typename T>
+MW_HD void chol_solve(const Env<T>& e, int A, int x, int n) {
+    for (int i = 0; i < n; i++) {
+        T s = e.R(x + i);
+        for (int k = 0; k < i; k++) s -= e.R(A + i * n + k) * e.R(x + k);
+        e.R(x + i) = s / e.R(A + i * n + i);
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        T s = e.R(x + i);
+        for (int k = i + 1; k < n; k++) s -= e.R(A + k * n + i) * e.R(x + k);
+        e.R(x + i) = s / e.R(A + i * n + i);
+    }
+}
+
+// ------------------------------------------------------------------ mass matrix
+template <typename T>
+MW_HD void crb(const Env<T>& e) {
+    const Model<T>& m = *e.m;
+    const Layout& L = e.L;
+    const int nb = m.sz.nbody, nv = m.sz.nv;
+    for (int i = 0; i < 10 * nb; i++) e.R(L.crb + i) = e.R(L.cinert + i);
+    for (int b = nb - 1; b > 0; b--) {
+        const int p = m.body_parentid[b];
+        if (p > 0)
+            for (int k = 0; k < 10; k++) e.R(L.crb + 10 * p + k) += e.R(L.crb + 10 * b + k);
+    }
+    for (int i = 0; i < nv * nv; i++) e.R(L.qM + i) = 0;
+    for (int i = 0; i < nv; i++) {
+        T I[10], s[6], f[6];
+        const int b = m.dof_bodyid[i];
+        for (int k = 0; k < 10; k++) I[k] = e.R(L.crb + 10 * b + k);
+        for (int k = 0; k < 6; k++) s[k] = e.R(L.cdof + 6 * i + k);
+        inertia_mul(f, I, s);
+        for (int j = i; j >= 0; j = m.dof_parentid[j]) {
+            T v = 0;
+            for (int k = 0; k < 6; k++) v += e.R(L.cdof + 6 * j + k) * f[k];
+            if (j == i) v += m.dof_armature[i];
+            e.R(L.qM + i * nv + j) = v;
+            e.R(L.qM + j * nv + i) = v;
+        }
+    }
+    for (int i = 0; i < nv * nv; i++) e.R(L.qL + i) = e.R(L.qM + i);
+    chol_factor(e, L.qL, nv);
+}
+
+// ------------------------------------------------------------------ bias forces (RNE), passive, actuation
+template <typename T>
+MW_HD void cross_motion(T* r, const T* v, const T* s) {
+    V3<T> vw{v[0], v[1], v[2]}, vl{v[3], v[4], v[5]}, sw{s[0], s[1], s[2]}, sl{s[3], s[4], s[5]};
+    V3<T> a = cross(vw, sw), b = cross(vw, sl) + cross(vl, sw);
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = b.x; r[4] = b.y; r[5] = b.z;
+}
+template <typename T>
+MW_HD void smooth_forces(const Env<T>& e) {
+    const Model<T>& m = *e.m;
+    const Layout& L = e.L;
+    const int nb = m.sz.nbody, nv = m.sz.nv;
+    for (int k = 0; k < 6; k++) { e.R(L.cvel + k) = 0; e.R(L.cfrc + k) = 0; }
+    e.R(L.cacc) = 0; e.R(L.cacc + 1) = 0; e.R(L.cacc + 2) = 0;
+    e.R(L.cacc + 3) = -m.gravity[0]; e.R(L.cacc + 4) = -m.gravity[1]; e.R(L.cacc + 5) = -m.gravity[2];
+    for (int b = 1; b < nb; b++) {
+        const int p = m.body_parentid[b];
+        T v[6], a[6];
+        for (int k = 0; k < 6; k++) { v[k] = e.R(L.cvel + 6 * p + k); a[k] = e.R(L.cacc + 6 * p + k); }
+        const int j0 = m.body_jntadr[b], jn = m.body_jntnum[b];
+        for (int jj = 0; jj < jn; jj++) {
+            const int j = j0 + jj, da = m.jnt_dofadr[j];
+            if (m.jnt_type[j] == J_FREE) {
+                for (int i = 0; i < 3; i++) {
+                    const T qd = e.R(L.qvel + da + i);
+                    for (int c = 0; c < 6; c++) v[c] += e.R(L.cdof + 6 * (da + i) + c) * qd;
+                }
+                T vs[6];
+                for (int c = 0; c < 6; c++) vs[c] = v[c];
+                for (int i = 3; i < 6; i++) {
+                    T s[6], sd[6];
+                    for (int c = 0; c < 6; c++) s[c] = e.R(L.cdof + 6 * (da + i) + c);
+                    cross_motion(sd, vs, s);
+                    const T qd = e.R(L.qvel + da + i);
+                    for (int c = 0; c < 6; c++) { v[c] += s[c] * qd; a[c] += sd[c] * qd; }
+                }
+            } else {
+                T s[6], sd[6];
+                for (int c = 0; c < 6; c++) s[c] = e.R(L.cdof + 6 * da + c);
+                cross_motion(sd, v, s);
+                const T qd = e.R(L.qvel + da);
+                for (int c = 0; c < 6; c++) { v[c] += s[c] * qd; a[c] += sd[c] * qd; }
+            }
+        }
+        T I[10], Ia[6], Iv[6];
+        for (int k = 0; k < 10; k++) I[k] = e.R(L.cinert + 10 * b + k);
+        inertia_mul(Ia, I, a);
+        inertia_mul(Iv, I, v);
+        // v x* (I v)
+        V3<T> vw{v[0], v[1], v[2]}, vl{v[3], v[4], v[5]}, fn{Iv[0], Iv[1], Iv[2]}, ff{Iv[3], Iv[4], Iv[5]};
+        V3<T> tn = cross(vw, fn) + cross(vl, ff), tf = cross(vw, ff);
+        for (int k = 0; k < 6; k++) { e.R(L.cvel + 6 * b + k) = v[k]; e.R(L.cacc + 6 * b + k) = a[k]; }
+        e.R(L.cfrc + 6 * b) = Ia[0] + tn.x; e.R(L.cfrc + 6 * b + 1) = Ia[1] + tn.y; e.R(L.cfrc + 6 * b + 2) = Ia[2] + tn.z;
+        e.R(L.cfrc + 6 * b + 3) = Ia[3] + tf.x; e.R(L.cfrc + 6 * b + 4) = Ia[4] + tf.y; e.R(L.cfrc + 6 * b + 5) = Ia[5] + tf.z;
+    }
+    for (int b = nb - 1; b > 0; b--) {
+        const int p = m.body_parentid[b];
+        if (p > 0)
+            for (int k = 0; k < 6; k++) e.R(L.cfrc + 6 * p + k) += e.R(L.cfrc + 6 * b + k);
+    }
+    // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
+    for (int i = 0; i < nv; i++) {
+        T bias = 0;
+        const int b = m.dof_bodyid[i];
+        for (int k = 0; k < 6; k++) bias += e.R(L.cdof + 6 * i + k) * e.R(L.cfrc + 6 * b + k);
+        e.R(L.bias + i) = bias;
+        T f = -m.dof_damping[i] * e.R(L.qvel + i) - bias;
+        const int j = m.dof_jntid[i];
+        if (m.jnt_type[j] != J_FREE && m.jnt_stiffness[j] != 0)
+            f -= m.jnt_stiffness[j] * (e.R(L.qpos + m.jnt_qposadr[j]) - m.jnt_springref[j]);
+        e.R(L.smooth + i) = f;
+    }
+    for (int u = 0; u < m.sz.nu; u++) {
+        const T c = mw_clamp(e.R(L.ctrl + u), m.act_ctrlrange[2 * u], m.act_ctrlrange[2 * u + 1]);
+        e.R(L.smooth + m.act_dofid[u]) += m.act_kp[u] * (c - e.R(L.qpos + m.act_qposid[u]));
+    }
+    for (int i = 0; i < nv; i++) e.R(L.qacc_smooth + i) = e.R(L.smooth + i);
+    chol_solve(e, L.qL, L.qacc_smooth, nv);
+}
+
+// ------------------------------------------------------------------ constraint rows
+// efcX per row: 0 pos, 1 margin, 2 R, 3 D, 4 aref, 5 force, 6 jar, 7 Jv
+template <typename T> MW_HD T& EX(const Env<T>& e, int row, int k) { return e.R(e.L.efcX + EFC_EXTRA * row + k); }
+template <typename T> MW_HD T& EJ(const Env<T>& e, int row, int i) { return e.R(e.L.efcJ + row * e.m->sz.nv + i); }
+template <typename T> MW_HD T& CON(const Env<T>& e, int c, int k) { return e.R(e.L.con + CON_STRIDE * c + k); }
+// contact record: 0 dist, 1-3 pos, 4-12 frame, 13 includemargin, 14-16 friction(slide,torsion,roll), 17-18 solref, 19-23 solimp, 24 mu
+template <typename T> MW_HD int& ICON(const Env<T>& e, int c, int k) { return e.I(e.L.icon + CON_ISTRIDE * c + k); }  // g1,g2,dim,efc_address
+template <typename T> MW_HD int& IEFC(const Env<T>& e, int r, int k) { return e.I(e.L.iefc + EFC_ISTRIDE * r + k); }  // type,id,state
+
+template <typename T>
+MW_HD T impedance(const T* solimp, T x) {
+    T d0 = mw_clamp(solimp[0], T(0.0001), T(0.9999)), dw = mw_clamp(solimp[1], T(0.0001), T(0.9999));
+    T width = solimp[2], mid = mw_clamp(solimp[3], T(0.0001), T(0.9999)), power = mw_max(solimp[4], T(1));
+    if (width < T(1e-15) || d0 == dw) return T(0.5) * (d0 + dw);
+    x = mw_abs(x) / width;
+    if (x >= 1) return dw;
+    if (x <= 0) return d0;
+    T y;
+    if (power == 1) y = x;
+    else if (power == 2) y = x <= mid ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);
+    else y = x <= mid ? T(pow(double(x / mid), double(power))) * mid : 1 - T(pow(double((1 - x) / (1 - mid)), double(power))) * (1 - mid);
+    return d0 + y * (dw - d0);
+}
+
+// finish a row whose J / pos / margin are set: regulariser R, D, reference acceleration
+template <typename T>
+MW_HD void finish_row(const Env<T>& e, int row, const T* solref, const T* solimp, T diagApprox, T* Rout, T* Bout, T* Iout) {
+    const Model<T>& m = *e.m;
+    const int nv = m.sz.nv;
+    T tc = solref[0], dr = solref[1];
+    if (tc > 0) tc = mw_max(tc, 2 * m.timestep);
+    const T dmax = mw_clamp(solimp[1], T(0.0001), T(0.9999));
+    const T K = 1 / mw_max(T(1e-15), dmax * dmax * tc * tc * dr * dr), B = 2 / mw_max(T(1e-15), dmax * tc);
+    const T r = EX(e, row, 0) - EX(e, row, 1);
+    const T imp = impedance(solimp, r);
+    const T R = mw_max(T(1e-15), (1 - imp) / imp * diagApprox);
+    T vel = 0;
+    for (int i = 0; i < nv; i++) vel += EJ(e, row, i) * e.R(e.L.qvel + i);
+    EX(e, row, 2) = R; EX(e, row, 3) = 1 / R;
+    EX(e, row, 4) = -B * vel - K * imp * r;
+    if (Rout) { *Rout = R; *Bout = B; *Iout = imp; }
+}
+
+// J rows (translational/rotational) of a world point on body b: accumulate sign * axis . jac into row
+template <typename T>
+MW_HD void add_jac_row(const Env<T>& e, int row, int body, V3<T> point, V3<T> axis, bool rotational, T sign) {
+    const Model<T>& m = *e.m;
+    for (int i = m.body_lastdof[body]; i >= 0; i = m.dof_parentid[i]) {
+        V3<T> w = ld3(e, e.L.cdof + 6 * i);
+        T val;
+        if (rotational) val = dot(axis, w);
+        else val = dot(axis, ld3(e, e.L.cdof + 6 * i + 3) + cross(w, point));
+        EJ(e, row, i) += sign * val;
+    }
+}
+
+template <typename T>
+MW_HD int new_rows(const Env<T>& e, int n, int type, int id) {
+    const Model<T>& m = *e.m;
+    int& nefc = e.I(e.L.icount + 1);
+    if (nefc + n > m.sz.maxefc) { e.I(e.L.icount + 3) |= 1; return -1; }
+    const int r0 = nefc;
+    for (int k = 0; k < n; k++) {
+        IEFC(e, r0 + k, 0) = type; IEFC(e, r0 + k, 1) = id; IEFC(e, r0 + k, 2) = 0;
+        for (int i = 0; i < m.sz.nv; i++) EJ(e, r0 + k, i) = 0;
+        EX(e, r0 + k, 0) = 0; EX(e, r0 + k, 1) = 0;
+    }
+    nefc += n;
+    return r0;
+}
+
+template <typename T>
+MW_HD void make_constraints(const Env<T>& e) {
+    const Model<T>& m = *e.m;
+    const Layout& L = e.L;
+    const int nv = m.sz.nv;
+    e.I(L.icount + 1) = 0;
+    // ---- weld(mocap, hand): 3 translational + 3 rotational rows ----
+    for (int q = 0; q < m.sz.neq; q++) {
+        const int b1 = m.eq_body1[q], b2 = m.eq_body2[q];
+        const T* data = m.eq_data + 11 * q;
+        V3<T> p1 = ld3(e, L.xpos + 3 * b1) + ld9(e, L.xmat + 9 * b1) * mv3(data + 3);
+        V3<T> p2 = ld3(e, L.xpos + 3 * b2) + ld9(e, L.xmat + 9 * b2) * mv3(data);
+        V3<T> cp = p1 - p2;
+        const T ts = data[10];
+        Q4<T> qa = qmul(ld4(e, L.xquat + 4 * b1), mq4(data + 6));
+        Q4<T> q2n = qconj(ld4(e, L.xquat + 4 * b2));
+        Q4<T> qr = qmul(q2n, qa);
+        const int r0 = new_rows(e, 6, C_EQUALITY, q);
+        if (r0 < 0) continue;
+        for (int k = 0; k < 3; k++) {
+            V3<T> ax{T(k == 0), T(k == 1), T(k == 2)};
+            add_jac_row(e, r0 + k, b1, p1, ax, false, T(1));
+            add_jac_row(e, r0 + k, b2, p2, ax, false, T(-1));
+        }
+        // rotational rows: 0.5 * imag( conj(q2) * (w1 - w2) * q1 * rel ) * torquescale
+        for (int pass = 0; pass < 2; pass++) {
+            const int b = pass ? b2 : b1;
+            const T sg = pass ? T(-1) : T(1);
+            for (int i = m.body_lastdof[b]; i >= 0; i = m.dof_parentid[i]) {
+                V3<T> w = ld3(e, L.cdof + 6 * i);
+                Q4<T> q4 = qmul(qmul(q2n, Q4<T>{0, w.x, w.y, w.z}), qa);
+                EJ(e, r0 + 3, i) += sg * T(0.5) * q4.x * ts;
+                EJ(e, r0 + 4, i) += sg * T(0.5) * q4.y * ts;
+                EJ(e, r0 + 5, i) += sg * T(0.5) * q4.z * ts;
+            }
+        }
+        const T res[6] = {cp.x, cp.y, cp.z, ts * qr.x, ts * qr.y, ts * qr.z};
+        for (int k = 0; k < 6; k++) {
+            EX(e, r0 + k, 0) = res[k];
+            finish_row(e, r0 + k, m.eq_solref + 2 * q, m.eq_solimp + 5 * q, m.eq_invweight0[2 * q + (k >= 3)], (T*)nullptr, (T*)nullptr, (T*)nullptr);
+        }
+    }
+    // ---- joint limits ----
+    for (int j = 0; j < m.sz.njnt; j++) {
+        if (!m.jnt_limited[j] || m.jnt_type[j] == J_FREE) continue;
+        const T q = e.R(L.qpos + m.jnt_qposadr[j]), margin = m.jnt_margin[j];
+        for (int side = -1; side <= 1; side += 2) {
+            const T dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - q);
+            if (dist < margin) {
+                const int r = new_rows(e, 1, C_LIMIT, j);
+                if (r < 0) continue;
+                EJ(e, r, m.jnt_dofadr[j]) = T(-side);
+                EX(e, r, 0) = dist; EX(e, r, 1) = margin;
+                finish_row(e, r, m.jnt_solref + 2 * j, m.jnt_solimp + 5 * j, m.dof_invweight0[m.jnt_dofadr[j]], (T*)nullptr, (T*)nullptr, (T*)nullptr);
+            }
+        }
+    }
+    // ---- contacts (elliptic cones, condim 3 or 4) ----
+    const int ncon = e.I(L.icount);
+    for (int c = 0; c < ncon; c++) {
+        ICON(e, c, 3) = -1;
+        const T dist = CON(e, c, 0), inc = CON(e, c, 13);
+        if (dist >= inc) continue;
+        const int g1 = ICON(e, c, 0), g2 = ICON(e, c, 1), dim = ICON(e, c, 2);
+        const int r0 = new_rows(e, dim, C_CONTACT, c);
+        if (r0 < 0) continue;
+        ICON(e, c, 3) = r0;
+        const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
+        V3<T> pos{CON(e, c, 1), CON(e, c, 2), CON(e, c, 3)};
+        for (int k = 0; k < dim; k++) {
+            const int a = k < 3 ? k : k - 3;
+            V3<T> ax{CON(e, c, 4 + 3 * a), CON(e, c, 5 + 3 * a), CON(e, c, 6 + 3 * a)};
+            add_jac_row(e, r0 + k, b2, pos, ax, k >= 3, T(1));
+            add_jac_row(e, r0 + k, b1, pos, ax, k >= 3, T(-1));
+        }
+        EX(e, r0, 0) = dist; EX(e, r0, 1) = inc;
+        T solref[2] = {CON(e, c, 17), CON(e, c, 18)}, solimp[5];
+        for (int k = 0; k < 5; k++) solimp[k] = CON(e, c, 19 + k);
+        const T wt = m.geom_invweight0[2 * g1] + m.geom_invweight0[2 * g2];
+        T R0, B, imp;
+        finish_row(e, r0, solref, solimp, wt, &R0, &B, &imp);
+        // friction rows: R scaled by friction ratios (impratio 1), aref = -B * vel
+        const T f0 = CON(e, c, 14), f1 = CON(e, c, 15);
+        for (int k = 1; k < dim; k++) {
+            const T fk = k < 3 ? f0 : f1;
+            const T R = R0 * f0 * f0 / (fk * fk);
+            T vel = 0;
+            for (int i = 0; i < nv; i++) vel += EJ(e, r0 + k, i) * e.R(L.qvel + i);
+            EX(e, r0 + k, 2) = R; EX(e, r0 + k, 3) = 1 / R; EX(e, r0 + k, 4) = -B * vel;
+        }
+        CON(e, c, 24) = f0;  // mu = friction[0] * sqrt(R[1]/R[0]) with impratio 1
+    }
+}
+
+// ------------------------------------------------------------------ Newton solver
+// cone bookkeeping for one contact at the current jar (offset `off` selects jar (6) or jar + alpha*Jv)
+template <typename T>
+struct ConeEval { T mu, fri[4], U[4], N, Tn; int dim, zone; };   // zone: 0 top, 1 bottom(quadratic), 2 middle
+template <typename T>
+MW_HD ConeEval<T> cone_eval(const Env<T>& e, int r0, int c, T alpha) {
+    ConeEval<T> z;
+    z.dim = ICON(e, c, 2);
+    z.mu = CON(e, c, 24);
+    z.fri[0] = z.mu;
+    const T f0 = CON(e, c, 14), f1 = CON(e, c, 15);
+    T tt = 0;
+    for (int k = 0; k < z.dim; k++) {
+        if (k > 0) z.fri[k] = k < 3 ? f0 : f1;
+        const T x = EX(e, r0 + k, 6) + alpha * EX(e, r0 + k, 7);
+        z.U[k] = x * z.fri[k];
+        if (k > 0) tt += z.U[k] * z.U[k];
+    }
+    z.N = z.U[0];
+    z.Tn = mw_sqrt(tt);
+    if (z.N >= z.mu * z.Tn || (z.Tn <= 0 && z.N >= 0)) z.zone = 0;
+    else if (z.mu * z.N + z.Tn <= 0 || (z.Tn <= 0 && z.N < 0)) z.zone = 1;
+    else z.zone = 2;
+    return z;
+}
+
+// cost, forces, states at the current jar; qfrc_constraint = J' force; returns total cost incl. Gauss term
+template <typename T>
+MW_HD T update_constraint(const Env<T>& e) {
+    const Model<T>& m = *e.m;
+    const Layout& L = e.L;
+    const int nv = m.sz.nv, nefc = e.I(L.icount + 1);
+    T cost = 0;
+    for (int i = 0; i < nefc; i++) {
+        const int type = IEFC(e, i, 0);
+        const T D = EX(e, i, 3), jar = EX(e, i, 6);
+        if (type == C_EQUALITY || (type == C_LIMIT && jar < 0)) {
+            EX(e, i, 5) = -D * jar; cost += T(0.5) * D * jar * jar; IEFC(e, i, 2) = S_QUADRATIC;
+        } else if (type == C_LIMIT) {
+            EX(e, i, 5) = 0; IEFC(e, i, 2) = S_SATISFIED;
+        } else {
+            const int c = IEFC(e, i, 1);
+            ConeEval<T> z = cone_eval(e, i, c, T(0));
+            int st;
+            if (z.zone == 0) {
+                st = S_SATISFIED;
+                for (int k = 0; k < z.dim; k++) EX(e, i + k, 5) = 0;
+            } else if (z.zone == 1) {
+                st = S_QUADRATIC;
+                for (int k = 0; k < z.dim; k++) {
+                    const T Dk = EX(e, i + k, 3), x = EX(e, i + k, 6);
+                    EX(e, i + k, 5) = -Dk * x; cost += T(0.5) * Dk * x * x;
+                }
+            } else {
+                st = S_CONE;
+                const T Dm = D / (z.mu * z.mu * (1 + z.mu * z.mu)), NmT = z.N - z.mu * z.Tn;
+                cost += T(0.5) * Dm * NmT * NmT;
+                const T f0 = -Dm * NmT * z.mu;
+                EX(e, i, 5) = f0;
+                for (int k = 1; k < z.dim; k++) EX(e, i + k, 5) = -f0 / z.Tn * z.U[k] * z.fri[k];
+            }
+            for (int k = 0; k < z.dim; k++) IEFC(e, i + k, 2) = st;
+            i += z.dim - 1;
+        }
+    }
+    T gauss = 0;
+    for (int k = 0; k < nv; k++) {
+        T s = 0;
+        for (int i = 0; i < nefc; i++) s += EJ(e, i, k) * EX(e, i, 5);
+        e.R(L.qfrc_c + k) = s;
+        gauss += (e.R(L.Ma + k) - e.R(L.smooth + k)) * (e.R(L.qacc + k) - e.R(L.qacc_smooth + k));
+    }
+    return cost + T(0.5) * gauss;
+}
+
+// constraint part of the cost (no forces written) at jar + alpha*Jv, with 1st/2nd derivatives along the line
+template <typename T>
+MW_HD void line_eval(const Env<T>& e, T alpha, const T* quadGauss, T* cost, T* d1, T* d2) {
+    const int nefc = e.I(e.L.icount + 1);
+    T C = alpha * alpha * quadGauss[2] + alpha * quadGauss[1] + quadGauss[0];
+    T D1 = 2 * alpha * quadGauss[2] + quadGauss[1], D2 = 2 * quadGauss[2];
+    for (int i = 0; i < nefc; i++) {
+        const int type = IEFC(e, i, 0);
+        const T D = EX(e, i, 3), jv = EX(e, i, 7), x = EX(e, i, 6) + alpha * jv;
+        if (type == C_EQUALITY || (type == C_LIMIT && x < 0)) {
+            C += T(0.5) * D * x * x; D1 += D * x * jv; D2 += D * jv * jv;
+        } else if (type == C_CONTACT) {
+            const int c = IEFC(e, i, 1);
+            ConeEval<T> z = cone_eval(e, i, c, alpha);
+            if (z.zone == 1) {
+                for (int k = 0; k < z.dim; k++) {
+                    const T Dk = EX(e, i + k, 3), jk = EX(e, i + k, 7), xk = EX(e, i + k, 6) + alpha * jk;
+                    C += T(0.5) * Dk * xk * xk; D1 += Dk * xk * jk; D2 += Dk * jk * jk;
+                }
+            } else if (z.zone == 2) {
+                T UV = 0, VV = 0;
+                for (int k = 1; k < z.dim; k++) {
+                    const T v = EX(e, i + k, 7) * z.fri[k];
+                    UV += z.U[k] * v; VV += v * v;
+                }
+                const T Dm = D / (z.mu * z.mu * (1 + z.mu * z.mu));
+                const T N1 = EX(e, i, 7) * z.mu, T1 = UV / z.Tn, T2 = VV / z.Tn - UV * T1 / (z.Tn * z.Tn);
+                const T NmT = z.N - z.mu * z.Tn, g = N1 - z.mu * T1;
+                C += T(0.5) * Dm * NmT * NmT; D1 += Dm * NmT * g; D2 += Dm * (g * g - NmT * z.mu * T2);
+            }
+            i += z.dim - 1;
+        }
+    }
+    *cost = C; *d1 = D1; *d2 = D2;
+}
+
+template <typename T>
+MW_HD void solve(const Env<T>& e) {
+    const Model<T>& m = *e.m;
+    const Layout& L = e.L;
+    const int nv = m.sz.nv, nefc = e.I(L.icount + 1);
+    e.I(L.icount + 2) = 0;
+    if (nefc == 0) {
+        for (int k = 0; k < nv; k++) { e.R(L.qacc + k) = e.R(L.qacc_smooth + k); e.R(L.qfrc_c + k) = 0; }
+        return;
+    }
+    auto set_point = [&](int src) {   // qacc <- src ; Ma, jar
+        for (int k = 0; k < nv; k++) e.R(L.qacc + k) = e.R(src + k);
+        for (int k = 0; k < nv; k++) {
+            T s = 0;
+            for (int j = 0; j < nv; j++) s += e.R(L.qM + k * nv + j) * e.R(L.qacc + j);
+            e.R(L.Ma + k) = s;
+        }
+        for (int i = 0; i < nefc; i++) {
+            T s = -EX(e, i, 4);
+            for (int j = 0; j < nv; j++) s += EJ(e, i, j) * e.R(L.qacc + j);
+            EX(e, i, 6) = s;
+        }
+    };
+    // warm start: the better of qacc_warmstart and qacc_smooth
+    set_point(L.warm);
+    T cost = update_constraint(e);
+    {
+        set_point(L.qacc_smooth);
+        const T cs = update_constraint(e);
+        if (cost > cs) cost = cs;
+        else { set_point(L.warm); cost = update_constraint(e); }
+    }
+    const T scale = 1 / (m.meaninertia * T(nv > 1 ? nv : 1));
+    for (int iter = 0; iter < m.sz.iterations; iter++) {
+        T gn = 0;
+        for (int k = 0; k < nv; k++) {
+            const T g = e.R(L.Ma + k) - e.R(L.smooth + k) - e.R(L.qfrc_c + k);
+            e.R(L.grad + k) = g; gn += g * g;
+        }
+        if (scale * mw_sqrt(gn) < m.tolerance) break;
+        // H = M + J' D J over quadratic rows (+ dense cone blocks), lower triangle, then Cholesky in place
+        for (int a = 0; a < nv; a++)
+            for (int b = 0; b <= a; b++) e.R(L.qH + a * nv + b) = e.R(L.qM + a * nv + b);
+        for (int i = 0; i < nefc; i++) {
+            const int st = IEFC(e, i, 2);
+            if (st == S_QUADRATIC) {
+                const T D = EX(e, i, 3);
+                for (int a = 0; a < nv; a++) {
+                    const T ja = EJ(e, i, a);
+                    if (ja == 0) continue;
+                    const T Da = D * ja;
+                    for (int b = 0; b <= a; b++) e.R(L.qH + a * nv + b) += Da * EJ(e, i, b);
+                }
+            } else if (st == S_CONE) {
+                const int c = IEFC(e, i, 1);
+                ConeEval<T> z = cone_eval(e, i, c, T(0));
+                const T Dm = EX(e, i, 3) / (z.mu * z.mu * (1 + z.mu * z.mu));
+                T Hc[16];
+                const T scl = z.mu * z.N / (z.Tn * z.Tn * z.Tn), dg = z.mu * z.mu - z.mu * z.N / z.Tn;
+                for (int r = 0; r < z.dim; r++)
+                    for (int s = 0; s < z.dim; s++) {
+                        T h;
+                        if (r == 0 && s == 0) h = 1;
+                        else if (r == 0) h = -z.mu * z.U[s] / z.Tn;
+                        else if (s == 0) h = -z.mu * z.U[r] / z.Tn;
+                        else h = scl * z.U[r] * z.U[s] + (r == s ? dg : T(0));
+                        Hc[4 * r + s] = h * Dm * z.fri[r] * z.fri[s];
+                    }
+                for (int a = 0; a < nv; a++) {
+                    T ja[4], t[4];
+                    bool any = false;
+                    for (int r = 0; r < z.dim; r++) { ja[r] = EJ(e, i + r, a); any |= ja[r] != 0; }
+                    if (!any) continue;
+                    for (int s = 0; s < z.dim; s++) {
+                        t[s] = 0;
+                        for (int r = 0; r < z.dim; r++) t[s] += ja[r] * Hc[4 * r + s];
+                    }
+                    for (int b = 0; b <= a; b++) {
+                        T acc = 0;
+                        for (int s = 0; s < z.dim; s++) acc += t[s] * EJ(e, i + s, b);
+                        e.R(L.qH + a * nv + b) += acc;
+                    }
+                }
+                i += z.dim - 1;
+            } else if (IEFC(e, i, 0) == C_CONTACT) {
+                i += ICON(e, IEFC(e, i, 1), 2) - 1;
+            }
+        }
+        chol_factor(e, L.qH, nv);
+        for (int k = 0; k < nv; k++) e.R(L.search + k) = -e.R(L.grad + k);
+        chol_solve(e, L.qH, L.search, nv);
+        // ---- exact line search (safeguarded Newton on the 1-D convex cost) ----
+        T snorm = 0, quadGauss[3] = {0, 0, 0};
+        for (int k = 0; k < nv; k++) {
+            T s = 0;
+            for (int j = 0; j < nv; j++) s += e.R(L.qM + k * nv + j) * e.R(L.search + j);
+            e.R(L.Mv + k) = s;
+            const T sk = e.R(L.search + k);
+            snorm += sk * sk;
+            quadGauss[1] += sk * (e.R(L.Ma + k) - e.R(L.smooth + k));
+            quadGauss[2] += T(0.5) * sk * s;
+            quadGauss[0] += T(0.5) * (e.R(L.Ma + k) - e.R(L.smooth + k)) * (e.R(L.qacc + k) - e.R(L.qacc_smooth + k));
+        }
+        snorm = mw_sqrt(snorm);
+        if (snorm < T(1e-15)) break;
+        for (int i = 0; i < nefc; i++) {
+            T s = 0;
+            for (int j = 0; j < nv; j++) s += EJ(e, i, j) * e.R(L.search + j);
+            EX(e, i, 7) = s;
+        }
+        const T gtol = m.tolerance * T(0.01) * snorm / scale;
+        T c0, d1, d2;
+        line_eval(e, T(0), quadGauss, &c0, &d1, &d2);
+        if (d1 >= 0 || d2 <= 0) break;
+        T lo = 0, hi = -1, alpha = -d1 / d2;
+        for (int it = 0; it < m.sz.ls_iterations; it++) {
+            T ca, da, dda;
+            line_eval(e, alpha, quadGauss, &ca, &da, &dda);
+            if (mw_abs(da) < gtol) break;
+            if (da < 0) lo = alpha; else hi = alpha;
+            T an = alpha - da / dda;
+            if (hi < 0) { if (an <= lo) an = 2 * alpha; }
+            else if (!(an > lo && an < hi)) an = T(0.5) * (lo + hi);
+            if (hi > 0 && (hi - lo) <= T(1e-7) * hi * (sizeof(T) == 8 ? T(1e-9) : T(1))) { alpha = T(0.5) * (lo + hi); break; }
+            alpha = an;
+        }
+        if (alpha == 0) break;
+        for (int k = 0; k < nv; k++) { e.R(L.qacc + k) += alpha * e.R(L.search + k); e.R(L.Ma + k) += alpha * e.R(L.Mv + k); }
+        for (int i = 0; i < nefc; i++) EX(e, i, 6) += alpha * EX(e, i, 7);
+        const T old = cost;
+        cost = update_constraint(e);
+        e.I(L.icount + 2) = iter + 1;
+        if (scale * (old - cost) < m.tolerance) break;
+    }
+}
+
+// ------------------------------------------------------------------ pipeline
+template <typename T>
+MW_HD void forward(const Env<T>& e) {
+    kinematics(e);
+    crb(e);
+    collision(e);
+    make_constraints(e);
+    smooth_forces(e);
+    solve(e);
+}
+
+template <typename T>
+MW_HD void substep(const Env<T>& e) {
+    const Model<T>& m = *e.m;
+    const Layout& L = e.L;
+    const int nv = m.sz.nv;
+    const T h = m.timestep;
+    forward(e);
+    // warmstart <- solver acceleration; then (M + h B) a = f_smooth + f_constraint in qH / search
+    for (int k = 0; k < nv; k++) e.R(L.warm + k) = e.R(L.qacc + k);
+    for (int a = 0; a < nv; a++) {
+        for (int b = 0; b <= a; b++) e.R(L.qH + a * nv + b) = e.R(L.qM + a * nv + b);
+        e.R(L.qH + a * nv + a) += h * m.dof_damping[a];
+        e.R(L.search + a) = e.R(L.smooth + a) + e.R(L.qfrc_c + a);
+    }
+    chol_factor(e, L.qH, nv);
+    chol_solve(e, L.qH, L.search, nv);
+    for (int k = 0; k < nv; k++) e.R(L.qvel + k) += h * e.R(L.search + k);
+    for (int j = 0; j < m.sz.njnt; j++) {
+        const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+        if (m.jnt_type[j] == J_FREE) {
+            for (int k = 0; k < 3; k++) e.R(L.qpos + qa + k) += h * e.R(L.qvel + da + k);
+            V3<T> w = ld3(e, L.qvel + da + 3);
+            T wn;
+            V3<T> ax = normalized(w, &wn);
+            const T ang = wn * h;
+            if (ang >= T(1e-15)) {
+                const T s = sin(T(0.5) * ang);
+                Q4<T> q = qmul(ld4(e, L.qpos + qa + 3), Q4<T>{cos(T(0.5) * ang), s * ax.x, s * ax.y, s * ax.z});
+                st4(e, L.qpos + qa + 3, qnormalized(q));
+            }
+        } else e.R(L.qpos + qa) += h * e.R(L.qvel + da);
+    }
+    e.R(L.time) += h;
+}
+
+// mj_resetData
+template <typename T>
+MW_HD void reset_data(const Env<T>& e) {
+    const Model<T>& m = *e.m;
+    const Layout& L = e.L;
+    for (int i = 0; i < m.sz.nq; i++) e.R(L.qpos + i) = m.qpos0[i];
+    for (int i = 0; i < m.sz.nv; i++) { e.R(L.qvel + i) = 0; e.R(L.warm + i) = 0; }
+    for (int i = 0; i < m.sz.nu; i++) e.R(L.ctrl + i) = 0;
+    e.R(L.time) = 0;
+    for (int b = 0; b < m.sz.nbody; b++)
+        if (m.body_mocap[b]) st3(e, L.mocap, mv3(m.body_pos + 3 * b));
+}
+
+}  // namespace mw

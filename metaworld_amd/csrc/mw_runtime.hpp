@@ -1,0 +1,564 @@
+// mw_runtime.hpp -- context / group / snapshot management and the lane programs that the
+// kernels run.  Included by mwgpu.hip (device backend; the product) and by
+// tests/host_harness.cpp (host backend; CPU test harness for the same lane code).
+//
+// The including file must define, before inclusion, a `Backend` struct with:
+//   static void* alloc(size_t bytes);  static void free(void*);  static void zero(void*, size_t);
+//   static void h2d(void* dst, const void* src, size_t);  static void d2h(void* dst, const void* src, size_t);
+//   template <class F> static void launch(int nblocks, F lane_program);   // F(block, thread) for 64 threads / block
+//   static void sync();
+#pragma once
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mw_collide.hpp"
+#include "mw_common.hpp"
+#include "mw_phys.hpp"
+#include "mw_tasks.hpp"
+
+namespace mw {
+
+constexpr int BLOCK = 64;   // one wavefront per workgroup: spreads small batches over as many CUs as possible
+
+// ------------------------------------------------------------------ host-side model description
+struct ModelData {
+    std::map<std::string, std::vector<int>> ints;
+    std::map<std::string, std::vector<double>> reals;
+    Sizes sz{};
+    double timestep = 0.0025, tolerance = 1e-10, meaninertia = 1, gravity[3] = {0, 0, -9.81};
+    const std::vector<int>& I(const std::string& k) const {
+        auto it = ints.find(k);
+        if (it == ints.end()) throw std::runtime_error("model is missing int field " + k);
+        return it->second;
+    }
+    const std::vector<double>& Rr(const std::string& k) const {
+        auto it = reals.find(k);
+        if (it == reals.end()) throw std::runtime_error("model is missing real field " + k);
+        return it->second;
+    }
+    void finalize() {
+        sz.nq = (int)Rr("qpos0").size(); sz.nv = (int)I("dof_bodyid").size(); sz.nbody = (int)I("body_parentid").size();
+        sz.njnt = (int)I("jnt_type").size(); sz.ngeom = (int)I("geom_type").size(); sz.nmesh = (int)I("mesh_vertnum").size();
+        sz.nmeshvert = (int)Rr("mesh_vert").size() / 3; sz.npair = (int)I("pair_geom").size() / 2;
+        sz.nu = (int)I("act_dofid").size(); sz.neq = (int)I("eq_body1").size(); sz.nprobe = (int)I("probe_body").size();
+        sz.nsite = 0;
+        if (sz.nv > MAX_NV) throw std::runtime_error("nv exceeds MAX_NV");
+        if (sz.nu != 2) throw std::runtime_error("expected the two finger position actuators");
+    }
+};
+
+template <typename T, typename Backend>
+struct DeviceModel {
+    Model<T> m{};
+    int* iblob = nullptr;
+    T* rblob = nullptr;
+    explicit DeviceModel(const ModelData& d) {
+        struct IF { const char* name; const int* Model<T>::*p; };
+        struct RF { const char* name; const T* Model<T>::*p; };
+        const IF ifs[] = {{"body_parentid", &Model<T>::body_parentid}, {"body_mocap", &Model<T>::body_mocap},
+            {"body_jntadr", &Model<T>::body_jntadr}, {"body_jntnum", &Model<T>::body_jntnum}, {"body_lastdof", &Model<T>::body_lastdof},
+            {"body_relocid", &Model<T>::body_relocid}, {"jnt_type", &Model<T>::jnt_type}, {"jnt_bodyid", &Model<T>::jnt_bodyid},
+            {"jnt_qposadr", &Model<T>::jnt_qposadr}, {"jnt_dofadr", &Model<T>::jnt_dofadr}, {"jnt_limited", &Model<T>::jnt_limited},
+            {"dof_bodyid", &Model<T>::dof_bodyid}, {"dof_jntid", &Model<T>::dof_jntid}, {"dof_parentid", &Model<T>::dof_parentid},
+            {"geom_type", &Model<T>::geom_type}, {"geom_bodyid", &Model<T>::geom_bodyid}, {"geom_meshid", &Model<T>::geom_meshid},
+            {"geom_condim", &Model<T>::geom_condim}, {"mesh_vertadr", &Model<T>::mesh_vertadr}, {"mesh_vertnum", &Model<T>::mesh_vertnum},
+            {"pair_geom", &Model<T>::pair_geom}, {"act_dofid", &Model<T>::act_dofid}, {"act_qposid", &Model<T>::act_qposid},
+            {"eq_body1", &Model<T>::eq_body1}, {"eq_body2", &Model<T>::eq_body2}, {"probe_body", &Model<T>::probe_body}};
+        const RF rfs[] = {{"body_pos", &Model<T>::body_pos}, {"body_quat", &Model<T>::body_quat}, {"body_ipos", &Model<T>::body_ipos},
+            {"body_iquat", &Model<T>::body_iquat}, {"body_mass", &Model<T>::body_mass}, {"body_inertia", &Model<T>::body_inertia},
+            {"jnt_pos", &Model<T>::jnt_pos}, {"jnt_axis", &Model<T>::jnt_axis}, {"jnt_range", &Model<T>::jnt_range},
+            {"jnt_stiffness", &Model<T>::jnt_stiffness}, {"jnt_springref", &Model<T>::jnt_springref}, {"jnt_solref", &Model<T>::jnt_solref},
+            {"jnt_solimp", &Model<T>::jnt_solimp}, {"jnt_margin", &Model<T>::jnt_margin}, {"dof_armature", &Model<T>::dof_armature},
+            {"dof_damping", &Model<T>::dof_damping}, {"dof_invweight0", &Model<T>::dof_invweight0}, {"qpos0", &Model<T>::qpos0},
+            {"geom_size", &Model<T>::geom_size}, {"geom_pos", &Model<T>::geom_pos}, {"geom_quat", &Model<T>::geom_quat},
+            {"geom_friction", &Model<T>::geom_friction}, {"geom_solref", &Model<T>::geom_solref}, {"geom_solimp", &Model<T>::geom_solimp},
+            {"geom_solmix", &Model<T>::geom_solmix}, {"geom_margin", &Model<T>::geom_margin}, {"geom_gap", &Model<T>::geom_gap},
+            {"geom_rbound", &Model<T>::geom_rbound}, {"geom_invweight0", &Model<T>::geom_invweight0}, {"mesh_vert", &Model<T>::mesh_vert},
+            {"act_kp", &Model<T>::act_kp}, {"act_ctrlrange", &Model<T>::act_ctrlrange}, {"eq_solref", &Model<T>::eq_solref},
+            {"eq_solimp", &Model<T>::eq_solimp}, {"eq_data", &Model<T>::eq_data}, {"eq_invweight0", &Model<T>::eq_invweight0},
+            {"probe_pos", &Model<T>::probe_pos}, {"probe_quat", &Model<T>::probe_quat}};
+        std::vector<int> ib;
+        std::vector<T> rb;
+        std::vector<size_t> ioff, roff;
+        for (auto& f : ifs) { ioff.push_back(ib.size()); const auto& v = d.I(f.name); ib.insert(ib.end(), v.begin(), v.end()); ib.push_back(0); }
+        for (auto& f : rfs) { roff.push_back(rb.size()); const auto& v = d.Rr(f.name); for (double x : v) rb.push_back((T)x); rb.push_back(0); }
+        iblob = (int*)Backend::alloc(ib.size() * sizeof(int));
+        rblob = (T*)Backend::alloc(rb.size() * sizeof(T));
+        Backend::h2d(iblob, ib.data(), ib.size() * sizeof(int));
+        Backend::h2d(rblob, rb.data(), rb.size() * sizeof(T));
+        size_t k = 0;
+        for (auto& f : ifs) m.*(f.p) = iblob + ioff[k++];
+        k = 0;
+        for (auto& f : rfs) m.*(f.p) = rblob + roff[k++];
+        m.sz = d.sz;
+        m.timestep = (T)d.timestep; m.tolerance = (T)d.tolerance; m.meaninertia = (T)d.meaninertia;
+        for (int c = 0; c < 3; c++) m.gravity[c] = (T)d.gravity[c];
+    }
+    ~DeviceModel() { Backend::free(iblob); Backend::free(rblob); }
+    DeviceModel(const DeviceModel&) = delete;
+};
+
+// ------------------------------------------------------------------ device-visible world description
+template <typename T>
+struct GroupDev {
+    Model<T> m;
+    Layout L;
+    T* col;
+    int* icol;
+    size_t stride;
+    int nenv, block0;
+    const int* gid;   // lane -> global env index
+};
+
+struct IOPtrs {
+    const float* act;        // [N][4]
+    const int* next_goal;    // [N] goal index to use at the next auto-reset of each env
+    double* obs;             // [N][D]
+    double* reward;          // [N]
+    uint8_t *terminated, *truncated, *success, *done;   // [N]
+    float* info;             // [N][6]
+    double* final_obs;       // [N][D] (valid where done)
+    double* ep_ret;          // [N]   (valid where done)
+    int* ep_len;             // [N]
+    int D;
+};
+
+template <typename T>
+struct World {
+    const GroupDev<T>* groups;
+    int ngroups;
+    const TaskDesc<T>* tasks;
+    const T* snap;            // reset snapshots
+    const long long* snap_off;  // per task: element offset of goal 0
+    const int* snap_stride;   // per task: elements per snapshot (= nstate + 39)
+    int max_episode_steps, terminate_on_success, one_hot, num_tasks;
+    IOPtrs io;
+};
+
+template <typename T>
+MW_HD bool locate(const World<T>& w, int block, int thread, Env<T>* e, int* gid) {
+    int g = 0;
+    while (g + 1 < w.ngroups && block >= w.groups[g + 1].block0) g++;
+    const GroupDev<T>& G = w.groups[g];
+    const int lane = (block - G.block0) * BLOCK + thread;
+    if (lane >= G.nenv) return false;
+    e->m = &G.m; e->L = G.L; e->col = G.col + lane; e->icol = G.icol + lane; e->stride = G.stride;
+    *gid = G.gid[lane];
+    return true;
+}
+
+template <typename T>
+MW_HD void write_obs(const World<T>& w, const TaskDesc<T>& td, double* dst, const T* obs39, int onehot_id) {
+    for (int k = 0; k < 39; k++) dst[k] = (double)obs39[k];
+    if (w.one_hot)
+        for (int k = 0; k < w.num_tasks; k++) dst[39 + k] = k == onehot_id ? 1.0 : 0.0;
+}
+
+template <typename T>
+MW_HD void load_snapshot(const World<T>& w, const Env<T>& e, int task, int goal, T* obs39) {
+    const T* s = w.snap + w.snap_off[task] + (long long)goal * w.snap_stride[task];
+    const int ns = e.L.nstate;
+    for (int k = 0; k < ns; k++) e.R(k) = s[k];
+    for (int k = 0; k < 39; k++) obs39[k] = s[ns + k];
+}
+
+// ---- lane programs -------------------------------------------------------------------------
+// faithful reset (slow path; builds snapshots and serves explicit mw_reset_full)
+template <typename T>
+MW_HD void lane_reset_full(const World<T>& w, int block, int thread) {
+    Env<T> e; int gid;
+    if (!locate(w, block, thread, &e, &gid)) return;
+    const int task = (int)TK(e, TK_TASK);
+    const TaskDesc<T>& td = w.tasks[task];
+    T obs[39];
+    env_reset(e, td, obs);
+    if (w.io.obs) write_obs(w, td, w.io.obs + (size_t)gid * w.io.D, obs, (int)td.c[15]);
+}
+
+// reset from snapshot for masked envs (mask may be null = all); goal from io.next_goal
+template <typename T>
+MW_HD void lane_reset_snap(const World<T>& w, const uint8_t* mask, int block, int thread) {
+    Env<T> e; int gid;
+    if (!locate(w, block, thread, &e, &gid)) return;
+    if (mask && !mask[gid]) return;
+    const int task = (int)TK(e, TK_TASK);
+    const TaskDesc<T>& td = w.tasks[task];
+    T obs[39];
+    load_snapshot(w, e, task, w.io.next_goal[gid], obs);
+    if (w.io.obs) write_obs(w, td, w.io.obs + (size_t)gid * w.io.D, obs, (int)td.c[15]);
+}
+
+// one VectorEnv.step for one env: SawyerXYZEnv.step + TimeLimit + AutoTerminateOnSuccess + OneHot +
+// RecordEpisodeStatistics + SAME_STEP auto-reset (metaworld/__init__.py:430-454, :465)
+template <typename T>
+MW_HD void lane_step(const World<T>& w, int block, int thread) {
+    Env<T> e; int gid;
+    if (!locate(w, block, thread, &e, &gid)) return;
+    const int task = (int)TK(e, TK_TASK);
+    const TaskDesc<T>& td = w.tasks[task];
+    T act[4], obs[39], reward, success;
+    Info info;
+    for (int k = 0; k < 4; k++) act[k] = (T)w.io.act[(size_t)gid * 4 + k];
+    env_step(e, td, act, obs, &reward, &success, &info);
+    TK(e, TK_SUCCESS) = success;
+    TK(e, TK_ELAPSED) += 1; TK(e, TK_EPRET) += reward; TK(e, TK_EPLEN) += 1;
+    const bool truncated = TK(e, TK_PATHLEN) >= td.max_path_length || TK(e, TK_ELAPSED) >= w.max_episode_steps;
+    const bool terminated = w.terminate_on_success && success == T(1);
+    const IOPtrs& io = w.io;
+    io.reward[gid] = (double)reward;
+    io.terminated[gid] = terminated; io.truncated[gid] = truncated; io.success[gid] = success == T(1);
+    io.done[gid] = terminated || truncated;
+    if (io.info) {
+        float* f = io.info + (size_t)gid * 6;
+        f[0] = info.near_object; f[1] = info.grasp_success; f[2] = info.grasp_reward; f[3] = info.in_place_reward;
+        f[4] = info.obj_to_target; f[5] = info.unscaled_reward;
+    }
+    const int oh = (int)td.c[15];
+    if (terminated || truncated) {
+        if (io.final_obs) write_obs(w, td, io.final_obs + (size_t)gid * io.D, obs, oh);
+        io.ep_ret[gid] = (double)TK(e, TK_EPRET); io.ep_len[gid] = (int)TK(e, TK_EPLEN);
+        load_snapshot(w, e, task, io.next_goal[gid], obs);
+    }
+    write_obs(w, td, io.obs + (size_t)gid * io.D, obs, oh);
+}
+
+// debugging / parity hooks: run raw physics on every lane
+template <typename T>
+MW_HD void lane_debug(const World<T>& w, int what, int n, int block, int thread) {
+    Env<T> e; int gid;
+    if (!locate(w, block, thread, &e, &gid)) return;
+    if (what == 0) forward(e);
+    else if (what == 1) for (int k = 0; k < n; k++) substep(e);
+    else if (what == 2) reset_data(e);
+    else if (what == 3) kinematics(e);
+}
+
+// ------------------------------------------------------------------ host-side context
+struct Config {
+    int precision;   // 0 = fp32, 1 = fp64
+    int device_id, rank, world_size;
+    int max_episode_steps, terminate_on_success, one_hot, num_tasks;
+};
+
+struct TaskSpec {      // precision-independent TaskDesc
+    int kind, probe[P_COUNT], nobj, quat_mode[2], qadr[4], dadr[4], geom[4], reloc[2], partially_observable, max_path_length;
+    double hand_init[3], mocap_low[3], mocap_high[3], goal_low[3], goal_high[3], obj_off[2][3], c[16];
+    int model;         // index into Context::models
+    std::vector<double> goals;   // [ngoals][6]
+};
+
+class ContextBase {
+public:
+    virtual ~ContextBase() {}
+    std::string error;
+    Config cfg{};
+    virtual void finalize() = 0;
+    virtual void build_snapshots() = 0;
+    virtual void reset(const uint8_t* mask, const int* goal_idx, double* obs_out) = 0;
+    virtual void step(const float* act, const int* next_goal, double* obs, double* reward, uint8_t* term, uint8_t* trunc,
+                      uint8_t* success, float* info, double* final_obs, double* ep_ret, int* ep_len) = 0;
+    virtual void step_device_only(const float* d_act, int nsteps, int act_stride_steps, float* kernel_ms) = 0;
+    virtual void upload_actions(const float* act, int nsteps) = 0;
+    virtual void read_col(int gid, const char* what, int n, double* out) = 0;
+    virtual void write_col(int gid, const char* what, int n, const double* in) = 0;
+    virtual void read_icol(int gid, const char* what, int n, int* out) = 0;
+    virtual void debug(int what, int n) = 0;
+    virtual int layout_size(int gid, const char* what) = 0;
+    std::vector<std::shared_ptr<ModelData>> models;
+    std::vector<TaskSpec> tasks;
+    std::vector<int> env_task;   // per global env: task index
+    int obs_dim() const { return 39 + (cfg.one_hot ? cfg.num_tasks : 0); }
+};
+
+template <typename T, typename Backend>
+class Context : public ContextBase {
+    struct Group {
+        std::unique_ptr<DeviceModel<T, Backend>> dm;
+        Layout L;
+        T* col = nullptr;
+        int* icol = nullptr;
+        int* gid_dev = nullptr;
+        size_t stride = 0;
+        int nenv = 0, block0 = 0, model = 0;
+        std::vector<int> gid;
+    };
+    std::vector<Group> groups_;
+    std::vector<int> env_group_, env_lane_;
+    GroupDev<T>* d_groups_ = nullptr;
+    TaskDesc<T>* d_tasks_ = nullptr;
+    T* d_snap_ = nullptr;
+    long long* d_snap_off_ = nullptr;
+    int* d_snap_stride_ = nullptr;
+    int nblocks_ = 0, N_ = 0;
+    // io buffers (device) + host staging
+    float* d_act_ = nullptr; size_t act_capacity_steps_ = 0;
+    int* d_next_goal_ = nullptr;
+    uint8_t* d_mask_ = nullptr;
+    double *d_obs_ = nullptr, *d_reward_ = nullptr, *d_final_ = nullptr, *d_epret_ = nullptr;
+    uint8_t* d_flags_ = nullptr;   // terminated, truncated, success, done : 4 x N
+    float* d_info_ = nullptr;
+    int* d_eplen_ = nullptr;
+    std::vector<long long> snap_off_;
+    std::vector<int> snap_stride_;
+
+    World<T> world(bool with_io = true) const {
+        World<T> w{};
+        w.groups = d_groups_; w.ngroups = (int)groups_.size(); w.tasks = d_tasks_;
+        w.snap = d_snap_; w.snap_off = d_snap_off_; w.snap_stride = d_snap_stride_;
+        w.max_episode_steps = cfg.max_episode_steps; w.terminate_on_success = cfg.terminate_on_success;
+        w.one_hot = cfg.one_hot; w.num_tasks = cfg.num_tasks;
+        if (with_io) {
+            w.io.act = d_act_; w.io.next_goal = d_next_goal_; w.io.obs = d_obs_; w.io.reward = d_reward_;
+            w.io.terminated = d_flags_; w.io.truncated = d_flags_ + N_; w.io.success = d_flags_ + 2 * N_; w.io.done = d_flags_ + 3 * N_;
+            w.io.info = d_info_; w.io.final_obs = d_final_; w.io.ep_ret = d_epret_; w.io.ep_len = d_eplen_; w.io.D = obs_dim();
+        }
+        return w;
+    }
+    static TaskDesc<T> to_desc(const TaskSpec& s) {
+        TaskDesc<T> d{};
+        d.kind = s.kind; d.nobj = s.nobj; d.partially_observable = s.partially_observable; d.max_path_length = s.max_path_length;
+        for (int k = 0; k < P_COUNT; k++) d.probe[k] = s.probe[k];
+        for (int k = 0; k < 2; k++) { d.quat_mode[k] = s.quat_mode[k]; d.reloc[k] = s.reloc[k]; for (int c = 0; c < 3; c++) d.obj_off[k][c] = (T)s.obj_off[k][c]; }
+        for (int k = 0; k < 4; k++) { d.qadr[k] = s.qadr[k]; d.dadr[k] = s.dadr[k]; d.geom[k] = s.geom[k]; }
+        for (int k = 0; k < 3; k++) {
+            d.hand_init[k] = (T)s.hand_init[k]; d.mocap_low[k] = (T)s.mocap_low[k]; d.mocap_high[k] = (T)s.mocap_high[k];
+            d.goal_low[k] = (T)s.goal_low[k]; d.goal_high[k] = (T)s.goal_high[k];
+        }
+        for (int k = 0; k < 16; k++) d.c[k] = (T)s.c[k];
+        return d;
+    }
+    void make_group(Group& g, int model, const std::vector<int>& gids) {
+        g.model = model;
+        g.dm.reset(new DeviceModel<T, Backend>(*models[model]));
+        g.L = make_layout(models[model]->sz);
+        g.nenv = (int)gids.size();
+        g.gid = gids;
+        g.stride = (size_t)((g.nenv + BLOCK - 1) / BLOCK) * BLOCK;
+        g.col = (T*)Backend::alloc(sizeof(T) * g.stride * g.L.nreal);
+        g.icol = (int*)Backend::alloc(sizeof(int) * g.stride * g.L.nint);
+        Backend::zero(g.col, sizeof(T) * g.stride * g.L.nreal);
+        Backend::zero(g.icol, sizeof(int) * g.stride * g.L.nint);
+        g.gid_dev = (int*)Backend::alloc(sizeof(int) * g.nenv);
+        Backend::h2d(g.gid_dev, gids.data(), sizeof(int) * g.nenv);
+    }
+    void free_group(Group& g) { Backend::free(g.col); Backend::free(g.icol); Backend::free(g.gid_dev); g.col = nullptr; }
+    GroupDev<T> dev_of(const Group& g) const {
+        GroupDev<T> d{};
+        d.m = g.dm->m; d.L = g.L; d.col = g.col; d.icol = g.icol; d.stride = g.stride; d.nenv = g.nenv; d.block0 = g.block0; d.gid = g.gid_dev;
+        return d;
+    }
+    void set_task_field(Group& g, int lane, int k, double v) {
+        T x = (T)v;
+        Backend::h2d(g.col + (size_t)(g.L.task + k) * g.stride + lane, &x, sizeof(T));
+    }
+
+public:
+    ~Context() override {
+        for (auto& g : groups_) free_group(g);
+        Backend::free(d_groups_); Backend::free(d_tasks_); Backend::free(d_snap_); Backend::free(d_snap_off_); Backend::free(d_snap_stride_);
+        Backend::free(d_act_); Backend::free(d_next_goal_); Backend::free(d_mask_); Backend::free(d_obs_); Backend::free(d_reward_);
+        Backend::free(d_final_); Backend::free(d_epret_); Backend::free(d_flags_); Backend::free(d_info_); Backend::free(d_eplen_);
+    }
+
+    void finalize() override {
+        N_ = (int)env_task.size();
+        if (N_ == 0) throw std::runtime_error("no environments");
+        // one group per model, lanes in global-env order
+        std::map<int, std::vector<int>> by_model;
+        for (int i = 0; i < N_; i++) by_model[tasks.at(env_task[i]).model].push_back(i);
+        env_group_.assign(N_, 0); env_lane_.assign(N_, 0);
+        groups_.resize(by_model.size());
+        int gi = 0, blk = 0;
+        for (auto& kv : by_model) {
+            Group& g = groups_[gi];
+            make_group(g, kv.first, kv.second);
+            g.block0 = blk;
+            blk += (g.nenv + BLOCK - 1) / BLOCK;
+            for (int l = 0; l < g.nenv; l++) { env_group_[kv.second[l]] = gi; env_lane_[kv.second[l]] = l; }
+            gi++;
+        }
+        nblocks_ = blk;
+        std::vector<GroupDev<T>> gd;
+        for (auto& g : groups_) gd.push_back(dev_of(g));
+        d_groups_ = (GroupDev<T>*)Backend::alloc(sizeof(GroupDev<T>) * gd.size());
+        Backend::h2d(d_groups_, gd.data(), sizeof(GroupDev<T>) * gd.size());
+        std::vector<TaskDesc<T>> td;
+        for (auto& s : tasks) td.push_back(to_desc(s));
+        d_tasks_ = (TaskDesc<T>*)Backend::alloc(sizeof(TaskDesc<T>) * td.size());
+        Backend::h2d(d_tasks_, td.data(), sizeof(TaskDesc<T>) * td.size());
+        const int D = obs_dim();
+        d_next_goal_ = (int*)Backend::alloc(sizeof(int) * N_); Backend::zero(d_next_goal_, sizeof(int) * N_);
+        d_mask_ = (uint8_t*)Backend::alloc(N_);
+        d_obs_ = (double*)Backend::alloc(sizeof(double) * N_ * D); d_final_ = (double*)Backend::alloc(sizeof(double) * N_ * D);
+        Backend::zero(d_final_, sizeof(double) * N_ * D);
+        d_reward_ = (double*)Backend::alloc(sizeof(double) * N_); d_epret_ = (double*)Backend::alloc(sizeof(double) * N_);
+        Backend::zero(d_epret_, sizeof(double) * N_);
+        d_flags_ = (uint8_t*)Backend::alloc(4 * N_); d_info_ = (float*)Backend::alloc(sizeof(float) * 6 * N_);
+        d_eplen_ = (int*)Backend::alloc(sizeof(int) * N_); Backend::zero(d_eplen_, sizeof(int) * N_);
+        d_act_ = (float*)Backend::alloc(sizeof(float) * 4 * N_); act_capacity_steps_ = 1;
+        for (int i = 0; i < N_; i++) set_task_field(groups_[env_group_[i]], env_lane_[i], TK_TASK, env_task[i]);
+        build_snapshots();
+    }
+
+    // run the faithful reset once per (task, goal) and keep the resulting persistent state + reset observation
+    void build_snapshots() override {
+        Backend::free(d_snap_); Backend::free(d_snap_off_); Backend::free(d_snap_stride_);
+        snap_off_.assign(tasks.size(), 0); snap_stride_.assign(tasks.size(), 0);
+        long long total = 0;
+        for (size_t t = 0; t < tasks.size(); t++) {
+            const int ns = make_layout(models[tasks[t].model]->sz).nstate + 39;
+            snap_off_[t] = total; snap_stride_[t] = ns;
+            total += (long long)ns * (tasks[t].goals.size() / 6);
+        }
+        std::vector<T> snap((size_t)total);
+        // temporary groups: one per model, one lane per (task, goal)
+        std::map<int, std::vector<std::pair<int, int>>> by_model;
+        for (size_t t = 0; t < tasks.size(); t++)
+            for (size_t g = 0; g < tasks[t].goals.size() / 6; g++) by_model[tasks[t].model].push_back({(int)t, (int)g});
+        for (auto& kv : by_model) {
+            Group g;
+            std::vector<int> gids(kv.second.size());
+            for (size_t i = 0; i < gids.size(); i++) gids[i] = (int)i;
+            make_group(g, kv.first, gids);
+            // seed the task block of each lane: task id, goal idx, rand_vec
+            std::vector<T> host((size_t)g.L.nstate * g.stride, (T)0);
+            for (size_t l = 0; l < kv.second.size(); l++) {
+                const int t = kv.second[l].first, go = kv.second[l].second;
+                host[(size_t)(g.L.task + TK_TASK) * g.stride + l] = (T)t;
+                host[(size_t)(g.L.task + TK_GOAL) * g.stride + l] = (T)go;
+                for (int k = 0; k < 6; k++) host[(size_t)(g.L.task + TK_RANDVEC + k) * g.stride + l] = (T)tasks[t].goals[6 * go + k];
+            }
+            Backend::h2d(g.col, host.data(), host.size() * sizeof(T));
+            GroupDev<T> gd = dev_of(g);
+            GroupDev<T>* d_g = (GroupDev<T>*)Backend::alloc(sizeof(GroupDev<T>));
+            Backend::h2d(d_g, &gd, sizeof(gd));
+            const int D = obs_dim();
+            double* d_o = (double*)Backend::alloc(sizeof(double) * g.nenv * D);
+            World<T> w = world(false);
+            w.groups = d_g; w.ngroups = 1; w.io.obs = d_o; w.io.D = D;
+            Backend::launch((g.nenv + BLOCK - 1) / BLOCK, [w] MW_LAMBDA(int b, int t) { lane_reset_full(w, b, t); });
+            Backend::sync();
+            Backend::d2h(host.data(), g.col, host.size() * sizeof(T));
+            std::vector<double> obs((size_t)g.nenv * D);
+            Backend::d2h(obs.data(), d_o, obs.size() * sizeof(double));
+            for (size_t l = 0; l < kv.second.size(); l++) {
+                const int t = kv.second[l].first, go = kv.second[l].second;
+                T* dst = snap.data() + snap_off_[t] + (long long)go * snap_stride_[t];
+                for (int k = 0; k < g.L.nstate; k++) dst[k] = host[(size_t)k * g.stride + l];
+                for (int k = 0; k < 39; k++) dst[g.L.nstate + k] = (T)obs[l * D + k];
+            }
+            Backend::free(d_o); Backend::free(d_g);
+            free_group(g);
+        }
+        d_snap_ = (T*)Backend::alloc(sizeof(T) * (size_t)(total > 0 ? total : 1));
+        Backend::h2d(d_snap_, snap.data(), sizeof(T) * (size_t)total);
+        d_snap_off_ = (long long*)Backend::alloc(sizeof(long long) * tasks.size());
+        Backend::h2d(d_snap_off_, snap_off_.data(), sizeof(long long) * tasks.size());
+        d_snap_stride_ = (int*)Backend::alloc(sizeof(int) * tasks.size());
+        Backend::h2d(d_snap_stride_, snap_stride_.data(), sizeof(int) * tasks.size());
+    }
+
+    void reset(const uint8_t* mask, const int* goal_idx, double* obs_out) override {
+        Backend::h2d(d_next_goal_, goal_idx, sizeof(int) * N_);
+        const uint8_t* dm = nullptr;
+        if (mask) { Backend::h2d(d_mask_, mask, N_); dm = d_mask_; }
+        World<T> w = world();
+        Backend::launch(nblocks_, [w, dm] MW_LAMBDA(int b, int t) { lane_reset_snap(w, dm, b, t); });
+        Backend::sync();
+        if (obs_out) Backend::d2h(obs_out, d_obs_, sizeof(double) * N_ * obs_dim());
+    }
+
+    void step(const float* act, const int* next_goal, double* obs, double* reward, uint8_t* term, uint8_t* trunc,
+              uint8_t* success, float* info, double* final_obs, double* ep_ret, int* ep_len) override {
+        Backend::h2d(d_act_, act, sizeof(float) * 4 * N_);
+        if (next_goal) Backend::h2d(d_next_goal_, next_goal, sizeof(int) * N_);
+        World<T> w = world();
+        Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t) { lane_step(w, b, t); });
+        Backend::sync();
+        const int D = obs_dim();
+        if (obs) Backend::d2h(obs, d_obs_, sizeof(double) * N_ * D);
+        if (reward) Backend::d2h(reward, d_reward_, sizeof(double) * N_);
+        if (term) Backend::d2h(term, d_flags_, N_);
+        if (trunc) Backend::d2h(trunc, d_flags_ + N_, N_);
+        if (success) Backend::d2h(success, d_flags_ + 2 * N_, N_);
+        if (info) Backend::d2h(info, d_info_, sizeof(float) * 6 * N_);
+        if (final_obs) Backend::d2h(final_obs, d_final_, sizeof(double) * N_ * D);
+        if (ep_ret) Backend::d2h(ep_ret, d_epret_, sizeof(double) * N_);
+        if (ep_len) Backend::d2h(ep_len, d_eplen_, sizeof(int) * N_);
+    }
+
+    void upload_actions(const float* act, int nsteps) override {
+        if ((size_t)nsteps > act_capacity_steps_) {
+            Backend::free(d_act_);
+            d_act_ = (float*)Backend::alloc(sizeof(float) * 4 * N_ * nsteps);
+            act_capacity_steps_ = nsteps;
+        }
+        Backend::h2d(d_act_, act, sizeof(float) * 4 * N_ * nsteps);
+    }
+
+    // bench path: actions already resident on the device; outputs stay on the device
+    void step_device_only(const float* d_act, int nsteps, int act_steps, float* kernel_ms) override {
+        World<T> w = world();
+        const float* base = d_act ? d_act : d_act_;
+        Backend::timed_begin();
+        for (int s = 0; s < nsteps; s++) {
+            w.io.act = base + (size_t)(act_steps > 0 ? s % act_steps : 0) * 4 * N_;
+            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t) { lane_step(w, b, t); });
+        }
+        float ms = Backend::timed_end();
+        if (kernel_ms) *kernel_ms = ms;
+    }
+
+    void debug(int what, int n) override {
+        World<T> w = world();
+        Backend::launch(nblocks_, [w, what, n] MW_LAMBDA(int b, int t) { lane_debug(w, what, n, b, t); });
+        Backend::sync();
+    }
+
+    static int offset_of(const Layout& L, const Sizes& s, const std::string& k, int* n) {
+        struct E { const char* name; int off, n; };
+        const E tab[] = {{"qpos", L.qpos, s.nq}, {"qvel", L.qvel, s.nv}, {"warm", L.warm, s.nv}, {"ctrl", L.ctrl, s.nu}, {"mocap", L.mocap, 3},
+            {"reloc", L.reloc, 3 * (s.nreloc > 0 ? s.nreloc : 1)}, {"time", L.time, 1}, {"task", L.task, TASK_NREAL}, {"state", 0, L.nstate},
+            {"xpos", L.xpos, 3 * s.nbody}, {"xquat", L.xquat, 4 * s.nbody}, {"xmat", L.xmat, 9 * s.nbody}, {"xipos", L.xipos, 3 * s.nbody},
+            {"geom_xpos", L.geom_xpos, 3 * s.ngeom}, {"geom_xmat", L.geom_xmat, 9 * s.ngeom}, {"cdof", L.cdof, 6 * s.nv},
+            {"qM", L.qM, s.nv * s.nv}, {"qL", L.qL, s.nv * s.nv}, {"bias", L.bias, s.nv}, {"smooth", L.smooth, s.nv},
+            {"qacc_smooth", L.qacc_smooth, s.nv}, {"qfrc_constraint", L.qfrc_c, s.nv}, {"qacc", L.qacc, s.nv},
+            {"con", L.con, CON_STRIDE * s.maxcon}, {"efcJ", L.efcJ, s.nv * s.maxefc}, {"efcX", L.efcX, EFC_EXTRA * s.maxefc}};
+        for (auto& e : tab) if (k == e.name) { *n = e.n; return e.off; }
+        throw std::runtime_error("unknown column " + k);
+    }
+    static int ioffset_of(const Layout& L, const Sizes& s, const std::string& k, int* n) {
+        if (k == "icon") { *n = CON_ISTRIDE * s.maxcon; return L.icon; }
+        if (k == "iefc") { *n = EFC_ISTRIDE * s.maxefc; return L.iefc; }
+        if (k == "icount") { *n = 4; return L.icount; }
+        throw std::runtime_error("unknown int column " + k);
+    }
+    int layout_size(int gid, const char* what) override {
+        int n; const Group& g = groups_.at(env_group_.at(gid));
+        try { offset_of(g.L, models[g.model]->sz, what, &n); } catch (...) { ioffset_of(g.L, models[g.model]->sz, what, &n); }
+        return n;
+    }
+    void read_col(int gid, const char* what, int n, double* out) override {
+        const Group& g = groups_.at(env_group_.at(gid));
+        int cnt; const int off = offset_of(g.L, models[g.model]->sz, what, &cnt);
+        if (n > cnt) n = cnt;
+        for (int k = 0; k < n; k++) { T x; Backend::d2h(&x, g.col + (size_t)(off + k) * g.stride + env_lane_[gid], sizeof(T)); out[k] = (double)x; }
+    }
+    void write_col(int gid, const char* what, int n, const double* in) override {
+        Group& g = groups_.at(env_group_.at(gid));
+        int cnt; const int off = offset_of(g.L, models[g.model]->sz, what, &cnt);
+        if (n > cnt) n = cnt;
+        for (int k = 0; k < n; k++) { T x = (T)in[k]; Backend::h2d(g.col + (size_t)(off + k) * g.stride + env_lane_[gid], &x, sizeof(T)); }
+    }
+    void read_icol(int gid, const char* what, int n, int* out) override {
+        const Group& g = groups_.at(env_group_.at(gid));
+        int cnt; const int off = ioffset_of(g.L, models[g.model]->sz, what, &cnt);
+        if (n > cnt) n = cnt;
+        for (int k = 0; k < n; k++) Backend::d2h(out + k, g.icol + (size_t)(off + k) * g.stride + env_lane_[gid], sizeof(int));
+    }
+};
+
+}  // namespace mw

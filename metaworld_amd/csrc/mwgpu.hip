@@ -1,0 +1,66 @@
+// mwgpu.hip -- libmwgpu.so: HIP (gfx950) backend of the batched Meta-World runtime + its C ABI (include/mwgpu.h).
+//
+// Kernel shape: one wavefront (64 lanes = 64 environments) per workgroup, grid = sum over model groups of
+// ceil(n_env / 64); every wavefront is model-uniform.  All per-env data is in the column store described in
+// mw_common.hpp, so each per-env load/store of a wave is one coalesced request.
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+
+#define MW_LAMBDA __host__ __device__
+
+namespace {
+inline void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_lanes(F f) { f((int)blockIdx.x, (int)threadIdx.x); }
+
+struct Backend {
+    static hipStream_t& stream() { static hipStream_t s = nullptr; return s; }
+    static hipEvent_t* events() { static hipEvent_t ev[2] = {nullptr, nullptr}; return ev; }
+    static void init(int device) {
+        int n = 0;
+        hip_check(hipGetDeviceCount(&n), "hipGetDeviceCount");
+        if (n <= 0) throw std::runtime_error("libmwgpu: no HIP device visible (this library has no CPU fallback)");
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        if (!stream()) {
+            hip_check(hipStreamCreateWithFlags(&stream(), hipStreamNonBlocking), "hipStreamCreate");
+            hip_check(hipEventCreate(&events()[0]), "hipEventCreate");
+            hip_check(hipEventCreate(&events()[1]), "hipEventCreate");
+        }
+    }
+    static void* alloc(size_t bytes) { void* p = nullptr; hip_check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc"); return p; }
+    static void free(void* p) { if (p) (void)hipFree(p); }
+    static void zero(void* p, size_t bytes) { hip_check(hipMemsetAsync(p, 0, bytes, stream()), "hipMemset"); }
+    static void h2d(void* dst, const void* src, size_t bytes) {
+        hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream()), "hipMemcpy H2D");
+        hip_check(hipStreamSynchronize(stream()), "sync");
+    }
+    static void d2h(void* dst, const void* src, size_t bytes) {
+        hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream()), "hipMemcpy D2H");
+        hip_check(hipStreamSynchronize(stream()), "sync");
+    }
+    template <class F>
+    static void launch(int nblocks, F f) {
+        hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), 0, stream(), f);
+        hip_check(hipGetLastError(), "kernel launch");
+    }
+    static void sync() { hip_check(hipStreamSynchronize(stream()), "hipStreamSynchronize"); }
+    static void timed_begin() { hip_check(hipEventRecord(events()[0], stream()), "hipEventRecord"); }
+    static float timed_end() {
+        hip_check(hipEventRecord(events()[1], stream()), "hipEventRecord");
+        hip_check(hipEventSynchronize(events()[1]), "hipEventSynchronize");
+        float ms = 0;
+        hip_check(hipEventElapsedTime(&ms, events()[0], events()[1]), "hipEventElapsedTime");
+        return ms;
+    }
+};
+}  // namespace
+
+#include "mw_runtime.hpp"
+
+#include "../../include/mwgpu.h"
+#define MW_API(name) mw_##name
+#include "mw_abi.inl"

@@ -816,3 +816,26 @@ def _set_const(m: Model):
     A["body_invweight0"] = inv_b
     A["dof_invweight0"] = inv_d
     A["stat_meaninertia"] = np.array([np.trace(M) / max(nv, 1)])
+
+
+# ----------------------------------------------------------------------------
+# (de)serialisation of compiled models: the GPU box has no MJCF/STL assets, only these tables
+# ----------------------------------------------------------------------------
+def save_model(m: Model, path):
+    import json
+    meta = dict(name=m.name, opt_timestep=m.opt_timestep, opt_iterations=m.opt_iterations,
+                opt_tolerance=m.opt_tolerance, gravity=list(map(float, m.gravity)), names=m.names)
+    np.savez_compressed(path, __meta__=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **m.arrays)
+
+
+def load_model(path) -> Model:
+    import json
+    z = np.load(path)
+    meta = json.loads(bytes(z["__meta__"]).decode())
+    m = Model(name=meta["name"], opt_timestep=meta["opt_timestep"], opt_iterations=meta["opt_iterations"],
+              opt_tolerance=meta["opt_tolerance"], gravity=np.array(meta["gravity"]))
+    m.names = meta["names"]
+    for k in z.files:
+        if k != "__meta__":
+            m.arrays[k] = z[k]
+    return m

@@ -1,0 +1,202 @@
+"""ctypes binding of the C ABI in include/mwgpu.h.
+
+`load()` returns the HIP library (metaworld_amd/libmwgpu.so) and raises if it is missing or
+if no GPU is visible -- the product path has no CPU fallback.  `load(prefix="mwh_", path=...)`
+is used by the CPU test-suite to drive tests/host_harness.cpp (same lane code, host loops).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmwgpu.so")
+NPROBE = 16
+
+
+class MwConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("precision", "device_id", "rank", "world_size", "max_episode_steps",
+                                         "terminate_on_success", "one_hot", "num_tasks")]
+
+
+class MwTask(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("model", C.c_int32), ("onehot_id", C.c_int32), ("probe", C.c_int32 * NPROBE),
+                ("nobj", C.c_int32), ("quat_mode", C.c_int32 * 2), ("qadr", C.c_int32 * 4), ("dadr", C.c_int32 * 4),
+                ("geom", C.c_int32 * 4), ("reloc", C.c_int32 * 2), ("partially_observable", C.c_int32),
+                ("max_path_length", C.c_int32), ("hand_init", C.c_double * 3), ("mocap_low", C.c_double * 3),
+                ("mocap_high", C.c_double * 3), ("goal_low", C.c_double * 3), ("goal_high", C.c_double * 3),
+                ("obj_off", (C.c_double * 3) * 2), ("c", C.c_double * 15)]
+
+
+class Lib:
+    def __init__(self, path, prefix):
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        self.dll = C.CDLL(path)
+        self.prefix = prefix
+        f = self._f
+        f("model_new", C.c_void_p)
+        f("model_free", None, C.c_void_p)
+        f("model_set_int", C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int)
+        f("model_set_real", C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int)
+        f("model_set_option", C.c_int, C.c_void_p, C.c_char_p, C.c_double)
+        f("create", C.c_int, C.POINTER(MwConfig), C.POINTER(C.c_void_p))
+        f("add_model", C.c_int, C.c_void_p, C.c_void_p)
+        f("add_task", C.c_int, C.c_void_p, C.POINTER(MwTask), C.c_void_p, C.c_int)
+        f("set_envs", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+        f("finalize", C.c_int, C.c_void_p)
+        f("destroy", None, C.c_void_p)
+        f("last_error", C.c_char_p, C.c_void_p)
+        f("num_envs", C.c_int, C.c_void_p)
+        f("obs_dim", C.c_int, C.c_void_p)
+        f("reset", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+        f("step", C.c_int, *([C.c_void_p] * 12))
+        f("upload_actions", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+        f("step_resident", C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float))
+        f("column_size", C.c_int, C.c_void_p, C.c_int, C.c_char_p)
+        f("read", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
+        f("write", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
+        f("read_int", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
+        f("debug", C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+    def _f(self, name, restype, *argtypes):
+        fn = getattr(self.dll, self.prefix + name)
+        fn.restype = restype
+        fn.argtypes = list(argtypes)
+        setattr(self, name, fn)
+
+
+_libs = {}
+
+
+def load(prefix="mw_", path=None) -> Lib:
+    path = path or LIB_PATH
+    key = (prefix, path)
+    if key not in _libs:
+        _libs[key] = Lib(path, prefix)
+    return _libs[key]
+
+
+EXPORTED_SYMBOLS = ["model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
+                    "add_model", "add_task", "set_envs", "finalize", "destroy", "last_error", "num_envs", "obs_dim",
+                    "reset", "step", "upload_actions", "step_resident", "column_size", "read", "write", "read_int",
+                    "debug"]
+
+
+class Context:
+    """Thin object wrapper over mw_ctx."""
+
+    def __init__(self, lib: Lib, precision=0, device_id=0, rank=0, world_size=1, max_episode_steps=500,
+                 terminate_on_success=False, one_hot=False, num_tasks=1):
+        self.lib = lib
+        cfg = MwConfig(int(precision), device_id, rank, world_size, max_episode_steps, int(terminate_on_success),
+                       int(one_hot), num_tasks)
+        self.ptr = C.c_void_p()
+        rc = lib.create(C.byref(cfg), C.byref(self.ptr))
+        self._check(rc)
+        self.N = 0
+        self.D = 39 + (num_tasks if one_hot else 0)
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RuntimeError("mwgpu: " + self.lib.last_error(self.ptr).decode())
+        return rc
+
+    def add_model(self, packed) -> int:
+        """packed: dict(ints={name: int32 array}, reals={name: float64 array}, options={name: float})"""
+        L = self.lib
+        m = C.c_void_p(L.model_new())
+        keep = []
+        for k, v in packed["ints"].items():
+            a = np.ascontiguousarray(v, dtype=np.int32)
+            keep.append(a)
+            L.model_set_int(m, k.encode(), a.ctypes.data, a.size)
+        for k, v in packed["reals"].items():
+            a = np.ascontiguousarray(v, dtype=np.float64)
+            keep.append(a)
+            L.model_set_real(m, k.encode(), a.ctypes.data, a.size)
+        for k, v in packed["options"].items():
+            if L.model_set_option(m, k.encode(), float(v)) != 0:
+                raise RuntimeError(f"unknown model option {k}")
+        idx = self._check(L.add_model(self.ptr, m))
+        L.model_free(m)
+        return idx
+
+    def add_task(self, task: MwTask, goals) -> int:
+        g = np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 6)
+        return self._check(self.lib.add_task(self.ptr, C.byref(task), g.ctypes.data, len(g)))
+
+    def set_envs(self, env_task):
+        a = np.ascontiguousarray(env_task, dtype=np.int32)
+        self.N = len(a)
+        self._check(self.lib.set_envs(self.ptr, a.ctypes.data, len(a)))
+
+    def finalize(self):
+        self._check(self.lib.finalize(self.ptr))
+        N, D = self.N, self.D
+        self.obs = np.zeros((N, D)); self.final_obs = np.zeros((N, D))
+        self.reward = np.zeros(N); self.ep_ret = np.zeros(N); self.ep_len = np.zeros(N, dtype=np.int32)
+        self.terminated = np.zeros(N, dtype=np.uint8); self.truncated = np.zeros(N, dtype=np.uint8)
+        self.success = np.zeros(N, dtype=np.uint8); self.info = np.zeros((N, 6), dtype=np.float32)
+
+    def reset(self, goal_idx, mask=None):
+        g = np.ascontiguousarray(goal_idx, dtype=np.int32)
+        mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._check(self.lib.reset(self.ptr, None if mk is None else mk.ctypes.data, g.ctypes.data, self.obs.ctypes.data))
+        return self.obs
+
+    def step(self, actions, next_goal=None):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        assert a.shape == (self.N, 4)
+        ng = None if next_goal is None else np.ascontiguousarray(next_goal, dtype=np.int32)
+        self._check(self.lib.step(self.ptr, a.ctypes.data, None if ng is None else ng.ctypes.data, self.obs.ctypes.data,
+                                  self.reward.ctypes.data, self.terminated.ctypes.data, self.truncated.ctypes.data,
+                                  self.success.ctypes.data, self.info.ctypes.data, self.final_obs.ctypes.data,
+                                  self.ep_ret.ctypes.data, self.ep_len.ctypes.data))
+        return self.obs, self.reward, self.terminated, self.truncated, self.success, self.info
+
+    def upload_actions(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        assert a.ndim == 3 and a.shape[1:] == (self.N, 4)
+        self._check(self.lib.upload_actions(self.ptr, a.ctypes.data, a.shape[0]))
+        self._resident_steps = a.shape[0]
+
+    def step_resident(self, nsteps):
+        ms = C.c_float(0)
+        self._check(self.lib.step_resident(self.ptr, nsteps, self._resident_steps, C.byref(ms)))
+        return ms.value
+
+    def read(self, env, what, n=None):
+        if n is None:
+            n = self._check(self.lib.column_size(self.ptr, env, what.encode()))
+        out = np.zeros(n)
+        self._check(self.lib.read(self.ptr, env, what.encode(), out.ctypes.data, n))
+        return out
+
+    def read_int(self, env, what, n=None):
+        if n is None:
+            n = self._check(self.lib.column_size(self.ptr, env, what.encode()))
+        out = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.read_int(self.ptr, env, what.encode(), out.ctypes.data, n))
+        return out
+
+    def write(self, env, what, values):
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        self._check(self.lib.write(self.ptr, env, what.encode(), a.ctypes.data, a.size))
+
+    def debug(self, what, n=0):
+        self._check(self.lib.debug(self.ptr, {"forward": 0, "substeps": 1, "reset_data": 2, "kinematics": 3}[what], n))
+
+    def close(self):
+        if self.ptr:
+            self.lib.destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

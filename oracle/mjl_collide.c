@@ -475,12 +475,13 @@ static void tri_closest_origin(const double* a, const double* b, const double* c
     double den = 1 / (va + vb + vc);
     w[1] = vb * den; w[2] = vc * den; w[0] = 1 - w[1] - w[2];
 }
-static int mpr(const Shape* A, const Shape* B, double margin, Hit* h) {
+static int mpr(const Shape* A, const Shape* B, double margin, Hit* h, const double* v0_override) {
     SV v0, v1, v2, v3, v4;
     double dir[3], t[3], t2[3];
     /* interior point of B-A */
     copy3(v0.a, A->pos); copy3(v0.b, B->pos);
     sub3(v0.v, v0.b, v0.a);
+    if (v0_override) copy3(v0.v, v0_override);
     if (norm3(v0.v) < 1e-10) v0.v[0] = 1e-5;
     scl3(dir, v0.v, -1); normalize3(dir);
     msupport(A, B, dir, &v1);
@@ -543,6 +544,75 @@ static int mpr(const Shape* A, const Shape* B, double margin, Hit* h) {
     return 1;
 }
 
+/* MPR's penetration direction depends on the interior ray (centre to centre).  Re-shoot the ray along the
+   normal just found until the depth stops decreasing: converges to a local minimum-translation direction. */
+static int mpr_refined(const Shape* A, const Shape* B, double margin, Hit* h) {
+    if (!mpr(A, B, margin, h, NULL)) return 0;
+    for (int it = 0; it < 4; it++) {
+        double depth = margin - h->dist, v0[3];
+        if (depth <= 1e-9) break;
+        scl3(v0, h->normal, 0.02 * depth);
+        Hit h2;
+        if (!mpr(A, B, margin, &h2, v0)) break;
+        double d2 = margin - h2.dist;
+        if (d2 >= depth * (1 - 1e-6)) break;
+        *h = h2;
+    }
+    return 1;
+}
+
+/* A cylinder / capsule touching the interior of a box face: replace the single MPR point by the
+   multi-point plane-cylinder / plane-capsule contact against that face (well-conditioned resting and
+   grasp contacts).  Returns 0 when the MPR normal is not a face normal or no point lies on the face. */
+static int face_upgrade(const Shape* c, const Shape* box, Hit* h, double margin) {
+    double n[3], ax[3];
+    copy3(n, h[0].normal);                 /* from the cylinder/capsule toward the box */
+    int k = -1;
+    double best = 0;
+    for (int i = 0; i < 3; i++) {
+        col3(ax, box->mat, i);
+        double cth = dot3(ax, n);
+        if (fabs(cth) > fabs(best)) { best = cth; k = i; }
+    }
+    if (fabs(best) < 1 - 1e-4) return 0;
+    /* face plane: outward normal nf = -sign(best) * axis_k, passing through the face centre */
+    double nf[3], p0[3], pm[9];
+    col3(ax, box->mat, k);
+    scl3(nf, ax, best > 0 ? -1 : 1);
+    addscl3(p0, box->pos, nf, box->size[k]);
+    /* build a plane shape whose z axis is nf */
+    double fr[9];
+    copy3(fr, nf); fr[3] = fr[4] = fr[5] = 0;
+    if (nf[1] < 0.5 && nf[1] > -0.5) fr[4] = 1; else fr[5] = 1;
+    double tt = dot3(fr, fr + 3);
+    addscl3(fr + 3, fr + 3, fr, -tt); normalize3(fr + 3);
+    cross3(fr + 6, fr, fr + 3);
+    for (int r = 0; r < 3; r++) { pm[3 * r + 2] = fr[r]; pm[3 * r + 0] = fr[3 + r]; pm[3 * r + 1] = fr[6 + r]; }
+    Shape pl;
+    memset(&pl, 0, sizeof pl);
+    pl.type = MJL_PLANE; pl.pos = p0; pl.mat = pm; pl.size = box->size;
+    Hit t[8];
+    int cnt = c->type == MJL_CYLINDER ? plane_cylinder(&pl, c, margin, t) : plane_capsule(&pl, c, margin, t);
+    int m = 0;
+    Hit out[8];
+    for (int i = 0; i < cnt; i++) {
+        double d_[3];
+        sub3(d_, t[i].pos, box->pos);
+        int inside = 1;
+        for (int j = 0; j < 3; j++) {
+            if (j == k) continue;
+            col3(ax, box->mat, j);
+            if (fabs(dot3(d_, ax)) > box->size[j] + 1e-9) inside = 0;
+        }
+        if (!inside) { if (i == 0) return 0; continue; }   /* deepest point off the face: keep the MPR contact */
+        out[m] = t[i];
+        scl3(out[m].normal, nf, -1);
+        m++;
+    }
+    for (int i = 0; i < m; i++) h[i] = out[i];
+    return m;
+}
+
 /* ------------------------------------------------------------ dispatch */
 static void make_shape(const MjlModel* m, const MjlData* d, int g, Shape* s) {
     s->type = m->geom_type[g];
@@ -578,8 +648,13 @@ int mjl_collide_pair(const MjlModel* m, const MjlData* d, int g1, int g2, double
     else if (t1 == MJL_BOX && t2 == MJL_BOX) n = box_box(&a, &b, margin, h, 8);
     else {
         a.margin = b.margin = 0.5 * margin;
-        n = mpr(&a, &b, margin, h);
+        n = mpr_refined(&a, &b, margin, h);
         if (n && h[0].dist > margin) n = 0;
+        a.margin = b.margin = 0;
+        if (n && (t1 == MJL_CYLINDER || t1 == MJL_CAPSULE) && t2 == MJL_BOX) {
+            int k = face_upgrade(&a, &b, h, margin);
+            if (k) n = k;
+        }
     }
     if (n > maxout) n = maxout;
     for (int i = 0; i < n; i++) {

@@ -614,6 +614,8 @@ static double impedance(const double* solimp, double x) {
 }
 
 static void make_impedance(const MjlModel* m, MjlData* d) {
+    if (d->ncon > d->max_ncon) d->max_ncon = d->ncon;
+    if (d->nefc > d->max_nefc) d->max_nefc = d->nefc;
     for (int i = 0; i < d->nefc; i++) {
         const double *ref, *imp;
         int type = d->efc_type[i], id = d->efc_id[i], dim = 1;
@@ -1006,6 +1008,7 @@ void mjl_step_n(const MjlModel* m, MjlData* d, int n) {
 /* ------------------------------------------------------------------ accessors for the Python binding */
 void mjl_data_info(const MjlData* d, int* out) {
     out[0] = d->ncon; out[1] = d->nefc; out[2] = d->ne; out[3] = d->nl; out[4] = d->solver_niter; out[5] = d->warning_overflow;
+    out[6] = d->max_ncon; out[7] = d->max_nefc;
 }
 void mjl_data_contact(const MjlData* d, int i, int* iv, double* rv) {
     const MjlContact* c = d->contact + i;

@@ -92,6 +92,7 @@ typedef struct {
         efc_force[MJL_MAXEFC];
     int solver_niter;
     int warning_overflow;
+    int max_ncon, max_nefc;   /* high-water marks (sizing the GPU caps) */
 } MjlData;
 
 MjlModel* mjl_model_new(void);
@@ -117,7 +118,7 @@ void mjl_rne_bias(const MjlModel* m, MjlData* d);
 void mjl_collision(const MjlModel* m, MjlData* d);
 void mjl_jac(const MjlModel* m, const MjlData* d, double* jacp, double* jacr, const double point[3], int body);
 
-void mjl_data_info(const MjlData* d, int* out6);
+void mjl_data_info(const MjlData* d, int* out8);
 void mjl_data_contact(const MjlData* d, int i, int* iv4, double* rv16);
 void mjl_data_efc_int(const MjlData* d, int* type, int* id, int* state);
 

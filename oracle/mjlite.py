@@ -145,9 +145,9 @@ class OracleData:
         return float(self.time_buf[0])
 
     def info(self):
-        out = (C.c_int * 6)()
+        out = (C.c_int * 8)()
         lib().mjl_data_info(self.ptr, out)
-        return dict(ncon=out[0], nefc=out[1], ne=out[2], nl=out[3], niter=out[4], overflow=out[5])
+        return dict(ncon=out[0], nefc=out[1], ne=out[2], nl=out[3], niter=out[4], overflow=out[5], max_ncon=out[6], max_nefc=out[7])
 
     @property
     def ncon(self):

@@ -1,0 +1,38 @@
+// tests/host_harness.cpp -- TEST HARNESS ONLY.  Compiles the *same* lane programs that libmwgpu.so runs on
+// the GPU (metaworld_amd/csrc/*.hpp) for the host, with a plain loop over (block, thread) standing in for
+// the wavefronts, so that the kernel logic can be checked against the oracle in a container without a GPU.
+// Exports the ABI of include/mwgpu.h under the prefix mwh_.  Never loaded by the product path.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#define MW_LAMBDA
+
+namespace {
+struct Backend {
+    static void init(int) {}
+    static void* alloc(size_t bytes) { return std::malloc(bytes ? bytes : 16); }
+    static void free(void* p) { std::free(p); }
+    static void zero(void* p, size_t bytes) { std::memset(p, 0, bytes); }
+    static void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+    static void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+    template <class F>
+    static void launch(int nblocks, F f) {
+#pragma omp parallel for schedule(dynamic)
+        for (int b = 0; b < nblocks; b++)
+            for (int t = 0; t < 64; t++) f(b, t);
+    }
+    static void sync() {}
+    static std::chrono::steady_clock::time_point& t0() { static std::chrono::steady_clock::time_point t; return t; }
+    static void timed_begin() { t0() = std::chrono::steady_clock::now(); }
+    static float timed_end() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0()).count(); }
+};
+}  // namespace
+
+#include "../metaworld_amd/csrc/mw_runtime.hpp"
+
+#include "../include/mwgpu.h"
+#define MW_API(name) mwh_##name
+#include "../metaworld_amd/csrc/mw_abi.inl"
