@@ -340,7 +340,7 @@ MW_HD void tri_closest_origin(V3<T> a, V3<T> b, V3<T> c, T* w) {
 }
 template <typename T>
 MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V3<T>* v0_override = nullptr) {
-    const T tol = sizeof(T) == 8 ? T(1e-6) : T(1e-5);
+    const T tol = sizeof(T) == 8 ? T(1e-10) : T(2e-6);
     SV<T> v0, v1, v2, v3_, v4;
     v0.a = A.pos; v0.b = B.pos; v0.v = v0.b - v0.a;
     if (v0_override) v0.v = *v0_override;
@@ -384,11 +384,23 @@ MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V
         else { if (dot(v3_.v, t) > 0) v2 = v4; else v1 = v4; }
     }
     if (!hit) return 0;
+    // contact normal = portal plane normal, depth = distance of the origin to that plane; the contact point is where
+    // the origin ray pierces the portal (barycentric), falling back to the closest point if degenerate
     T w[3];
-    tri_closest_origin(v1.v, v2.v, v3_.v, w);
-    const V3<T> cp = v1.v * w[0] + v2.v * w[1] + v3_.v * w[2];
-    const T depth = norm(cp);
-    h->normal = depth > T(1e-12) ? cp * (T(-1) / depth) : -dir;
+    const V3<T> rd = normalized(-v0.v);
+    const T denom = dot(rd, dir), depth = dot(v1.v, dir);
+    bool okw = false;
+    if (denom > T(1e-12)) {
+        const V3<T> x = rd * (depth / denom), e1 = v2.v - v1.v, e2 = v3_.v - v1.v, ex = x - v1.v;
+        const T d11 = dot(e1, e1), d12 = dot(e1, e2), d22 = dot(e2, e2), dx1 = dot(ex, e1), dx2 = dot(ex, e2);
+        const T den = d11 * d22 - d12 * d12;
+        if (mw_abs(den) > T(1e-30)) {
+            w[1] = (d22 * dx1 - d12 * dx2) / den; w[2] = (d11 * dx2 - d12 * dx1) / den; w[0] = 1 - w[1] - w[2];
+            okw = w[0] > T(-1e-6) && w[1] > T(-1e-6) && w[2] > T(-1e-6);
+        }
+    }
+    if (!okw) tri_closest_origin(v1.v, v2.v, v3_.v, w);
+    h->normal = -dir;
     h->dist = -depth + margin;
     h->pos = ((v1.a + v1.b) * w[0] + (v2.a + v2.b) * w[1] + (v3_.a + v3_.b) * w[2]) * T(0.5);
     return 1;
@@ -399,15 +411,17 @@ MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V
 template <typename T>
 MW_HD int mpr_refined(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h) {
     if (!mpr(A, B, margin, h)) return 0;
-    for (int it = 0; it < 4; it++) {
+    const T rel = sizeof(T) == 8 ? T(1e-10) : T(1e-6);
+    for (int it = 0; it < 10; it++) {
         const T depth = margin - h->dist;
         if (depth <= T(1e-9)) break;
         const V3<T> v0 = h->normal * (T(0.02) * depth);
         Hit<T> h2;
         if (!mpr(A, B, margin, &h2, &v0)) break;
         const T d2 = margin - h2.dist;
-        if (d2 >= depth * (1 - T(1e-6))) break;
+        if (d2 > depth) break;
         *h = h2;
+        if (depth - d2 <= rel * depth) break;
     }
     return 1;
 }
@@ -435,18 +449,54 @@ MW_HD int face_upgrade(const Shape<T>& c, const Shape<T>& box, Hit<T>* h, T marg
     pl.mat.m[6] = fy.z; pl.mat.m[7] = fz.z; pl.mat.m[8] = nf.z;
     pl.size[0] = pl.size[1] = pl.size[2] = 0; pl.vert = nullptr; pl.nvert = 0; pl.margin = 0;
     Hit<T> t[8];
-    const int cnt = plane_x(pl, c, margin, t);
+    int cnt = 0;
+    V3<T> cax = col(c.mat, 2);
+    const T prj = dot(nf, cax);
+    if (c.type == G_CYLINDER && mw_abs(prj) > T(0.7)) {
+        cnt = plane_x(pl, c, margin, t);                 // cap on the face: rim points
+    } else {
+        // side / capsule: the contact line between the two ends, clipped to the face rectangle
+        if (prj > 0) cax = -cax;
+        const T r = c.size[0], hh = c.size[1];
+        V3<T> vec;
+        if (c.type == G_CYLINDER) {
+            vec = cax * dot(nf, cax) - nf;
+            const T len = norm(vec);
+            if (len < T(1e-12)) return 0;
+            vec = vec * (r / len);
+        } else vec = nf * (-r);
+        const V3<T> s1 = c.pos + cax * hh + vec, s2 = c.pos - cax * hh + vec, dl = s2 - s1;
+        T u0 = 0, u1 = 1;
+        for (int j = 0; j < 3; j++) {
+            if (j == k) continue;
+            const V3<T> ax = col(box.mat, j);
+            const T a0 = dot(s1 - box.pos, ax), da = dot(dl, ax), lim = box.size[j];
+            if (mw_abs(da) < T(1e-14)) { if (mw_abs(a0) > lim) return 0; continue; }
+            T ua = (-lim - a0) / da, ub = (lim - a0) / da;
+            if (ua > ub) { const T tt = ua; ua = ub; ub = tt; }
+            if (ua > u0) u0 = ua;
+            if (ub < u1) u1 = ub;
+        }
+        if (u0 > u1) return 0;
+        const T us[2] = {u0, u1};
+        const int np = (u1 - u0) * norm(dl) > T(1e-6) ? 2 : 1;
+        for (int q = 0; q < np; q++) cnt += hit_plane_point(nf, pl.pos, s1 + dl * us[q], margin, t + cnt);
+    }
     int mcount = 0;
+    T deepest = T(1e30);
     for (int i = 0; i < cnt; i++) {
         const V3<T> d_ = t[i].pos - box.pos;
         bool inside = true;
         for (int j = 0; j < 3; j++)
             if (j != k && mw_abs(dot(d_, col(box.mat, j))) > box.size[j] + T(1e-9)) inside = false;
-        if (!inside) { if (i == 0) return 0; continue; }
+        if (!inside) continue;
         t[mcount] = t[i];
         t[mcount].normal = -nf;
+        if (t[mcount].dist < deepest) deepest = t[mcount].dist;
         mcount++;
     }
+    // order-independent acceptance: some point lies on the face and none of the depth found by MPR is lost
+    if (mcount == 0 || deepest > h[0].dist + T(1e-6)) return 0;
     for (int i = 0; i < mcount; i++) h[i] = t[i];
     return mcount;
 }

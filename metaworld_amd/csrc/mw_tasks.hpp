@@ -167,44 +167,319 @@ MW_HD void set_obj_xyz(const Env<T>& e, V3<T> p) {
 
 struct Info { float near_object, grasp_success, grasp_reward, in_place_reward, obj_to_target, unscaled_reward; };
 
+MW_HD Info make_info(double near_object, double grasp_success, double grasp_reward, double in_place, double obj_to_target, double unscaled) {
+    return Info{float(near_object), float(grasp_success), float(grasp_reward), float(in_place), float(obj_to_target), float(unscaled)};
+}
+
+// ---- per-task slots ----
+// TaskDesc::geom : 0 main object geom (touching_main_object), 1 leftpad_geom, 2 rightpad_geom
+// TaskDesc::c    : 0-2 init_config obj_init_pos, 3-5 class `goal`, 6.. task constants, 15 one-hot id
+enum { G_OBJ = 0, G_LPAD = 1, G_RPAD = 2 };
+
+// touching_object (sawyer_xyz_env.py:401-440): both pads have positive summed normal force against the geom.
+// Faithful to the reference's `efc_force[contact.efc_address]` including efc_address == -1 reading the LAST row.
+template <typename T>
+MW_HD bool touching_object(const Env<T>& e, const TaskDesc<T>& td, int objgeom) {
+    const int ncon = e.I(e.L.icount), nefc = e.I(e.L.icount + 1);
+    T fl = 0, fr = 0;
+    for (int c = 0; c < ncon; c++) {
+        const int g1 = ICON(e, c, 0), g2 = ICON(e, c, 1);
+        if (g1 != objgeom && g2 != objgeom) continue;
+        const bool l = g1 == td.geom[G_LPAD] || g2 == td.geom[G_LPAD], r = g1 == td.geom[G_RPAD] || g2 == td.geom[G_RPAD];
+        if (!l && !r) continue;
+        int adr = ICON(e, c, 3);
+        if (adr < 0) adr = nefc - 1;
+        const T f = adr >= 0 ? EX(e, adr, 5) : T(0);
+        if (l) fl += f;
+        if (r) fr += f;
+    }
+    return fl > 0 && fr > 0;
+}
+
+// base SawyerXYZEnv._gripper_caging_reward (sawyer_xyz_env.py:721-858); `ref` plays obj_init_pos (stick tasks pass stick_init_pos)
+template <typename T>
+MW_HD T caging_base(const Env<T>& e, const TaskDesc<T>& td, const T* act, V3<T> obj, V3<T> ref, T obj_radius, T pad_success_thresh,
+                    T object_reach_radius, T xz_thresh, T desired_effort, bool high_density, bool medium_density) {
+    const V3<T> lp = probe_pos(e, td.probe[P_LPAD]), rp = probe_pos(e, td.probe[P_RPAD]);
+    const T pad_y[2] = {lp.y, rp.y};
+    T cag[2];
+    for (int i = 0; i < 2; i++) {
+        const T x = mw_abs(pad_y[i] - obj.y), m = mw_abs(mw_abs(pad_y[i] - ref.y) - pad_success_thresh);
+        cag[i] = tolerance_lt(x, obj_radius, pad_success_thresh, m);
+    }
+    const T caging_y = hamacher(cag[0], cag[1]);
+    const V3<T> tcp = tcp_center(e, td), itcp = tk3(e, TK_INITTCP);
+    const T mxz = mw_sqrt((ref.x - itcp.x) * (ref.x - itcp.x) + (ref.z - itcp.z) * (ref.z - itcp.z)) - xz_thresh;
+    const T dxz = mw_sqrt((tcp.x - obj.x) * (tcp.x - obj.x) + (tcp.z - obj.z) * (tcp.z - obj.z));
+    const T caging_xz = tolerance_lt(dxz, T(0), xz_thresh, mxz);
+    const T closed = mw_min(mw_max(T(0), act[3]), desired_effort) / desired_effort;
+    const T caging = hamacher(caging_y, caging_xz);
+    const T gripping = caging > T(0.97) ? closed : T(0);
+    T cg = hamacher(caging, gripping);
+    if (high_density) cg = (cg + caging) / 2;
+    if (medium_density) {
+        const T tcp_to_obj = norm(obj - tcp), init = norm(ref - itcp);
+        const T reach = tolerance_lt(tcp_to_obj, T(0), object_reach_radius, mw_abs(init - object_reach_radius));
+        cg = (cg + reach) / 2;
+    }
+    return cg;
+}
+
+// the per-task overrides (pick-place :180-248; push-back/soccer/sweep/sweep-into): the "init" pads are live views,
+// i.e. the CURRENT pad positions.  mode 0 = pick-place, 1 = y-gripping family.
+template <typename T>
+MW_HD T caging_override(const Env<T>& e, const TaskDesc<T>& td, const T* act, V3<T> obj, int mode, T obj_radius, T grip_margin, T xz_margin) {
+    const T pad_margin = T(0.05);
+    const V3<T> lp = probe_pos(e, td.probe[P_LPAD]), rp = probe_pos(e, td.probe[P_RPAD]);
+    const T dl = lp.y - obj.y, dr = obj.y - rp.y;
+    const T mr = mw_abs(mw_abs(obj.y - rp.y) - pad_margin), ml = mw_abs(mw_abs(obj.y - lp.y) - pad_margin);
+    const T rc = tolerance_lt(dr, obj_radius, pad_margin, mr), lc = tolerance_lt(dl, obj_radius, pad_margin, ml);
+    const T y_caging = hamacher(lc, rc);
+    const V3<T> tcp = tcp_center(e, td), oi = tk3(e, TK_OBJINIT), itcp = tk3(e, TK_INITTCP);
+    const T dxz = mw_sqrt((tcp.x - obj.x) * (tcp.x - obj.x) + (tcp.z - obj.z) * (tcp.z - obj.z));
+    const T mxz = mw_sqrt((oi.x - itcp.x) * (oi.x - itcp.x) + (oi.z - itcp.z) * (oi.z - itcp.z)) - xz_margin;
+    const T xz_caging = tolerance_lt(dxz, T(0), xz_margin, mxz);
+    const T caging = hamacher(y_caging, xz_caging);
+    if (mode == 0) {
+        const T closed = mw_min(mw_max(T(0), act[3]), T(1));
+        const T gripping = caging > T(0.97) ? closed : T(0);
+        return (hamacher(caging, gripping) + caging) / 2;
+    }
+    const T rg = tolerance_lt(dr, obj_radius, grip_margin, mr), lg = tolerance_lt(dl, obj_radius, grip_margin, ml);
+    const T y_gripping = hamacher(rg, lg);
+    return (caging + (caging > T(0.95) ? y_gripping : T(0))) / 2;
+}
+
+template <typename T> MW_HD V3<T> obs3(const T* o, int k) { return V3<T>{o[k], o[k + 1], o[k + 2]}; }
+template <typename T> MW_HD V3<T> c3(const TaskDesc<T>& td, int k) { return V3<T>{td.c[k], td.c[k + 1], td.c[k + 2]}; }
+template <typename T> MW_HD V3<T> scale3(V3<T> a, T x, T y, T z) { return V3<T>{a.x * x, a.y * y, a.z * z}; }
+
 // =========================================================================== per-task code
-// ---- reach-v3 (id 43) / reach-wall-v3 (id 44): metaworld/envs/sawyer_reach_v3.py:119-161, sawyer_reach_wall_v3.py
+// Each task: <name>_reset restates reset_model(), <name>_eval restates evaluate_state()+compute_reward() (v2 branch).
+struct Out { double reward, success; Info info; };
+
+// ---- reach-v3 (43) / reach-wall-v3 (44): envs/sawyer_reach_v3.py:119-161, sawyer_reach_wall_v3.py ----
 template <typename T>
 MW_HD void reach_reset(const Env<T>& e, const TaskDesc<T>& td) {
     reset_hand(e, td);
-    const V3<T> rv_obj = tk3(e, TK_RANDVEC), rv_goal = tk3(e, TK_RANDVEC + 3);
-    set_tk3(e, TK_TARGET, rv_goal);
-    set_tk3(e, TK_OBJINIT, rv_obj);
-    set_obj_xyz(e, rv_obj);
+    set_tk3(e, TK_TARGET, tk3(e, TK_RANDVEC + 3));
+    set_tk3(e, TK_OBJINIT, tk3(e, TK_RANDVEC));
+    set_obj_xyz(e, tk3(e, TK_RANDVEC));
 }
 template <typename T>
-MW_HD void reach_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act, T* reward, T* success, Info* info) {
+MW_HD Out reach_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> tcp = tcp_center(e, td), target = tk3(e, TK_TARGET);
     const T d = norm(tcp - target);
-    const T margin = norm(v3(td.hand_init[0], td.hand_init[1], td.hand_init[2]) - target);
-    const T in_place = tolerance_lt(d, T(0), T(0.05), margin);
-    *reward = 10 * in_place;
-    *success = d <= T(0.05) ? T(1) : T(0);
-    info->near_object = float(d); info->grasp_success = 1.f; info->grasp_reward = float(d);
-    info->in_place_reward = float(in_place); info->obj_to_target = float(d); info->unscaled_reward = float(*reward);
+    const T in_place = tolerance_lt(d, T(0), T(0.05), norm(v3(td.hand_init[0], td.hand_init[1], td.hand_init[2]) - target));
+    if (td.kind == 44)   // reach-wall: near_object / grasp_success / grasp_reward are constant 0
+        return Out{double(10 * in_place), double(d <= T(0.05)), make_info(0.0, 0.0, 0.0, in_place, d, 10 * in_place)};
+    return Out{double(10 * in_place), double(d <= T(0.05)), make_info(d, 1.0, d, in_place, d, 10 * in_place)};
 }
 
+// ---- the push / pick-place family: free object at qpos[9:16], goal from rand_vec[3:6] ----
+// reset flavours (all after _reset_hand): where obj z and target z come from differs per task.
 template <typename T>
-MW_HD bool task_supported(int kind) { return kind == 43 || kind == 44; }
+MW_HD void pushpick_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
+    V3<T> oi = rv0, tg = rv1;
+    const T body_z = probe_pos(e, td.probe[P_OBJ0]).z;          // get_body_com("obj")[-1] / geom xpos[-1] after settling
+    switch (td.kind) {
+    case 40:  // push: z of both = fix_extreme_obj_pos(...)[2] = body z
+        oi.z = body_z; tg.z = body_z; break;
+    case 41:  // push-wall: adjust_initObjPos z = geom("objGeom").xpos z
+    case 42:  // push-back
+        oi.z = probe_pos(e, td.probe[P_OBJ1]).z; tg.z = oi.z; break;
+    case 30:  // pick-place: init_tcp / pads re-captured (views), obj & target straight from rand_vec
+        set_tk3(e, TK_INITTCP, tcp_center(e, td)); break;
+    case 28:  // pick-place-wall
+    default: break;
+    }
+    set_tk3(e, TK_TARGET, tg);
+    set_tk3(e, TK_OBJINIT, oi);
+    set_obj_xyz(e, oi);
+}
+template <typename T>
+MW_HD Out push_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {   // push-v3 (40)
+    const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
+    const T opened = obs[3], tcp_to_obj = norm(obj - tcp_center(e, td)), t2o = norm(obj - target);
+    const T in_place = tolerance_lt(t2o, T(0), T(0.05), norm(oi - target));
+    const T grasped = caging_base(e, td, act, obj, oi, T(0.015), T(0.05), T(0.01), T(0.005), T(1), true, false);
+    T reward = 2 * grasped;
+    if (tcp_to_obj < T(0.02) && opened > 0) reward += 1 + reward + 5 * in_place;
+    if (t2o < T(0.05)) reward = 10;
+    const bool gs = touching_object(e, td, td.geom[G_OBJ]) && opened > 0 && obj.z - T(0.02) > oi.z;
+    return Out{double(reward), double(t2o <= T(0.05)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, t2o, reward)};
+}
+template <typename T>
+MW_HD Out pick_place_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {   // pick-place-v3 (30)
+    const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
+    const T opened = obs[3], o2t = norm(obj - target), tcp_to_obj = norm(obj - tcp_center(e, td));
+    const T in_place = tolerance_lt(o2t, T(0), T(0.05), norm(oi - target));
+    const T grasped = caging_override(e, td, act, obj, 0, T(0.015), T(0), T(0.005));
+    T reward = hamacher(grasped, in_place);
+    if (tcp_to_obj < T(0.02) && opened > 0 && obj.z - T(0.01) > oi.z) reward += 1 + 5 * in_place;
+    if (o2t < T(0.05)) reward = 10;
+    const bool gs = touching_object(e, td, td.geom[G_OBJ]) && opened > 0 && obj.z - T(0.02) > oi.z;
+    return Out{double(reward), double(o2t <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, o2t, reward)};
+}
+template <typename T>
+MW_HD Out push_back_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {   // push-back-v3 (42)
+    const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
+    const T opened = obs[3], tcp_to_obj = norm(obj - tcp_center(e, td)), t2o = norm(obj - target), t2oi = norm(oi - target);
+    const T in_place = tolerance_lt(t2o, T(0), T(0.05), t2oi);
+    const T grasped = caging_override(e, td, act, obj, 1, T(0.007), T(0.007 + 0.003), T(0.01));
+    T reward = hamacher(grasped, in_place);
+    if (tcp_to_obj < T(0.01) && opened > 0 && opened < T(0.55) && t2oi - t2o > T(0.01)) reward += 1 + 5 * in_place;
+    if (t2o < T(0.05)) reward = 10;
+    const bool gs = touching_object(e, td, td.geom[G_OBJ]) && opened > 0 && obj.z - T(0.02) > oi.z;
+    return Out{double(reward), double(t2o <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, t2o, reward)};
+}
+template <typename T>
+MW_HD Out wall_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {   // push-wall (41) / pick-place-wall (28)
+    const bool pick = td.kind == 28;
+    const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
+    const T opened = obs[3], tcp_to_obj = norm(obj - tcp_center(e, td));
+    const V3<T> mid = pick ? V3<T>{target.x, T(0.77), T(0.25)} : V3<T>{T(-0.05), T(0.77), obj.z};
+    const T sx = pick ? T(1) : T(3), sz = pick ? T(3) : T(1);
+    const T o2m = norm(scale3(obj - mid, sx, T(1), sz)), o2mi = norm(scale3(oi - mid, sx, T(1), sz));
+    const T o2t = norm(obj - target), o2ti = norm(oi - target);
+    const T p1 = tolerance_lt(o2m, T(0), T(0.05), o2mi), p2 = tolerance_lt(o2t, T(0), T(0.05), o2ti);
+    const T grasped = caging_base(e, td, act, obj, oi, T(0.015), T(0.05), T(0.01), T(0.005), T(1), !pick, false);
+    T reward;
+    if (pick) {
+        const T ipg = hamacher(grasped, p1);
+        reward = ipg;
+        if (tcp_to_obj < T(0.02) && opened > 0 && obj.z - T(0.015) > oi.z) {
+            reward = ipg + 1 + 4 * p1;
+            if (obj.y > T(0.75)) reward = ipg + 1 + 4 + 3 * p2;
+        }
+    } else {
+        reward = 2 * grasped;
+        if (tcp_to_obj < T(0.02) && opened > 0) {
+            reward = 2 * grasped + 1 + 4 * p1;
+            if (obj.y > T(0.75)) reward = 2 * grasped + 1 + 4 + 3 * p2;
+        }
+    }
+    if (o2t < T(0.05)) reward = 10;
+    const bool gs = touching_object(e, td, td.geom[G_OBJ]) && opened > 0 && obj.z - T(0.02) > oi.z;
+    return Out{double(reward), double(o2t <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, p2, o2t, reward)};
+}
+
+// ---- sweep-v3 (47), sweep-into-v3 (46), soccer-v3 (37), hand-insert-v3 (17) ----
+template <typename T>
+MW_HD void sweepfam_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
+    V3<T> oi, tg;
+    if (td.kind == 47) {            // sweep: target = goal with y <- rand_vec.y ; obj z = init_config z
+        oi = V3<T>{rv0.x, rv0.y, td.c[2]}; tg = V3<T>{td.c[3], rv0.y, td.c[5]};
+    } else if (td.kind == 46) {     // sweep-into: obj z = settled body z ; target = class goal
+        oi = V3<T>{rv0.x, rv0.y, probe_pos(e, td.probe[P_OBJ0]).z}; tg = c3(td, 3);
+    } else if (td.kind == 37) {     // soccer: goal_whole body relocated to the target
+        oi = V3<T>{rv0.x, rv0.y, td.c[2]}; tg = rv1;
+        st3(e, e.L.reloc + 3 * td.reloc[0], tg);
+    } else {                        // hand-insert
+        oi = V3<T>{rv0.x, rv0.y, td.c[2]}; tg = rv1;
+    }
+    set_tk3(e, TK_TARGET, tg);
+    set_tk3(e, TK_OBJINIT, oi);
+    set_obj_xyz(e, oi);
+}
+template <typename T>
+MW_HD Out sweepfam_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> obj = obs3(obs, 4), oi = tk3(e, TK_OBJINIT);
+    V3<T> target = tk3(e, TK_TARGET);
+    const T opened = obs[3], tcp_to_obj = norm(obj - tcp_center(e, td));
+    const bool touch = touching_object(e, td, td.geom[G_OBJ]);
+    if (td.kind == 47 || td.kind == 46) {
+        if (td.kind == 46) target.z = obj.z;
+        const T o2t = norm(obj - target), in_place = tolerance_lt(o2t, T(0), T(0.05), norm(oi - target));
+        const T grasped = td.kind == 47 ? caging_override(e, td, act, obj, 1, T(0.02), T(0.02 + 0.01), T(0.005))
+                                        : caging_override(e, td, act, obj, 1, T(0.02), T(0.02 + 0.005), T(0.01));
+        T reward = 2 * grasped + 6 * hamacher(grasped, in_place);
+        if (o2t < T(0.05)) reward = 10;
+        return Out{double(reward), double(o2t <= T(0.05)), make_info(tcp_to_obj <= T(0.03), touch && opened > 0, grasped, in_place, o2t, reward)};
+    }
+    if (td.kind == 37) {
+        const T t2o = norm(scale3(obj - target, T(3), T(1), T(1))), t2oi = norm(scale3(obj - oi, T(3), T(1), T(1)));
+        T in_place = tolerance_lt(t2o, T(0), T(0.07), t2oi);
+        const T goal_line = target.y - T(0.1);
+        if (obj.y > goal_line && mw_abs(obj.x - target.x) > T(0.10))
+            in_place = mw_clamp(in_place - 2 * ((obj.y - goal_line) / (1 - goal_line)), T(0), T(1));
+        const T grasped = caging_override(e, td, act, obj, 1, T(0.013), T(0.013 + 0.01), T(0.005));
+        T reward = 3 * grasped + T(6.5) * in_place;
+        if (t2o < T(0.07)) reward = 10;
+        const T d = norm(obj - target);
+        const bool gs = touch && opened > 0 && obj.z - T(0.02) > oi.z;
+        return Out{double(reward), double(d <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, d, reward)};
+    }
+    // hand-insert
+    const T t2o = norm(obj - target), in_place = tolerance_lt(t2o, T(0), T(0.05), norm(oi - target));
+    const T grasped = caging_base(e, td, act, obj, oi, T(0.015), T(0.05), T(0.01), T(0.005), T(1), true, false);
+    T reward = hamacher(grasped, in_place);
+    if (tcp_to_obj < T(0.02) && opened > 0) reward += 1 + 7 * in_place;
+    if (t2o < T(0.05)) reward = 10;
+    const bool gs = touch && opened > 0 && obj.z - T(0.02) > oi.z;
+    return Out{double(reward), double(t2o <= T(0.05)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, t2o, reward)};
+}
+
+// ---- bin-picking-v3 (2): envs/sawyer_bin_picking_v3.py ; TK_EXTRA[0] = _target_to_obj_init latch (-1 = None) ----
+template <typename T>
+MW_HD void bin_picking_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC);
+    const V3<T> oi{rv0.x, rv0.y, probe_pos(e, td.probe[P_OBJ0]).z};
+    set_tk3(e, TK_OBJINIT, oi);
+    set_obj_xyz(e, oi);
+    set_tk3(e, TK_TARGET, probe_pos(e, td.probe[P_X0]));   // get_body_com("bin_goal")
+    TK(e, TK_EXTRA) = -1;
+}
+template <typename T>
+MW_HD Out bin_picking_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> hand = obs3(obs, 0), obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
+    const T t2o = norm(obj - target);
+    if (TK(e, TK_EXTRA) < 0) TK(e, TK_EXTRA) = t2o;
+    const T in_place = tolerance_lt(t2o, T(0), T(0.05), TK(e, TK_EXTRA));
+    const T thr = T(0.03);
+    const T r0 = mw_sqrt((hand.x - oi.x) * (hand.x - oi.x) + (hand.y - oi.y) * (hand.y - oi.y));
+    const T r1 = mw_sqrt((hand.x - target.x) * (hand.x - target.x) + (hand.y - target.y) * (hand.y - target.y));
+    const T f0 = r0 > thr ? T(0.02) * T(log(double(r0 - thr))) + T(0.2) : T(0), f1 = r1 > thr ? T(0.02) * T(log(double(r1 - thr))) + T(0.2) : T(0);
+    const T floor_ = mw_min(f0, f1);
+    const T above = hand.z >= floor_ ? T(1) : tolerance_lt(mw_max(floor_ - hand.z, T(0)), T(0), T(0.01), T(0.05));
+    const T grasped = caging_base(e, td, act, obj, oi, T(0.015), T(0.05), T(0.01), T(0.01), T(0.7), true, false);
+    T reward = hamacher(grasped, in_place);
+    const bool near = norm(obj - hand) < T(0.04), pinched = obs[3] < T(0.43), lifted = obj.z - T(0.02) > oi.z;
+    const bool gs = near && lifted && !pinched;
+    if (gs) reward += 1 + 5 * hamacher(above, in_place);
+    if (t2o < T(0.05)) reward = 10;
+    return Out{double(reward), double(t2o <= T(0.05)), make_info(near, gs, grasped, in_place, t2o, reward)};
+}
 
 template <typename T>
 MW_HD void task_reset_model(const Env<T>& e, const TaskDesc<T>& td) {
     switch (td.kind) {
     case 43: case 44: reach_reset(e, td); break;
-    default: break;
+    case 40: case 41: case 42: case 30: case 28: pushpick_reset(e, td); break;
+    case 47: case 46: case 37: case 17: sweepfam_reset(e, td); break;
+    case 2: bin_picking_reset(e, td); break;
+    default: reset_hand(e, td); break;
     }
 }
 template <typename T>
 MW_HD void task_evaluate(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act, T* reward, T* success, Info* info) {
+    Out o{0, 0, Info{0, 0, 0, 0, 0, 0}};
     switch (td.kind) {
-    case 43: case 44: reach_eval(e, td, obs, act, reward, success, info); break;
-    default: *reward = 0; *success = 0; *info = Info{0, 0, 0, 0, 0, 0}; break;
+    case 43: case 44: o = reach_eval(e, td, obs, act); break;
+    case 40: o = push_eval(e, td, obs, act); break;
+    case 30: o = pick_place_eval(e, td, obs, act); break;
+    case 42: o = push_back_eval(e, td, obs, act); break;
+    case 41: case 28: o = wall_eval(e, td, obs, act); break;
+    case 47: case 46: case 37: case 17: o = sweepfam_eval(e, td, obs, act); break;
+    case 2: o = bin_picking_eval(e, td, obs, act); break;
+    default: break;
     }
+    *reward = T(o.reward); *success = T(o.success); *info = o.info;
 }
 
 // =========================================================================== env-level reset / step
@@ -225,9 +500,11 @@ MW_HD void env_reset(const Env<T>& e, const TaskDesc<T>& td, T* obs39) {
 template <typename T>
 MW_HD void env_step(const Env<T>& e, const TaskDesc<T>& td, const T* act, T* obs39, T* reward, T* success, Info* info) {
     // set_xyz_action: mocap += clip(a,-1,1)*0.01, clipped to the mocap box
+    // (the reference multiplies the float32 action by action_scale in float32: numpy keeps float32 * python-float in float32)
     for (int k = 0; k < 3; k++) {
-        const T a = mw_clamp(act[k], T(-1), T(1));
-        e.R(e.L.mocap + k) = mw_clamp(e.R(e.L.mocap + k) + a * T(0.01), td.mocap_low[k], td.mocap_high[k]);
+        const float a = fminf(fmaxf(float(act[k]), -1.0f), 1.0f);
+        const float delta = a * 0.01f;
+        e.R(e.L.mocap + k) = mw_clamp(e.R(e.L.mocap + k) + T(delta), td.mocap_low[k], td.mocap_high[k]);
     }
     e.R(e.L.ctrl) = act[3]; e.R(e.L.ctrl + 1) = -act[3];
     for (int k = 0; k < 5; k++) substep(e);

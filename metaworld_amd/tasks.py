@@ -23,9 +23,26 @@ COMMON_PROBES = [("body", "hand"), ("body", "rightclaw"), ("body", "leftclaw"), 
 
 # name -> dict(objs=[(pos_probe, quat_probe, quat_mode, offset)], extra probes, ...).  Only tasks listed here
 # have device-side reward/reset code (metaworld_amd/csrc/mw_tasks.hpp `task_supported`).
+def _obj(pos, quat, mode, off=(0, 0, 0)):
+    return (pos, quat, mode, off)
+
+
+B, G, S = "body", "geom", "site"
+_PUCK = [_obj((B, "obj"), (G, "objGeom"), QUAT_SCIPY)]
+_GEOMPUCK = [_obj((G, "objGeom"), (G, "objGeom"), QUAT_SCIPY)]
 TASK_DEFS = {
-    "reach-v3": dict(objs=[(("body", "obj"), ("geom", "objGeom"), QUAT_SCIPY, (0, 0, 0))]),
-    "reach-wall-v3": dict(objs=[(("body", "obj"), ("geom", "objGeom"), QUAT_SCIPY, (0, 0, 0))]),
+    "reach-v3": dict(objs=_PUCK),
+    "reach-wall-v3": dict(objs=_PUCK),
+    "push-v3": dict(objs=_PUCK),
+    "pick-place-v3": dict(objs=_PUCK),
+    "push-back-v3": dict(objs=_GEOMPUCK),
+    "push-wall-v3": dict(objs=_GEOMPUCK),
+    "pick-place-wall-v3": dict(objs=_GEOMPUCK),
+    "sweep-v3": dict(objs=[_obj((B, "obj"), (B, "obj"), QUAT_MUJOCO)]),
+    "sweep-into-v3": dict(objs=_PUCK),
+    "soccer-v3": dict(objs=[_obj((B, "soccer_ball"), (B, "soccer_ball"), QUAT_SCIPY)], reloc=["goal_whole"]),
+    "hand-insert-v3": dict(objs=[_obj((B, "obj"), (B, "obj"), QUAT_MUJOCO)]),
+    "bin-picking-v3": dict(objs=[_obj((B, "obj"), (B, "obj"), QUAT_MUJOCO)], extra=[(B, "bin_goal")]),
 }
 
 with open(os.path.join(_HERE, "data", "task_constants.json")) as _f:
@@ -112,6 +129,14 @@ def task_struct(task, model_index, roles, reloc, onehot_id, partially_observable
             t.obj_off[i][k] = d["objs"][i][3][k] if i < t.nobj else 0.0
     for i in range(4):
         t.qadr[i] = t.dadr[i] = t.geom[i] = -1
+    m = compiled_model(c["model"])
+    gn = m.names["geom"]
+    main = d.get("geom", "objGeom")
+    t.geom[0] = gn.get(main, -1)
+    t.geom[1], t.geom[2] = gn["leftpad_geom"], gn["rightpad_geom"]
+    for i, jn in enumerate(d.get("joints", [])):
+        j = m.names["joint"][jn]
+        t.qadr[i], t.dadr[i] = int(m.arrays["jnt_qposadr"][j]), int(m.arrays["jnt_dofadr"][j])
     for i in range(2):
         t.reloc[i] = -1
     for i, b in enumerate(d.get("reloc", [])):
@@ -123,6 +148,10 @@ def task_struct(task, model_index, roles, reloc, onehot_id, partially_observable
     t.mocap_high[:] = c["mocap_high"]
     t.goal_low[:] = c["goal_low"]
     t.goal_high[:] = c["goal_high"]
+    oi = c.get("init_config", {}).get("obj_init_pos", [0, 0, 0])
+    for i in range(3):
+        t.c[i] = oi[i] if i < len(oi) else 0.0
+        t.c[3 + i] = c["goal"][i] if i < len(c["goal"]) else 0.0
     for i, v in enumerate(d.get("c", [])):
-        t.c[i] = v
+        t.c[6 + i] = v
     return t

@@ -16,7 +16,7 @@
 #include "mjl_core.h"
 
 #define MINVAL 1e-15
-#define CCD_TOL 1e-6
+#define CCD_TOL 1e-10
 #define CCD_ITER 50
 
 typedef struct { int type; const double *pos, *mat, *size; const double* vert; int nvert; double margin; } Shape;
@@ -494,7 +494,7 @@ static int mpr(const Shape* A, const Shape* B, double margin, Hit* h, const doub
         h->dist = -depth + margin;
         scl3(h->normal, d_, -1);
         for (int k = 0; k < 3; k++) h->pos[k] = 0.5 * (v1.a[k] + v1.b[k]);
-        return h->dist <= margin - 0 ? 1 : 0;
+        return 1;
     }
     normalize3(dir);
     msupport(A, B, dir, &v2);
@@ -532,12 +532,25 @@ static int mpr(const Shape* A, const Shape* B, double margin, Hit* h, const doub
         }
     }
     if (!hit) return 0;
-    double w[3], cp[3];
-    tri_closest_origin(v1.v, v2.v, v3.v, w);
-    for (int k = 0; k < 3; k++) cp[k] = w[0] * v1.v[k] + w[1] * v2.v[k] + w[2] * v3.v[k];
-    double depth = norm3(cp);
-    if (depth > 1e-12) scl3(h->normal, cp, -1 / depth);
-    else scl3(h->normal, dir, -1);
+    /* contact normal = portal plane normal, depth = distance of the origin to that plane; the contact point is
+       where the origin ray pierces the portal (barycentric), falling back to the closest point if degenerate */
+    double w[3], rd[3];
+    scl3(rd, v0.v, -1); normalize3(rd);
+    double denom = dot3(rd, dir), depth = dot3(v1.v, dir);
+    int okw = 0;
+    if (denom > 1e-12) {
+        double x[3], e1[3], e2[3], ex[3];
+        scl3(x, rd, depth / denom);
+        sub3(e1, v2.v, v1.v); sub3(e2, v3.v, v1.v); sub3(ex, x, v1.v);
+        double d11 = dot3(e1, e1), d12 = dot3(e1, e2), d22 = dot3(e2, e2), dx1 = dot3(ex, e1), dx2 = dot3(ex, e2);
+        double den = d11 * d22 - d12 * d12;
+        if (fabs(den) > 1e-300) {
+            w[1] = (d22 * dx1 - d12 * dx2) / den; w[2] = (d11 * dx2 - d12 * dx1) / den; w[0] = 1 - w[1] - w[2];
+            okw = w[0] > -1e-6 && w[1] > -1e-6 && w[2] > -1e-6;
+        }
+    }
+    if (!okw) tri_closest_origin(v1.v, v2.v, v3.v, w);
+    scl3(h->normal, dir, -1);
     h->dist = -depth + margin;
     for (int k = 0; k < 3; k++)
         h->pos[k] = 0.5 * (w[0] * (v1.a[k] + v1.b[k]) + w[1] * (v2.a[k] + v2.b[k]) + w[2] * (v3.a[k] + v3.b[k]));
@@ -548,15 +561,16 @@ static int mpr(const Shape* A, const Shape* B, double margin, Hit* h, const doub
    normal just found until the depth stops decreasing: converges to a local minimum-translation direction. */
 static int mpr_refined(const Shape* A, const Shape* B, double margin, Hit* h) {
     if (!mpr(A, B, margin, h, NULL)) return 0;
-    for (int it = 0; it < 4; it++) {
+    for (int it = 0; it < 10; it++) {
         double depth = margin - h->dist, v0[3];
         if (depth <= 1e-9) break;
         scl3(v0, h->normal, 0.02 * depth);
         Hit h2;
         if (!mpr(A, B, margin, &h2, v0)) break;
         double d2 = margin - h2.dist;
-        if (d2 >= depth * (1 - 1e-6)) break;
+        if (d2 > depth) break;
         *h = h2;
+        if (depth - d2 <= 1e-10 * depth) break;
     }
     return 1;
 }
@@ -592,9 +606,50 @@ static int face_upgrade(const Shape* c, const Shape* box, Hit* h, double margin)
     memset(&pl, 0, sizeof pl);
     pl.type = MJL_PLANE; pl.pos = p0; pl.mat = pm; pl.size = box->size;
     Hit t[8];
-    int cnt = c->type == MJL_CYLINDER ? plane_cylinder(&pl, c, margin, t) : plane_capsule(&pl, c, margin, t);
+    int cnt;
+    double cax[3];
+    col3(cax, c->mat, 2);
+    double prj = dot3(nf, cax);
+    if (c->type == MJL_CYLINDER && fabs(prj) > 0.7) {
+        cnt = plane_cylinder(&pl, c, margin, t);          /* cap on the face: rim points */
+    } else {
+        /* side / capsule: the contact line between the two ends, clipped to the face rectangle */
+        if (prj > 0) scl3(cax, cax, -1);                  /* axis toward the plane */
+        double vec[3], r = c->size[0], hh = c->size[1];
+        if (c->type == MJL_CYLINDER) {
+            scl3(vec, cax, dot3(nf, cax)); sub3(vec, vec, nf);
+            double len = norm3(vec);
+            if (len < 1e-12) return 0;
+            scl3(vec, vec, r / len);
+        } else scl3(vec, nf, -r);
+        double s1[3], s2[3], dl[3];
+        addscl3(s1, c->pos, cax, hh); add3(s1, s1, vec);
+        addscl3(s2, c->pos, cax, -hh); add3(s2, s2, vec);
+        sub3(dl, s2, s1);
+        double u0 = 0, u1 = 1;
+        for (int j = 0; j < 3; j++) {
+            if (j == k) continue;
+            col3(ax, box->mat, j);
+            double d1[3]; sub3(d1, s1, box->pos);
+            double a0 = dot3(d1, ax), da = dot3(dl, ax), lim = box->size[j];
+            if (fabs(da) < 1e-14) { if (fabs(a0) > lim) return 0; continue; }
+            double ua = (-lim - a0) / da, ub = (lim - a0) / da;
+            if (ua > ub) { double tt = ua; ua = ub; ub = tt; }
+            if (ua > u0) u0 = ua;
+            if (ub < u1) u1 = ub;
+        }
+        if (u0 > u1) return 0;
+        cnt = 0;
+        double us[2] = { u0, u1 };
+        for (int q = 0; q < ((u1 - u0) * norm3(dl) > 1e-6 ? 2 : 1); q++) {
+            double pt[3];
+            addscl3(pt, s1, dl, us[q]);
+            cnt += plane_point(nf, p0, pt, margin, t + cnt);
+        }
+    }
     int m = 0;
     Hit out[8];
+    double deepest = 1e30;
     for (int i = 0; i < cnt; i++) {
         double d_[3];
         sub3(d_, t[i].pos, box->pos);
@@ -604,11 +659,14 @@ static int face_upgrade(const Shape* c, const Shape* box, Hit* h, double margin)
             col3(ax, box->mat, j);
             if (fabs(dot3(d_, ax)) > box->size[j] + 1e-9) inside = 0;
         }
-        if (!inside) { if (i == 0) return 0; continue; }   /* deepest point off the face: keep the MPR contact */
+        if (!inside) continue;
         out[m] = t[i];
         scl3(out[m].normal, nf, -1);
+        if (out[m].dist < deepest) deepest = out[m].dist;
         m++;
     }
+    /* order-independent acceptance: some point lies on the face and none of the depth found by MPR is lost */
+    if (m == 0 || deepest > h[0].dist + 1e-6) return 0;
     for (int i = 0; i < m; i++) h[i] = out[i];
     return m;
 }

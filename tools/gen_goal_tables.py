@@ -33,6 +33,7 @@ def table(bench):
 
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 42
+    consts_only = "--consts-only" in sys.argv
     from oracle import refshim
     refshim.install()
     import metaworld
@@ -52,15 +53,21 @@ def main():
             mocap_high=list(map(float, env.mocap_high)), goal_low=list(map(float, env.goal_space.low)),
             goal_high=list(map(float, env.goal_space.high)),
             reset_low=list(map(float, env._random_reset_space.low)), reset_high=list(map(float, env._random_reset_space.high)),
-            max_path_length=int(env.max_path_length))
+            max_path_length=int(env.max_path_length),
+            init_config={k: (list(map(float, np.ravel(v))) if np.ndim(v) else float(v)) for k, v in getattr(env, "init_config", {}).items()
+                         if isinstance(v, (int, float, np.ndarray, list, tuple))},
+            goal=list(map(float, np.ravel(getattr(env, "goal", [0, 0, 0])))),
+            class_constants={k: float(getattr(env, k)) for k in ("TARGET_RADIUS", "OBJ_RADIUS", "liftThresh", "max_dist", "PAD_SUCCESS_MARGIN", "LIFT_THRESH", "LEVER_RADIUS")
+                             if isinstance(getattr(env, k, None), (int, float))})
         print(name, "ok", flush=True)
-    for bname, cls in (("MT10", metaworld.MT10), ("MT50", metaworld.MT50)):
+    for bname, cls in (() if consts_only else (("MT10", metaworld.MT10), ("MT50", metaworld.MT50))):
         tb = table(cls(seed=seed))
         for k, v in tb.items():
             data[f"{bname}/{k}"] = v
         print(bname, "ok", flush=True)
     os.makedirs(os.path.join(ROOT, "metaworld_amd", "data"), exist_ok=True)
-    np.savez_compressed(os.path.join(ROOT, "metaworld_amd", "data", f"goals_seed{seed}.npz"), **data)
+    if not consts_only:
+        np.savez_compressed(os.path.join(ROOT, "metaworld_amd", "data", f"goals_seed{seed}.npz"), **data)
     with open(os.path.join(ROOT, "metaworld_amd", "data", "task_constants.json"), "w") as f:
         json.dump(dict(all_v3=names, mt10=list(MT10_V3.keys()), tasks=consts), f, indent=1)
 
