@@ -279,28 +279,31 @@ MW_HD int box_box(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, int
 }
 
 // ------------------------------------------------------------ MPR on support functions
+// support point; exact ties (direction perpendicular to a flat feature) are broken canonically (towards +, lowest
+// vertex index) within `tie`, so that independent implementations walk the same portal
 template <typename T>
 MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
+    const T tie = sizeof(T) == 8 ? T(1e-9) : T(1e-6);
     const V3<T> dl = mulT(s.mat, dir);
     V3<T> pl{0, 0, 0};
     switch (s.type) {
     case G_SPHERE: pl = dl * s.size[0]; break;
-    case G_CAPSULE: pl = dl * s.size[0]; pl.z += dl.z >= 0 ? s.size[1] : -s.size[1]; break;
+    case G_CAPSULE: pl = dl * s.size[0]; pl.z += dl.z >= -tie ? s.size[1] : -s.size[1]; break;
     case G_CYLINDER: {
         const T r = mw_sqrt(dl.x * dl.x + dl.y * dl.y);
-        if (r > T(1e-15)) { pl.x = dl.x / r * s.size[0]; pl.y = dl.y / r * s.size[0]; }
-        pl.z = dl.z >= 0 ? s.size[1] : -s.size[1];
+        if (r > tie) { pl.x = dl.x / r * s.size[0]; pl.y = dl.y / r * s.size[0]; }
+        pl.z = dl.z >= -tie ? s.size[1] : -s.size[1];
         break;
     }
     case G_BOX:
-        pl = v3(dl.x >= 0 ? s.size[0] : -s.size[0], dl.y >= 0 ? s.size[1] : -s.size[1], dl.z >= 0 ? s.size[2] : -s.size[2]);
+        pl = v3(dl.x >= -tie ? s.size[0] : -s.size[0], dl.y >= -tie ? s.size[1] : -s.size[1], dl.z >= -tie ? s.size[2] : -s.size[2]);
         break;
     case G_MESH: {
         int best = 0;
         T bd = T(-1e30);
         for (int i = 0; i < s.nvert; i++) {
             const T dd = s.vert[3 * i] * dl.x + s.vert[3 * i + 1] * dl.y + s.vert[3 * i + 2] * dl.z;
-            if (dd > bd) { bd = dd; best = i; }
+            if (dd > bd + tie) { bd = dd; best = i; }
         }
         pl = mv3(s.vert + 3 * best);
         break;

@@ -116,7 +116,11 @@ MW_HD void curr_obs(const Env<T>& e, const TaskDesc<T>& td, T* o18) {
     for (int k = 4; k < 18; k++) o18[k] = 0;
     for (int i = 0; i < td.nobj; i++) {
         T* o = o18 + 4 + 7 * i;
-        const V3<T> p = probe_pos(e, td.probe[P_OBJ0 + 2 * i]);
+        V3<T> p = probe_pos(e, td.probe[P_OBJ0 + 2 * i]);
+        if (td.kind == 11) {   // dial-turn: dial centre + 0.05 * [sin q, -cos q, 0]  (envs/sawyer_dial_turn_v3.py:87-98)
+            const T q = e.R(e.L.qpos + td.qadr[0]);
+            p = p + v3<T>(T(0.05) * sin(q), T(-0.05) * cos(q), 0);
+        }
         o[0] = p.x + td.obj_off[i][0]; o[1] = p.y + td.obj_off[i][1]; o[2] = p.z + td.obj_off[i][2];
         const int qm = td.quat_mode[i];
         if (qm == QUAT_SCIPY) scipy_quat(q2mat(probe_quat(e, td.probe[P_OBJ1 + 2 * i])), o + 3);
@@ -456,6 +460,392 @@ MW_HD Out bin_picking_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs,
     return Out{double(reward), double(t2o <= T(0.05)), make_info(near, gs, grasped, in_place, t2o, reward)};
 }
 
+// ---- generic helpers for fixture tasks ----
+// per-env model write: model.body(X).pos = v  (reloc slot k)
+template <typename T> MW_HD void set_reloc(const Env<T>& e, const TaskDesc<T>& td, int k, V3<T> v) { st3(e, e.L.reloc + 3 * td.reloc[k], v); }
+// joint-level _set_obj_xyz variants: qpos[adr] <- q ; qvel[dadr] <- 0 ; set_state -> mj_forward
+template <typename T> MW_HD void set_joint(const Env<T>& e, int qadr, int dadr, T q) {
+    e.R(e.L.qpos + qadr) = q;
+    if (dadr >= 0) e.R(e.L.qvel + dadr) = 0;
+    forward(e);
+}
+
+// ---- button-press-topdown (4), -topdown-wall (5), button-press (6), -wall (7) ----
+// probes: P_X0 = site hole, P_X1 = site buttonStart ; reloc0 = body box ; TK_EXTRA[0] = _obj_to_target_init
+template <typename T>
+MW_HD void button_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> oi = tk3(e, TK_RANDVEC);
+    set_tk3(e, TK_OBJINIT, oi);
+    set_reloc(e, td, 0, oi);
+    if (td.kind == 4 || td.kind == 5) forward(e);       // mujoco.mj_forward
+    else set_joint(e, 9, 9, T(0));                      // _set_obj_xyz(0): qpos[9], qvel[9]
+    const V3<T> target = probe_pos(e, td.probe[P_X0]), bs = probe_pos(e, td.probe[P_X1]);
+    set_tk3(e, TK_TARGET, target);
+    const int ax = (td.kind == 4 || td.kind == 5) ? 2 : 1;
+    TK(e, TK_EXTRA) = mw_abs(comp(target, ax) - comp(bs, ax));
+}
+template <typename T>
+MW_HD Out button_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> obj = obs3(obs, 4), tcp = tcp_center(e, td), target = tk3(e, TK_TARGET);
+    const T tcp_to_obj = norm(obj - tcp), tcp_to_obj_init = norm(obj - tk3(e, TK_INITTCP));
+    const int ax = (td.kind == 4 || td.kind == 5) ? 2 : 1;
+    const T o2t = mw_abs(comp(target, ax) - comp(obj, ax));
+    const T pressed = tolerance_lt(o2t, T(0), T(0.005), TK(e, TK_EXTRA));
+    T near, reward, thr;
+    if (td.kind == 4) {
+        near = tolerance_lt(tcp_to_obj, T(0), T(0.01), tcp_to_obj_init);
+        reward = 5 * hamacher(1 - obs[3], near);
+        if (tcp_to_obj <= T(0.03)) reward += 5 * pressed;
+        thr = T(0.024);
+    } else if (td.kind == 5) {
+        near = tolerance_lt(tcp_to_obj, T(0), T(0.01), tcp_to_obj_init);
+        reward = 5 * hamacher(mw_max(obs[3], T(0)), near);
+        if (tcp_to_obj <= T(0.03)) reward += 5 * pressed;
+        thr = T(0.024);
+    } else if (td.kind == 6) {
+        near = tolerance_lt(tcp_to_obj, T(0), T(0.05), tcp_to_obj_init);
+        reward = 2 * hamacher(mw_max(obs[3], T(0)), near);
+        if (tcp_to_obj <= T(0.05)) reward += 8 * pressed;
+        thr = T(0.02);
+    } else {
+        near = tolerance_lt(tcp_to_obj, T(0), T(0.01), tcp_to_obj_init);
+        if (tcp_to_obj > T(0.07)) reward = 2 * hamacher((1 - obs[3]) / 2, near);
+        else reward = 2 + 2 * (1 + obs[3]) + 4 * pressed * pressed;
+        thr = T(0.03);
+    }
+    return Out{double(reward), double(o2t <= thr), make_info(tcp_to_obj <= T(0.05), obs[3] > 0, near, pressed, o2t, reward)};
+}
+
+// ---- coffee-button (8), coffee-pull (9), coffee-push (10): mug free joint FIRST (qpos[0:7]); reloc0 = coffee_machine ----
+template <typename T>
+MW_HD void coffee_set_mug(const Env<T>& e, V3<T> p) {      // qpos[0:3] <- pos ; qvel[9:15] <- 0 (robot dofs: reference quirk)
+    st3(e, e.L.qpos, p);
+    for (int k = 9; k < 15; k++) e.R(e.L.qvel + k) = 0;
+    forward(e);
+}
+template <typename T>
+MW_HD void coffee_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
+    if (td.kind == 8) {
+        set_tk3(e, TK_OBJINIT, rv0);
+        set_reloc(e, td, 0, rv0);
+        coffee_set_mug(e, rv0 + v3<T>(0, T(-0.22), 0));
+        set_tk3(e, TK_TARGET, rv0 + v3<T>(0, T(-0.22), T(0.3)) + v3<T>(0, T(0.03), 0));
+    } else {
+        coffee_set_mug(e, rv0);
+        set_tk3(e, TK_OBJINIT, rv0);
+        set_reloc(e, td, 0, (td.kind == 9 ? rv0 : rv1) + v3<T>(0, T(0.22), 0));
+        set_tk3(e, TK_TARGET, rv1);
+    }
+}
+template <typename T>
+MW_HD Out coffee_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> obj = obs3(obs, 4), tcp = tcp_center(e, td), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
+    const T tcp_to_obj = norm(obj - tcp);
+    if (td.kind == 8) {
+        const T o2t = mw_abs(target.y - obj.y);
+        const T near = tolerance_lt(tcp_to_obj, T(0), T(0.05), norm(obj - tk3(e, TK_INITTCP)));
+        const T pressed = tolerance_lt(o2t, T(0), T(0.005), T(0.03));
+        T reward = 2 * hamacher(mw_max(obs[3], T(0)), near);
+        if (tcp_to_obj <= T(0.05)) reward += 8 * pressed;
+        return Out{double(reward), double(o2t <= T(0.02)), make_info(tcp_to_obj <= T(0.05), obs[3] > 0, near, pressed, o2t, reward)};
+    }
+    const T t2o = norm(scale3(obj - target, T(2), T(2), T(1))), t2oi = norm(scale3(oi - target, T(2), T(2), T(1)));
+    const T in_place = tolerance_lt(t2o, T(0), T(0.05), t2oi);
+    const T grasped = caging_base(e, td, act, obj, oi, T(0.02), T(0.05), T(0.04), T(0.05), T(0.7), false, true);
+    T reward = hamacher(grasped, in_place);
+    if (tcp_to_obj < T(0.04) && obs[3] > 0) reward += 1 + 5 * in_place;
+    if (t2o < T(0.05)) reward = 10;
+    const T d = norm(obj - target);
+    const bool gs = touching_object(e, td, td.geom[G_OBJ]) && obs[3] > 0;
+    return Out{double(reward), double(d <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, d, reward)};
+}
+
+// ---- dial-turn (11): obs pos = B(dial) + 0.05*[sin q, -cos q, 0] ; reloc0 = dial ; qadr0 = knob_Joint_1 ; P_X0 = body dial ----
+template <typename T>
+MW_HD V3<T> dial_pos(const Env<T>& e, const TaskDesc<T>& td) {
+    const T q = e.R(e.L.qpos + td.qadr[0]);
+    return probe_pos(e, td.probe[P_X0]) + v3<T>(T(0.05) * sin(q), T(-0.05) * cos(q), 0);
+}
+template <typename T>
+MW_HD void dial_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC);
+    set_tk3(e, TK_OBJINIT, rv0);
+    set_tk3(e, TK_TARGET, rv0 + v3<T>(0, T(0.03), T(0.03)));
+    set_reloc(e, td, 0, rv0);
+    st3(e, e.L.task + TK_EXTRA, dial_pos(e, td) + v3<T>(T(0.05), T(0.02), T(0.09)));   // dial_push_position (stale FK, like the reference)
+}
+template <typename T>
+MW_HD Out dial_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> obj = dial_pos(e, td), push = obj + v3<T>(T(0.05), T(0.02), T(0.09)), tcp = tcp_center(e, td), target = tk3(e, TK_TARGET);
+    const V3<T> push0 = tk3(e, TK_EXTRA);
+    const T t2o = norm(obj - target), t2oi = norm(push0 - target);
+    const T in_place = tolerance_lt(t2o, T(0), T(0.07), mw_abs(t2oi - T(0.07)));
+    const T tcp_to_obj = norm(push - tcp), tcp_to_obj_init = norm(push0 - tk3(e, TK_INITTCP));
+    T reach = tolerance_gauss(tcp_to_obj, T(0), T(0.005), mw_abs(tcp_to_obj_init - T(0.005)));
+    reach = hamacher(reach, mw_min(mw_max(T(0), act[3]), T(1)));
+    const T reward = 10 * hamacher(reach, in_place);
+    return Out{double(reward), double(t2o <= T(0.07)), make_info(tcp_to_obj <= T(0.01), 1.0, reach, in_place, t2o, reward)};
+}
+
+// ---- door-close (13), door-open (15) [sawyer_door_pull], door-lock (14), door-unlock (16) [sawyer_door_lock] ----
+// reloc0 = door ; qadr0/dadr0 = doorjoint ; P_X0 = body lock_link
+template <typename T>
+MW_HD void door_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC);
+    if (td.kind == 13 || td.kind == 15) {
+        set_tk3(e, TK_OBJINIT, rv0);
+        set_tk3(e, TK_TARGET, rv0 + (td.kind == 13 ? v3<T>(T(0.2), T(-0.2), 0) : v3<T>(T(-0.3), T(-0.45), 0)));
+        set_reloc(e, td, 0, rv0);
+        set_joint(e, td.qadr[0], td.dadr[0], td.kind == 13 ? T(-1.5708) : T(0));
+    } else if (td.kind == 14) {
+        set_reloc(e, td, 0, rv0);
+        for (int k = 0; k < 5; k++) substep(e);                 // raw mj_step x frame_skip
+        const V3<T> oi = probe_pos(e, td.probe[P_X0]);          // body("lock_link").xpos (view; read at reset for the target)
+        set_tk3(e, TK_OBJINIT, oi);
+        set_tk3(e, TK_TARGET, oi + v3<T>(0, T(-0.04), T(-0.1)));
+    } else {
+        set_reloc(e, td, 0, rv0);
+        set_joint(e, 9, 9, T(1.5708));
+        const V3<T> oi = probe_pos(e, td.probe[P_X0]);
+        set_tk3(e, TK_OBJINIT, oi);
+        set_tk3(e, TK_TARGET, oi + v3<T>(T(0.1), T(-0.04), 0));
+    }
+}
+template <typename T>
+MW_HD Out door_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET);
+    if (td.kind == 13) {
+        const V3<T> tcp = tcp_center(e, td);
+        const T tcp_to_target = norm(tcp - target), o2t = norm(obj - target);
+        const T in_place = tolerance_gauss(o2t, T(0), T(0.05), norm(tk3(e, TK_OBJINIT) - target));
+        const T hand_margin = norm(v3(td.hand_init[0], td.hand_init[1], td.hand_init[2]) - obj) + T(0.1);
+        const T hand_in_place = tolerance_gauss(tcp_to_target, T(0), T(0.25 * 0.05), hand_margin);
+        T reward = 3 * hand_in_place + 6 * in_place;
+        if (o2t < T(0.05)) reward = 10;
+        return Out{double(reward), double(o2t <= T(0.08)), make_info(0.0, 1.0, 1.0, hand_in_place, o2t, reward)};
+    }
+    if (td.kind == 15) {
+        const T theta = e.R(e.L.qpos + td.qadr[0]);
+        const T grab = (mw_clamp(act[3], T(-1), T(1)) + 1) / 2;
+        const V3<T> hand = obs3(obs, 0), door = obj + v3<T>(T(-0.05), 0, 0);
+        const T thr = T(0.12), radius = mw_sqrt((hand.x - door.x) * (hand.x - door.x) + (hand.y - door.y) * (hand.y - door.y));
+        const T floor_ = radius <= thr ? T(0) : T(0.04) * T(log(double(radius - thr))) + T(0.4);
+        const T above = hand.z >= floor_ ? T(1) : tolerance_lt(floor_ - hand.z, T(0), T(0.01), floor_ / 2);
+        const T in_place = tolerance_lt(norm(hand - door - v3<T>(T(0.05), T(0.03), T(-0.01))), T(0), thr / 2, T(0.5));
+        const T ready = hamacher(above, in_place);
+        const T pi = T(3.14159265358979323846);
+        const T opened = T(0.2) * T(theta < -pi / 90) + T(0.8) * tolerance_lt(pi / 2 + pi / 6 + theta, T(0), T(0.5), pi / 3);
+        T reward = 2 * hamacher(ready, grab) + 8 * opened;
+        const bool ok = mw_abs(obs[4] - target.x) <= T(0.08);
+        if (ok) reward = 10;
+        return Out{double(reward), double(ok), make_info(ready, grab >= T(0.5), grab, opened, 0.0, reward)};
+    }
+    if (td.kind == 14) {
+        const V3<T> tcp = probe_pos(e, td.probe[P_LPAD]);
+        const T tcp_to_obj = norm(scale3(obj - tcp, T(0.25), T(1), T(0.5)));
+        const T tcp_to_obj_init = tcp_to_obj;              // init_left_pad is a live view of the left pad
+        const T o2t = mw_abs(target.z - obj.z);
+        const T near = tolerance_lt(tcp_to_obj, T(0), T(0.01), tcp_to_obj_init);
+        const T pressed = tolerance_lt(o2t, T(0), T(0.005), T(0.1));
+        const T reward = 2 * hamacher(mw_max(obs[3], T(0)), near) + 8 * pressed;
+        return Out{double(reward), double(o2t <= T(0.02)), make_info(tcp_to_obj <= T(0.05), obs[3] > 0, near, pressed, o2t, reward)};
+    }
+    // door-unlock: obj_init_pos is a live view of lock_link.xpos
+    const V3<T> gripper = obs3(obs, 0), off = v3<T>(0, T(0.055), T(0.07)), oi_live = probe_pos(e, td.probe[P_X0]);
+    const T s2l = norm(scale3(gripper + off - obj, T(0.25), T(1), T(0.5)));
+    const T s2li = norm(scale3(tk3(e, TK_INITTCP) + off - oi_live, T(0.25), T(1), T(0.5)));
+    const T ready = tolerance_lt(s2l, T(0), T(0.02), s2li);
+    const T o2t = mw_abs(target.x - obj.x);
+    const T pushed = tolerance_lt(o2t, T(0), T(0.005), T(0.1));
+    const T reward = 2 * ready + 8 * pushed;
+    return Out{double(reward), double(o2t <= T(0.02)), make_info(s2l <= T(0.05), obs[3] > 0, ready, pushed, o2t, reward)};
+}
+
+// ---- drawer-close (18), drawer-open (19): reloc0 = drawer ; obs pos = B(drawer_link) + offset ----
+template <typename T>
+MW_HD void drawer_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC);
+    set_reloc(e, td, 0, rv0);
+    if (td.kind == 18) {
+        set_tk3(e, TK_TARGET, rv0 + v3<T>(0, T(-0.16), T(0.09)));
+        set_joint(e, 9, -1, T(-0.15));                   // _set_obj_xyz(-maxDist): qpos[9] only, qvel untouched
+        set_tk3(e, TK_OBJINIT, probe_pos(e, td.probe[P_OBJ0]) + v3<T>(0, T(-0.16), T(0.05)));
+    } else {
+        set_tk3(e, TK_OBJINIT, rv0);
+        set_tk3(e, TK_TARGET, rv0 + v3<T>(0, T(-0.16 - 0.2), T(0.09)));
+    }
+}
+template <typename T>
+MW_HD Out drawer_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET);
+    if (td.kind == 18) {
+        const V3<T> oi = tk3(e, TK_OBJINIT), tcp = tcp_center(e, td);
+        const T t2o = norm(obj - target), t2oi = norm(oi - target);
+        const T in_place = tolerance_lt(t2o, T(0), T(0.05), mw_abs(t2oi - T(0.05)));
+        const T tcp_to_obj = norm(obj - tcp), tcp_to_obj_init = norm(oi - tk3(e, TK_INITTCP));
+        T reach = tolerance_gauss(tcp_to_obj, T(0), T(0.005), mw_abs(tcp_to_obj_init - T(0.005)));
+        reach = hamacher(reach, mw_min(mw_max(T(0), act[3]), T(1)));
+        T reward = hamacher(reach, in_place);
+        if (t2o <= T(0.05 + 0.015)) reward = 1;
+        reward *= 10;
+        return Out{double(reward), double(t2o <= T(0.05 + 0.015)), make_info(tcp_to_obj <= T(0.01), 1.0, reach, in_place, t2o, reward)};
+    }
+    const V3<T> gripper = obs3(obs, 0);
+    const T handle_error = norm(obj - target);
+    const T opening = tolerance_lt(handle_error, T(0), T(0.02), T(0.2));
+    const V3<T> handle_init = target + v3<T>(0, T(0.2), 0);
+    const T ge = norm(scale3(obj - gripper, T(3), T(3), T(1))), gei = norm(scale3(handle_init - tk3(e, TK_INITTCP), T(3), T(3), T(1)));
+    const T caging = tolerance_lt(ge, T(0), T(0.01), gei);
+    const T reward = (caging + opening) * 5;
+    const T gerr = norm(obj - gripper);
+    return Out{double(reward), double(handle_error <= T(0.03)), make_info(gerr <= T(0.03), obs[3] > 0, caging, opening, handle_error, reward)};
+}
+
+// ---- faucet-open (20), faucet-close (21): reloc0 = faucetBase ----
+template <typename T>
+MW_HD void faucet_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC);
+    set_tk3(e, TK_OBJINIT, rv0);
+    set_reloc(e, td, 0, rv0);
+    set_tk3(e, TK_TARGET, rv0 + v3<T>(td.kind == 20 ? T(0.175) : T(-0.175), 0, T(0.125)));
+    if (td.kind == 21) forward(e);
+}
+template <typename T>
+MW_HD Out faucet_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    V3<T> obj = obs3(obs, 4);
+    if (td.kind == 20) obj = obj + v3<T>(T(-0.04), 0, T(0.03));
+    const V3<T> tcp = tcp_center(e, td), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
+    const T t2o = norm(obj - target), t2oi = norm(oi - target);
+    const T in_place = tolerance_lt(t2o, T(0), T(0.07), mw_abs(t2oi - T(0.07)));
+    const T tcp_to_obj = norm(obj - tcp), tcp_to_obj_init = norm(oi - tk3(e, TK_INITTCP));
+    const T reach = tolerance_gauss(tcp_to_obj, T(0), T(0.01), mw_abs(tcp_to_obj_init - T(0.01)));
+    T reward = (2 * reach + 3 * in_place) * 2;
+    if (t2o <= T(0.07)) reward = 10;
+    return Out{double(reward), double(t2o <= T(0.07)), make_info(tcp_to_obj <= T(0.01), 1.0, reach, in_place, t2o, reward)};
+}
+
+// ---- handle-press-side (23), handle-press (24), handle-pull-side (25), handle-pull (26): reloc0 = box ----
+// probes: P_X0 = goal site (goalPress / goalPull) ; TK_EXTRA[0..2] = _handle_init_pos
+template <typename T>
+MW_HD void handle_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC);
+    set_tk3(e, TK_OBJINIT, rv0);
+    set_reloc(e, td, 0, rv0);
+    set_joint(e, 9, 9, (td.kind == 23 || td.kind == 24) ? T(-0.001) : T(-0.1));
+    set_tk3(e, TK_TARGET, probe_pos(e, td.probe[P_X0]));
+    const V3<T> h0 = probe_pos(e, td.probe[P_OBJ0]);
+    st3(e, e.L.task + TK_EXTRA, h0);
+    if (td.kind == 25) set_tk3(e, TK_OBJINIT, h0);      // handle-pull-side re-captures obj_init_pos; handle-pull keeps rand_vec
+}
+template <typename T>
+MW_HD Out handle_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> target = tk3(e, TK_TARGET), tcp = tcp_center(e, td);
+    if (td.kind == 23 || td.kind == 24) {
+        const V3<T> obj = probe_pos(e, td.probe[P_OBJ0]), h0 = tk3(e, TK_EXTRA);
+        const T t2o = mw_abs(obj.z - target.z), t2oi = mw_abs(h0.z - target.z);
+        const T in_place = tolerance_lt(t2o, T(0), T(0.02), mw_abs(t2oi - T(0.02)));
+        const T tcp_to_obj = norm(obj - tcp), tcp_to_obj_init = norm(h0 - tk3(e, TK_INITTCP));
+        const T reach = tolerance_lt(tcp_to_obj, T(0), T(0.02), mw_abs(tcp_to_obj_init - T(0.02)));
+        T reward = hamacher(reach, in_place);
+        if (t2o <= T(0.02)) reward = 1;
+        reward *= 10;
+        return Out{double(reward), double(t2o <= T(0.02)), make_info(tcp_to_obj <= T(0.05), 1.0, reach, in_place, t2o, reward)};
+    }
+    const V3<T> obj = obs3(obs, 4), oi = tk3(e, TK_OBJINIT);
+    T t2o, in_place, grasped;
+    bool lifted;
+    if (td.kind == 25) {
+        t2o = norm(obj - target);
+        in_place = tolerance_lt(t2o, T(0), T(0.05), norm(oi - target));
+        grasped = caging_base(e, td, act, obj, oi, T(0.032), T(0.06), T(0.01), T(0.01), T(1), true, false);
+        lifted = obj.z - T(0.01) > oi.z;
+    } else {
+        t2o = mw_abs(target.z - obj.z);
+        in_place = tolerance_lt(t2o, T(0), T(0.05), mw_abs(target.z - oi.z));
+        grasped = caging_base(e, td, act, obj, oi, T(0.022), T(0.05), T(0.01), T(0.01), T(1), true, false);
+        lifted = obj.y - T(0.01) > oi.z;               // sic: y vs z (envs/sawyer_handle_pull_v3.py:159)
+    }
+    T reward = hamacher(grasped, in_place);
+    const T tcp_to_obj = norm(obj - tcp);
+    if (tcp_to_obj < T(0.035) && obs[3] > 0 && lifted) reward += 1 + 5 * in_place;
+    if (t2o < T(0.05)) reward = 10;
+    const bool gs = obs[3] > 0 && obj.z - T(0.03) > oi.z;
+    return Out{double(reward), double(t2o <= (td.kind == 25 ? T(0.08) : T(0.05))), make_info(tcp_to_obj <= T(0.05), gs, grasped, in_place, t2o, reward)};
+}
+
+// ---- lever-pull (27): reloc0 = lever ; qadr0 = LeverAxis ; TK_EXTRA[0..2] = _lever_pos_init ----
+template <typename T>
+MW_HD void lever_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC);
+    set_tk3(e, TK_OBJINIT, rv0);
+    set_reloc(e, td, 0, rv0);
+    st3(e, e.L.task + TK_EXTRA, rv0 + v3<T>(T(0.12), T(-0.2), T(0.25)));
+    set_tk3(e, TK_TARGET, rv0 + v3<T>(T(0.12), 0, T(0.25 + 0.2)));
+}
+template <typename T>
+MW_HD Out lever_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> gripper = obs3(obs, 0), lever = obs3(obs, 4), off = v3<T>(0, T(0.055), T(0.07)), l0 = tk3(e, TK_EXTRA), target = tk3(e, TK_TARGET);
+    const T s2l = norm(scale3(gripper + off - lever, T(4), T(1), T(4)));
+    const T s2li = norm(scale3(tk3(e, TK_INITTCP) + off - l0, T(4), T(1), T(4)));
+    const T ready = tolerance_lt(s2l, T(0), T(0.02), s2li);
+    const T pi = T(3.14159265358979323846);
+    const T angle = -e.R(e.L.qpos + td.qadr[0]), err = mw_abs(angle - pi / 2);
+    const T engagement = tolerance_lt(err, T(0), pi / 48, pi / 2 - pi / 12);
+    const T in_place = tolerance_lt(norm(lever - target), T(0), T(0.04), norm(l0 - target));
+    const T reward = 10 * hamacher(ready, in_place);
+    return Out{double(reward), double(err <= pi / 24), make_info(s2l < T(0.03), ready > T(0.9), ready, engagement, s2l, reward)};
+}
+
+// ---- window-open (48), window-close (49): reloc0 = window ; qadr0 = window_slide ; TK_EXTRA[0..2] = window_handle_pos_init ----
+template <typename T>
+MW_HD void window_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    if (td.kind == 49) set_tk3(e, TK_INITTCP, tcp_center(e, td));
+    const V3<T> rv0 = tk3(e, TK_RANDVEC);
+    set_tk3(e, TK_OBJINIT, rv0);
+    set_tk3(e, TK_TARGET, td.kind == 48 ? rv0 + v3<T>(T(0.2), 0, 0) : rv0);
+    set_reloc(e, td, 0, rv0);
+    const V3<T> h = probe_pos(e, td.probe[P_OBJ0]);                      // stale FK, like the reference
+    st3(e, e.L.task + TK_EXTRA, td.kind == 48 ? h : h + v3<T>(T(0.2), 0, 0));
+    e.R(e.L.qpos + td.qadr[0]) = td.kind == 48 ? T(0) : T(0.2);          // data.joint("window_slide").qpos = ... (no forward)
+}
+template <typename T>
+MW_HD Out window_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> obj = probe_pos(e, td.probe[P_OBJ0]), tcp = tcp_center(e, td), target = tk3(e, TK_TARGET), h0 = tk3(e, TK_EXTRA);
+    const T t2o = mw_abs(obj.x - target.x);
+    const T t2oi = td.kind == 48 ? mw_abs(TK(e, TK_OBJINIT) - target.x) : mw_abs(h0.x - target.x);
+    const T in_place = tolerance_lt(t2o, T(0), T(0.05), mw_abs(t2oi - T(0.05)));
+    const T tcp_to_obj = norm(obj - tcp), tcp_to_obj_init = norm(h0 - tk3(e, TK_INITTCP));
+    const T reach = td.kind == 48 ? tolerance_lt(tcp_to_obj, T(0), T(0.02), mw_abs(tcp_to_obj_init - T(0.02)))
+                                  : tolerance_gauss(tcp_to_obj, T(0), T(0.02), mw_abs(tcp_to_obj_init - T(0.02)));
+    const T reward = 10 * hamacher(reach, in_place);
+    return Out{double(reward), double(t2o <= T(0.05)), make_info(tcp_to_obj <= T(0.05), 1.0, reach, in_place, t2o, reward)};
+}
+
+// model writes that the FIRST reset_model pass leaves behind (the physics of that pass is discarded by mj_resetData,
+// its `model.body(X).pos = ...` writes are not): apply them before the replayed second pass.
+template <typename T>
+MW_HD void task_model_writes(const Env<T>& e, const TaskDesc<T>& td) {
+    const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
+    switch (td.kind) {
+    case 37: set_reloc(e, td, 0, rv1); break;
+    case 4: case 5: case 6: case 7: case 8: case 11: case 13: case 15: case 14: case 16:
+    case 18: case 19: case 20: case 21: case 23: case 24: case 25: case 26: case 27: case 48: case 49: set_reloc(e, td, 0, rv0); break;
+    case 9: set_reloc(e, td, 0, rv0 + v3<T>(0, T(0.22), 0)); break;
+    case 10: set_reloc(e, td, 0, rv1 + v3<T>(0, T(0.22), 0)); break;
+    default: break;
+    }
+}
+
 template <typename T>
 MW_HD void task_reset_model(const Env<T>& e, const TaskDesc<T>& td) {
     switch (td.kind) {
@@ -463,6 +853,15 @@ MW_HD void task_reset_model(const Env<T>& e, const TaskDesc<T>& td) {
     case 40: case 41: case 42: case 30: case 28: pushpick_reset(e, td); break;
     case 47: case 46: case 37: case 17: sweepfam_reset(e, td); break;
     case 2: bin_picking_reset(e, td); break;
+    case 4: case 5: case 6: case 7: button_reset(e, td); break;
+    case 8: case 9: case 10: coffee_reset(e, td); break;
+    case 11: dial_reset(e, td); break;
+    case 13: case 14: case 15: case 16: door_reset(e, td); break;
+    case 18: case 19: drawer_reset(e, td); break;
+    case 20: case 21: faucet_reset(e, td); break;
+    case 23: case 24: case 25: case 26: handle_reset(e, td); break;
+    case 27: lever_reset(e, td); break;
+    case 48: case 49: window_reset(e, td); break;
     default: reset_hand(e, td); break;
     }
 }
@@ -477,6 +876,15 @@ MW_HD void task_evaluate(const Env<T>& e, const TaskDesc<T>& td, const T* obs, c
     case 41: case 28: o = wall_eval(e, td, obs, act); break;
     case 47: case 46: case 37: case 17: o = sweepfam_eval(e, td, obs, act); break;
     case 2: o = bin_picking_eval(e, td, obs, act); break;
+    case 4: case 5: case 6: case 7: o = button_eval(e, td, obs, act); break;
+    case 8: case 9: case 10: o = coffee_eval(e, td, obs, act); break;
+    case 11: o = dial_eval(e, td, obs, act); break;
+    case 13: case 14: case 15: case 16: o = door_eval(e, td, obs, act); break;
+    case 18: case 19: o = drawer_eval(e, td, obs, act); break;
+    case 20: case 21: o = faucet_eval(e, td, obs, act); break;
+    case 23: case 24: case 25: case 26: o = handle_eval(e, td, obs, act); break;
+    case 27: o = lever_eval(e, td, obs, act); break;
+    case 48: case 49: o = window_eval(e, td, obs, act); break;
     default: break;
     }
     *reward = T(o.reward); *success = T(o.success); *info = o.info;
@@ -491,6 +899,7 @@ MW_HD void env_reset(const Env<T>& e, const TaskDesc<T>& td, T* obs39) {
     reset_data(e);
     TK(e, TK_PATHLEN) = 0; TK(e, TK_ELAPSED) = 0; TK(e, TK_EPRET) = 0; TK(e, TK_EPLEN) = 0; TK(e, TK_SUCCESS) = 0;
     for (int k = 0; k < 16; k++) TK(e, TK_EXTRA + k) = 0;
+    task_model_writes(e, td);
     task_reset_model(e, td);
     get_obs(e, td, obs39);
     for (int k = 0; k < 18; k++) { obs39[18 + k] = obs39[k]; TK(e, TK_PREVOBS + k) = obs39[k]; }

@@ -43,6 +43,34 @@ TASK_DEFS = {
     "soccer-v3": dict(objs=[_obj((B, "soccer_ball"), (B, "soccer_ball"), QUAT_SCIPY)], reloc=["goal_whole"]),
     "hand-insert-v3": dict(objs=[_obj((B, "obj"), (B, "obj"), QUAT_MUJOCO)]),
     "bin-picking-v3": dict(objs=[_obj((B, "obj"), (B, "obj"), QUAT_MUJOCO)], extra=[(B, "bin_goal")]),
+    "button-press-topdown-v3": dict(objs=[_obj((B, "button"), (B, "button"), QUAT_MUJOCO, (0, 0, 0.193))],
+                                    extra=[(S, "hole"), (S, "buttonStart")], reloc=["box"], geom="btnGeom"),
+    "button-press-topdown-wall-v3": dict(objs=[_obj((B, "button"), (B, "button"), QUAT_MUJOCO, (0, 0, 0.193))],
+                                         extra=[(S, "hole"), (S, "buttonStart")], reloc=["box"], geom="btnGeom"),
+    "button-press-v3": dict(objs=[_obj((B, "button"), (B, "button"), QUAT_MUJOCO, (0, -0.193, 0))],
+                            extra=[(S, "hole"), (S, "buttonStart")], reloc=["box"], geom="btnGeom"),
+    "button-press-wall-v3": dict(objs=[_obj((B, "button"), (B, "button"), QUAT_MUJOCO, (0, -0.193, 0))],
+                                 extra=[(S, "hole"), (S, "buttonStart")], reloc=["box"], geom="btnGeom"),
+    "coffee-button-v3": dict(objs=[_obj((S, "buttonStart"), None, QUAT_IDENT)], reloc=["coffee_machine"], geom="mug"),
+    "coffee-pull-v3": dict(objs=[_obj((B, "obj"), (G, "mug"), QUAT_SCIPY)], reloc=["coffee_machine"], geom="mug"),
+    "coffee-push-v3": dict(objs=[_obj((B, "obj"), (G, "mug"), QUAT_SCIPY)], reloc=["coffee_machine"], geom="mug"),
+    "dial-turn-v3": dict(objs=[_obj((B, "dial"), (B, "dial"), QUAT_MUJOCO)], extra=[(B, "dial")], reloc=["dial"],
+                         joints=["knob_Joint_1"], dial=True),
+    "door-close-v3": dict(objs=[_obj((G, "handle"), (G, "handle"), QUAT_SCIPY)], reloc=["door"], joints=["doorjoint"]),
+    "door-open-v3": dict(objs=[_obj((G, "handle"), (G, "handle"), QUAT_SCIPY)], reloc=["door"], joints=["doorjoint"]),
+    "door-lock-v3": dict(objs=[_obj((S, "lockStartLock"), (B, "door_link"), QUAT_MUJOCO)], extra=[(B, "lock_link")], reloc=["door"]),
+    "door-unlock-v3": dict(objs=[_obj((S, "lockStartUnlock"), (B, "door_link"), QUAT_MUJOCO)], extra=[(B, "lock_link")], reloc=["door"]),
+    "drawer-close-v3": dict(objs=[_obj((B, "drawer_link"), None, QUAT_ZERO, (0, -0.16, 0.05))], reloc=["drawer"]),
+    "drawer-open-v3": dict(objs=[_obj((B, "drawer_link"), (B, "drawer_link"), QUAT_MUJOCO, (0, -0.16, 0))], reloc=["drawer"]),
+    "faucet-open-v3": dict(objs=[_obj((S, "handleStartOpen"), (B, "faucetBase"), QUAT_MUJOCO, (0, 0, -0.01))], reloc=["faucetBase"]),
+    "faucet-close-v3": dict(objs=[_obj((S, "handleStartClose"), (B, "faucetBase"), QUAT_MUJOCO, (0, 0, -0.01))], reloc=["faucetBase"]),
+    "handle-press-side-v3": dict(objs=[_obj((S, "handleStart"), None, QUAT_ZERO)], extra=[(S, "goalPress")], reloc=["box"]),
+    "handle-press-v3": dict(objs=[_obj((S, "handleStart"), None, QUAT_ZERO)], extra=[(S, "goalPress")], reloc=["box"]),
+    "handle-pull-side-v3": dict(objs=[_obj((S, "handleCenter"), None, QUAT_ZERO)], extra=[(S, "goalPull")], reloc=["box"]),
+    "handle-pull-v3": dict(objs=[_obj((S, "handleRight"), None, QUAT_ZERO)], extra=[(S, "goalPull")], reloc=["box"]),
+    "lever-pull-v3": dict(objs=[_obj((S, "leverStart"), (G, "objGeom"), QUAT_SCIPY)], reloc=["lever"], joints=["LeverAxis"]),
+    "window-open-v3": dict(objs=[_obj((S, "handleOpenStart"), None, QUAT_ZERO)], reloc=["window"], joints=["window_slide"]),
+    "window-close-v3": dict(objs=[_obj((S, "handleCloseStart"), None, QUAT_ZERO)], reloc=["window"], joints=["window_slide"]),
 }
 
 with open(os.path.join(_HERE, "data", "task_constants.json")) as _f:

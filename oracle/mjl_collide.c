@@ -410,6 +410,9 @@ static int box_box(const Shape* A, const Shape* B, double margin, Hit* h, int ma
 }
 
 /* ------------------------------------------- generic convex pair via MPR */
+/* support point; exact ties (direction perpendicular to a flat feature) are broken canonically (towards +,
+   lowest vertex index) within TIE so that two implementations walk the same portal */
+#define TIE 1e-9
 static void support(const Shape* s, const double* dir, double* out) {
     double dl[3], pl[3];
     mulT(dl, s->mat, dir);
@@ -419,23 +422,23 @@ static void support(const Shape* s, const double* dir, double* out) {
         break;
     case MJL_CAPSULE:
         scl3(pl, dl, s->size[0]);
-        pl[2] += dl[2] >= 0 ? s->size[1] : -s->size[1];
+        pl[2] += dl[2] >= -TIE ? s->size[1] : -s->size[1];
         break;
     case MJL_CYLINDER: {
         double r = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
-        if (r > MINVAL) { pl[0] = dl[0] / r * s->size[0]; pl[1] = dl[1] / r * s->size[0]; } else pl[0] = pl[1] = 0;
-        pl[2] = dl[2] >= 0 ? s->size[1] : -s->size[1];
+        if (r > TIE) { pl[0] = dl[0] / r * s->size[0]; pl[1] = dl[1] / r * s->size[0]; } else pl[0] = pl[1] = 0;
+        pl[2] = dl[2] >= -TIE ? s->size[1] : -s->size[1];
         break;
     }
     case MJL_BOX:
-        for (int k = 0; k < 3; k++) pl[k] = dl[k] >= 0 ? s->size[k] : -s->size[k];
+        for (int k = 0; k < 3; k++) pl[k] = dl[k] >= -TIE ? s->size[k] : -s->size[k];
         break;
     case MJL_MESH: {
         int best = 0;
         double bd = -1e30;
         for (int i = 0; i < s->nvert; i++) {
             double dd = dot3(s->vert + 3 * i, dl);
-            if (dd > bd) { bd = dd; best = i; }
+            if (dd > bd + TIE) { bd = dd; best = i; }
         }
         copy3(pl, s->vert + 3 * best);
         break;
