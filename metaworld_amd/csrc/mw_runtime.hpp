@@ -161,8 +161,10 @@ template <typename T>
 MW_HD void load_snapshot(const World<T>& w, const Env<T>& e, int task, int goal, T* obs39) {
     const T* s = w.snap + w.snap_off[task] + (long long)goal * w.snap_stride[task];
     const int ns = e.L.nstate;
+    const V3<T> persist = tk3(e, TK_PERSIST0);
     for (int k = 0; k < ns; k++) e.R(k) = s[k];
     for (int k = 0; k < 39; k++) obs39[k] = s[ns + k];
+    if (w.tasks[task].kind == 1) task_after_reset(e, w.tasks[task], persist, obs39);
 }
 
 // ---- lane programs -------------------------------------------------------------------------

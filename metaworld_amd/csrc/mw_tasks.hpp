@@ -30,7 +30,8 @@ enum {
     TK_RANDVEC = 33,  // rand_vec[6]
     TK_EXTRA = 39,    // task-specific scalars [16]
     TK_SUCCESS = 55,  // last success flag
-    TK_END = 56
+    TK_PERSIST0 = 56, // 3 reals that survive resets (basketball's drifting goal-site local position)
+    TK_END = 59
 };
 static_assert(TK_END <= TASK_NREAL, "task block too small");
 
@@ -831,6 +832,329 @@ MW_HD Out window_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, cons
     return Out{double(reward), double(t2o <= T(0.05)), make_info(tcp_to_obj <= T(0.05), 1.0, reach, in_place, t2o, reward)};
 }
 
+// ---- plate-slide (31), -side (32), -back (33), -back-side (34): puck on two slide joints qpos[9:11]; reloc0 = puck_goal ----
+template <typename T>
+MW_HD void plate_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
+    set_tk3(e, TK_OBJINIT, rv0);
+    set_tk3(e, TK_TARGET, rv1);
+    if (td.kind == 31) set_reloc(e, td, 0, rv1);
+    if (td.kind == 34) set_reloc(e, td, 0, rv0);
+    const T q0 = td.kind == 34 ? T(-0.15) : T(0), q1 = td.kind == 33 ? T(0.15) : T(0);
+    e.R(e.L.qpos + 9) = q0; e.R(e.L.qpos + 10) = q1;          // _set_obj_xyz: qpos[9:11], qvel untouched
+    forward(e);
+}
+template <typename T>
+MW_HD T tolerance_lt_checked(T x, T lo, T hi, T margin) {   // the reference raises ValueError for margin < 0; defined here as margin 0
+    return tolerance_lt(x, lo, hi, margin < 0 ? T(0) : margin);
+}
+template <typename T>
+MW_HD Out plate_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> tcp = tcp_center(e, td), obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
+    const T o2t = norm(obj - target), tcp_to_obj = norm(tcp - obj);
+    const T m1 = norm(oi - target), m2 = norm(tk3(e, TK_INITTCP) - oi);
+    T in_place, grasped, reward;
+    if (td.kind == 31) {
+        in_place = tolerance_lt(o2t, T(0), T(0.05), m1);
+        grasped = tolerance_lt(tcp_to_obj, T(0), T(0.05), m2);
+        reward = 8 * hamacher(grasped, in_place);
+    } else {
+        in_place = tolerance_lt_checked(o2t, T(0), T(0.05), m1 - T(0.05));
+        grasped = tolerance_lt_checked(tcp_to_obj, T(0), T(0.05), m2 - T(0.05));
+        reward = T(1.5) * grasped;
+        if (tcp.z <= T(0.03) && tcp_to_obj < T(0.07)) reward = 2 + 7 * in_place;
+    }
+    if (o2t < T(0.05)) reward = 10;
+    return Out{double(reward), double(o2t <= T(0.07)), make_info(tcp_to_obj <= T(0.03), 0.0, grasped, in_place, o2t, reward)};
+}
+
+// ---- assembly (0), disassemble (12) [sawyer_assembly_peg], hammer (22) ----
+// probes: P_X0 = site RoundNut (wrench centre) ; reloc0 = peg (assembly/disassemble), box (hammer) ; qadr0 = NailSlideJoint
+template <typename T>
+MW_HD void wrench_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
+    set_tk3(e, TK_OBJINIT, rv0);
+    if (td.kind == 0) {
+        set_tk3(e, TK_TARGET, rv1);
+        set_obj_xyz(e, rv0);
+        set_reloc(e, td, 0, rv1 - v3<T>(0, 0, T(0.05)));
+    } else if (td.kind == 12) {
+        set_tk3(e, TK_TARGET, rv0 + v3<T>(0, 0, T(0.15)));
+        set_reloc(e, td, 0, rv0 + v3<T>(0, 0, T(0.03)));
+        forward(e);
+        set_obj_xyz(e, rv0);
+    } else {
+        set_reloc(e, td, 0, v3<T>(T(0.24), T(0.85), 0));
+        set_tk3(e, TK_TARGET, probe_pos(e, td.probe[P_X0]));     // _get_site_pos("goal") from the current FK
+        set_obj_xyz(e, rv0);                                     // _set_hammer_xyz == default layout qpos[9:12], qvel[9:15]
+    }
+}
+template <typename T>
+MW_HD Out wrench_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> hand = obs3(obs, 0), obj = obs3(obs, 4), target = tk3(e, TK_TARGET);
+    V3<T> threshed = obj;
+    const T half = td.kind == 22 ? T(0.07) : T(0.01);
+    if (mw_abs(obj.x - hand.x) < half) threshed.x = hand.x;
+    const T ideal[4] = {td.kind == 22 ? T(1) : T(0.707), 0, 0, td.kind == 22 ? T(0) : T(0.707)};
+    T qe = 0;
+    for (int k = 0; k < 4; k++) qe += (obs[7 + k] - ideal[k]) * (obs[7 + k] - ideal[k]);
+    const T rquat = mw_max(1 - mw_sqrt(qe) / T(0.4), T(0));
+    const T grab = caging_base(e, td, act, threshed, tk3(e, TK_OBJINIT), T(0.015), T(0.02), T(0.01), T(0.01), T(1), td.kind != 0, td.kind == 0);
+    T in_place;
+    bool success;
+    if (td.kind == 0) {
+        const V3<T> wc = probe_pos(e, td.probe[P_X0]);
+        V3<T> pe = target - wc;
+        const T radius = mw_sqrt(pe.x * pe.x + pe.y * pe.y);
+        success = radius < T(0.02) && pe.z > 0;
+        const T thr = success ? T(0.02) : T(0.01);
+        T th = 0;
+        if (radius > thr) th = T(0.02) * T(log(double(radius - thr))) + T(0.2);
+        pe.z = th - wc.z;
+        const bool lifted = wc.z > T(0.02) || radius < thr;
+        in_place = T(0.1) * T(lifted) + T(0.9) * tolerance_lt(norm(scale3(pe, T(1), T(1), T(3))), T(0), T(0.02), T(0.4));
+    } else if (td.kind == 12) {
+        const V3<T> wc = probe_pos(e, td.probe[P_X0]);
+        in_place = T(0.1) * T(wc.z > T(0.02)) + T(0.9) * tolerance_lt(norm(target + v3<T>(0, 0, T(0.1)) - wc), T(0), T(0.02), T(0.2));
+        success = obs[6] > target.z;
+    } else {
+        const V3<T> head = obj + v3<T>(T(0.16), T(0.06), 0);
+        in_place = T(0.1) * T(head.z > T(0.02)) + T(0.9) * tolerance_lt(norm(target - head), T(0), T(0.02), T(0.2));
+        success = e.R(e.L.qpos + td.qadr[0]) > T(0.09);
+    }
+    T reward = (2 * grab + 6 * in_place) * rquat;
+    if (td.kind == 22 ? (success && reward > 5) : success) reward = 10;
+    return Out{double(reward), double(success), make_info(rquat, grab >= T(0.5), grab, in_place, 0.0, reward)};
+}
+
+// ---- basketball (1): reloc0 = basket_goal ; P_X0 = site goal.  The reference assigns the site's WORLD position to its
+// LOCAL model.site_pos at every reset_model call (envs/sawyer_basketball_v3.py:119-122), so the goal site drifts by
+// 2*(hoop position) per reset.  TK_PERSIST[0..2] = accumulated model.site("goal").pos (survives resets). ----
+enum { TK_PERSIST = TK_PERSIST0 };
+template <typename T>
+MW_HD void basketball_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
+    const V3<T> oi{rv0.x, rv0.y, td.c[2]};
+    set_tk3(e, TK_OBJINIT, oi);
+    set_reloc(e, td, 0, rv1);
+    set_obj_xyz(e, oi);
+    st3(e, e.L.task + TK_EXTRA, probe_pos(e, td.probe[P_X0]));   // hoop site position for local pos 0 (= B + c)
+}
+template <typename T>
+MW_HD Out basketball_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> obj = obs3(obs, 4), oi = tk3(e, TK_OBJINIT);
+    V3<T> target = tk3(e, TK_TARGET);
+    target.z = T(0.3);
+    const T t2o = norm(scale3(obj - target, T(1), T(1), T(2))), t2oi = norm(scale3(oi - target, T(1), T(1), T(2)));
+    const T in_place = tolerance_lt(t2o, T(0), T(0.08), t2oi);
+    const T opened = obs[3], tcp_to_obj = norm(obj - tcp_center(e, td));
+    T grasped = caging_base(e, td, act, obj, oi, T(0.025), T(0.06), T(0.01), T(0.005), T(1), true, false);
+    const bool held = tcp_to_obj < T(0.035) && opened > 0 && obj.z - T(0.01) > oi.z;
+    if (held) grasped = 1;
+    T reward = hamacher(grasped, in_place);
+    if (held) reward += 1 + 5 * in_place;
+    if (t2o < T(0.08)) reward = 10;
+    const bool gs = opened > 0 && obj.z - T(0.03) > oi.z;
+    return Out{double(reward), double(t2o <= T(0.08)), make_info(tcp_to_obj <= T(0.05), gs, grasped, in_place, t2o, reward)};
+}
+
+// ---- box-close (3): reloc0 = boxbody ; c[6] = model z of boxbody ----
+template <typename T>
+MW_HD void box_close_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
+    const V3<T> oi{rv0.x, rv0.y, td.c[2]};
+    set_tk3(e, TK_OBJINIT, oi);
+    set_tk3(e, TK_TARGET, rv1);
+    set_reloc(e, td, 0, v3<T>(rv1.x, rv1.y, td.c[6]));
+    for (int k = 0; k < 5; k++) substep(e);
+    set_obj_xyz(e, oi);
+}
+template <typename T>
+MW_HD Out box_close_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> hand = obs3(obs, 0), lid = obs3(obs, 4) + v3<T>(0, 0, T(0.02)), target = tk3(e, TK_TARGET);
+    const T grab = mw_clamp((mw_clamp(act[3], T(-1), T(1)) + 1) / 2, T(0), T(1));
+    const T ideal[4] = {T(0.707), 0, 0, T(0.707)};
+    T qe = 0;
+    for (int k = 0; k < 4; k++) qe += (obs[7 + k] - ideal[k]) * (obs[7 + k] - ideal[k]);
+    const T rquat = mw_max(1 - mw_sqrt(qe) / T(0.2), T(0));
+    const T radius = mw_sqrt((hand.x - lid.x) * (hand.x - lid.x) + (hand.y - lid.y) * (hand.y - lid.y));
+    const T floor_ = radius <= T(0.02) ? T(0) : T(0.04) * T(log(double(radius - T(0.02)))) + T(0.4);
+    const T above = hand.z >= floor_ ? T(1) : tolerance_lt(floor_ - hand.z, T(0), T(0.01), floor_ / 2);
+    const T in_place = tolerance_lt(norm(hand - lid), T(0), T(0.02), T(0.5));
+    const T ready = hamacher(above, in_place);
+    const T lifted = T(0.2) * T(lid.z > T(0.04)) + T(0.8) * tolerance_lt(norm(scale3(target - lid, T(1), T(1), T(3))), T(0), T(0.05), T(0.25));
+    T reward = 2 * hamacher(grab, ready) + 8 * lifted;
+    const bool success = norm(obs3(obs, 4) - target) < T(0.08);
+    if (success) reward = 10;
+    reward *= rquat;
+    return Out{double(reward), double(success), make_info(ready, grab >= T(0.5), grab, lifted, 0.0, reward)};
+}
+
+// ---- pick-out-of-hole (29), shelf-place (45), peg-insert-side (35), peg-unplug-side (36) ----
+template <typename T>
+MW_HD void misc_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
+    if (td.kind == 29) {
+        set_tk3(e, TK_OBJINIT, rv0); set_obj_xyz(e, rv0); set_tk3(e, TK_TARGET, rv1);
+    } else if (td.kind == 45) {
+        const V3<T> oi{rv0.x, rv0.y, probe_pos(e, td.probe[P_OBJ0]).z};     // adjust_initObjPos z = body z
+        const V3<T> shelf = rv1 - v3<T>(0, 0, T(0.3));
+        set_tk3(e, TK_OBJINIT, oi);
+        set_reloc(e, td, 0, shelf);
+        forward(e);
+        set_tk3(e, TK_TARGET, c3(td, 6) + shelf);                            // model.site("goal").pos + model.body("shelf").pos
+        set_obj_xyz(e, oi);
+    } else if (td.kind == 35) {
+        set_tk3(e, TK_OBJINIT, rv0);
+        st3(e, e.L.task + TK_EXTRA, probe_pos(e, td.probe[P_X0]));           // peg_head_pos_init (before the peg is placed)
+        set_obj_xyz(e, rv0);
+        set_reloc(e, td, 0, rv1);
+        set_tk3(e, TK_TARGET, rv1 + v3<T>(T(0.03), 0, T(0.13)));
+    } else {
+        set_reloc(e, td, 0, rv0);
+        const V3<T> plug = rv0 + v3<T>(T(0.044), 0, T(0.131));
+        st3(e, e.L.qpos + 9, plug);
+        st4(e, e.L.qpos + 12, Q4<T>{1, 0, 0, 0});
+        for (int k = 9; k < 12; k++) e.R(e.L.qvel + k) = 0;
+        forward(e);
+        set_tk3(e, TK_OBJINIT, probe_pos(e, td.probe[P_OBJ0]));
+        set_tk3(e, TK_TARGET, plug + v3<T>(T(0.15), 0, 0));
+    }
+}
+template <typename T>
+MW_HD T rect_prism_tolerance(V3<T> curr, V3<T> zero, V3<T> one) {
+    auto in_range = [](T a, T b, T c) { return c >= b ? (b <= a && a <= c) : (c <= a && a <= b); };
+    if (in_range(curr.x, zero.x, one.x) && in_range(curr.y, zero.y, one.y) && in_range(curr.z, zero.z, one.z)) {
+        const V3<T> d = one - zero;
+        return (curr.x - zero.x) / d.x * ((curr.y - zero.y) / d.y) * ((curr.z - zero.z) / d.z);
+    }
+    return 1;
+}
+template <typename T>
+MW_HD Out misc_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> tcp = tcp_center(e, td), obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
+    const T opened = obs[3], tcp_to_obj = norm(obj - tcp);
+    if (td.kind == 29) {
+        const T o2t = norm(obj - target);
+        const T radius = mw_sqrt((tcp.x - oi.x) * (tcp.x - oi.x) + (tcp.y - oi.y) * (tcp.y - oi.y));
+        const T floor_ = radius <= T(0.03) ? T(0) : T(0.015) * T(log(double(radius - T(0.03)))) + T(0.15);
+        const T above = tcp.z >= floor_ ? T(1) : tolerance_lt(mw_max(floor_ - tcp.z, T(0)), T(0), T(0.01), T(0.02));
+        const T grasped = caging_base(e, td, act, obj, oi, T(0.015), T(0.02), T(0.01), T(0.03), T(0.1), true, false);
+        const T in_place = tolerance_lt(o2t, T(0), T(0.02), norm(oi - target));
+        T reward = hamacher(grasped, in_place);
+        const bool gs = tcp_to_obj < T(0.04) && obj.z - T(0.02) > oi.z && !(opened < T(0.33));
+        if (gs) reward += 1 + 5 * hamacher(in_place, above);
+        if (o2t < T(0.05)) reward = 10;
+        return Out{double(reward), double(o2t <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, o2t, reward)};
+    }
+    if (td.kind == 45) {
+        const T o2t = norm(obj - target);
+        T in_place = tolerance_lt(o2t, T(0), T(0.05), norm(oi - target));
+        const T grasped = caging_base(e, td, act, obj, oi, T(0.02), T(0.05), T(0.01), T(0.01), T(1), false, false);
+        T reward = hamacher(grasped, in_place);
+        const bool inx = target.x - T(0.15) < obj.x && obj.x < target.x + T(0.15), inz = 0 < obj.z && obj.z < T(0.24);
+        if (inz && inx && target.y - T(0.15) < obj.y && obj.y < target.y) {
+            const T zs = (T(0.24) - obj.z) / T(0.24), ys = (obj.y - (target.y - T(0.15))) / T(0.15);
+            in_place = mw_clamp(in_place - hamacher(ys, zs), T(0), T(1));
+        }
+        if (inz && inx && obj.y > target.y) in_place = 0;
+        if (tcp_to_obj < T(0.025) && opened > 0 && obj.z - T(0.01) > oi.z) reward += 1 + 5 * in_place;
+        if (o2t < T(0.05)) reward = 10;
+        const bool gs = touching_object(e, td, td.geom[G_OBJ]) && opened > 0 && obj.z - T(0.02) > oi.z;
+        return Out{double(reward), double(o2t <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, o2t, reward)};
+    }
+    if (td.kind == 35) {
+        const V3<T> head = probe_pos(e, td.probe[P_X0]);
+        const T o2t = norm(scale3(head - target, T(1), T(2), T(2)));
+        T in_place = tolerance_lt(o2t, T(0), T(0.07), norm(scale3(tk3(e, TK_EXTRA) - target, T(1), T(2), T(2))));
+        const T cb1 = rect_prism_tolerance(head, probe_pos(e, td.probe[P_X1]), probe_pos(e, td.probe[P_X2]));
+        const T cb2 = rect_prism_tolerance(head, probe_pos(e, td.probe[P_X3]), probe_pos(e, td.probe[P_X4]));
+        in_place = hamacher(in_place, hamacher(cb2, cb1));
+        T grasped = caging_base(e, td, act, obj, oi, T(0.0075), T(0.03), T(0.01), T(0.005), T(1), true, false);
+        const bool held = tcp_to_obj < T(0.08) && opened > 0 && obj.z - T(0.01) > oi.z;
+        if (held) grasped = 1;
+        T reward = hamacher(grasped, in_place);
+        if (held) reward += 1 + 5 * in_place;
+        if (o2t <= T(0.07)) reward = 10;
+        const bool gs = tcp_to_obj < T(0.02) && opened > 0 && obj.z - T(0.01) > oi.z;
+        return Out{double(reward), double(o2t <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, o2t, reward)};
+    }
+    const T o2t = norm(obj - target);
+    const T grasped = caging_base(e, td, act, obj, oi, T(0.025), T(0.05), T(0.01), T(0.005), T(0.8), true, false);
+    const T in_place = tolerance_lt(o2t, T(0), T(0.05), norm(oi - target));
+    const bool gs = opened > T(0.5) && obj.x - oi.x > T(0.015);
+    T reward = 2 * grasped;
+    if (gs && tcp_to_obj < T(0.035)) reward = 1 + 2 * grasped + 5 * in_place;
+    if (o2t <= T(0.05)) reward = 10;
+    return Out{double(reward), double(o2t <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, o2t, reward)};
+}
+
+// ---- stick-push (38), stick-pull (39): stick free joint qpos[9:16], container slides qpos[16:18] ----
+// probes: OBJ0 = body stick, OBJ1 = body stick (scipy quat), OBJ2 = site insertion ; P_X0 = body object, P_X1 = site stick_end
+// TK_EXTRA[0..2] = stick_init_pos ; c[6] = stick_init z
+template <typename T>
+MW_HD void stick_reset(const Env<T>& e, const TaskDesc<T>& td) {
+    reset_hand(e, td);
+    const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
+    const V3<T> si{rv0.x, rv0.y, td.c[6]};
+    st3(e, e.L.task + TK_EXTRA, si);
+    set_tk3(e, TK_TARGET, v3<T>(rv1.x, rv1.y, td.kind == 38 ? probe_pos(e, td.probe[P_OBJ2]).z : si.z));
+    set_obj_xyz(e, si);                                           // _set_stick_xyz
+    e.R(e.L.qpos + 16) = 0; e.R(e.L.qpos + 17) = td.kind == 38 ? T(0) : T(0.09);
+    e.R(e.L.qvel + 15) = e.R(e.L.qvel + 15); e.R(e.L.qvel + 16) = 0;   // qvel[16:18] = 0 (index 17 is out of range for nv = 17)
+    forward(e);
+    set_tk3(e, TK_OBJINIT, probe_pos(e, td.probe[P_X0]));
+}
+template <typename T>
+MW_HD Out stick_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+    const V3<T> tcp = tcp_center(e, td), target = tk3(e, TK_TARGET), si = tk3(e, TK_EXTRA), oi = tk3(e, TK_OBJINIT);
+    const T opened = obs[3];
+    const bool touch = touching_object(e, td, td.geom[G_OBJ]);
+    if (td.kind == 38) {
+        const V3<T> stick = obs3(obs, 4) + v3<T>(T(0.015), 0, 0), container = obs3(obs, 11);
+        const T tcp_to_stick = norm(stick - tcp), s2t = norm(stick - target), c2t = norm(container - target);
+        const T sip = tolerance_lt_checked(s2t, T(0), T(0.12), norm(si - target) - T(0.12));
+        const T cip = tolerance_lt_checked(c2t, T(0), T(0.12), norm(oi - target) - T(0.12));
+        T grasped = caging_base(e, td, act, stick, si, T(0.04), T(0.05), T(0.01), T(0.01), T(1), true, false);
+        T reward = grasped;
+        if (tcp_to_stick < T(0.02) && opened > 0 && stick.z - T(0.01) > si.z) {
+            grasped = 1;
+            reward = 2 + 5 * sip + 3 * cip;
+            if (c2t <= T(0.12)) reward = 10;
+        }
+        const bool gs = touch && opened > 0 && obs[6] - T(0.01) > si.z;
+        const bool ok = norm(container - target) <= T(0.12);
+        return Out{double(reward), double(gs && ok), make_info(tcp_to_stick <= T(0.03), gs, grasped, sip, c2t, reward)};
+    }
+    const V3<T> stick = obs3(obs, 4), handle = obs3(obs, 11), end = probe_pos(e, td.probe[P_X1]);
+    const V3<T> container = handle + v3<T>(T(0.05), 0, 0), cinit = oi + v3<T>(T(0.05), 0, 0);
+    const T tcp_to_stick = norm(stick - tcp), h2t = norm(handle - target);
+    const T s2c = norm(scale3(stick - container, T(1), T(1), T(2)));
+    const T sip = tolerance_lt(s2c, T(0), T(0.05), norm(scale3(si - cinit, T(1), T(1), T(2))));
+    const T sip2 = tolerance_lt(norm(stick - target), T(0), T(0.05), norm(si - target));
+    const T cip = tolerance_lt(norm(container - target), T(0), T(0.05), norm(oi - target));
+    T grasped = caging_base(e, td, act, stick, oi, T(0.014), T(0.05), T(0.01), T(0.01), T(1), true, false);
+    const bool gsr = tcp_to_stick < T(0.02) && opened > 0 && stick.z - T(0.01) > si.z;
+    if (gsr) grasped = 1;
+    const bool inserted = end.x >= handle.x && mw_abs(end.y - handle.y) <= T(0.04) && mw_abs(end.z - handle.z) <= T(0.06);
+    const T ipg = hamacher(grasped, sip);
+    T reward = ipg;
+    if (gsr) {
+        reward = 1 + ipg + 5 * sip;
+        if (inserted) {
+            reward = 1 + ipg + 5 + 2 * sip2 + cip;
+            if (h2t <= T(0.12)) reward = 10;
+        }
+    }
+    const bool gs = touch && opened > 0 && stick.z - T(0.02) > oi.z;
+    return Out{double(reward), double(h2t <= T(0.12) && inserted), make_info(tcp_to_stick <= T(0.03), gs, grasped, sip, h2t, reward)};
+}
+
 // model writes that the FIRST reset_model pass leaves behind (the physics of that pass is discarded by mj_resetData,
 // its `model.body(X).pos = ...` writes are not): apply them before the replayed second pass.
 template <typename T>
@@ -841,6 +1165,15 @@ MW_HD void task_model_writes(const Env<T>& e, const TaskDesc<T>& td) {
     case 4: case 5: case 6: case 7: case 8: case 11: case 13: case 15: case 14: case 16:
     case 18: case 19: case 20: case 21: case 23: case 24: case 25: case 26: case 27: case 48: case 49: set_reloc(e, td, 0, rv0); break;
     case 9: set_reloc(e, td, 0, rv0 + v3<T>(0, T(0.22), 0)); break;
+    case 31: case 1: set_reloc(e, td, 0, rv1); break;
+    case 34: set_reloc(e, td, 0, rv0); break;
+    case 0: set_reloc(e, td, 0, rv1 - v3<T>(0, 0, T(0.05))); break;
+    case 12: set_reloc(e, td, 0, rv0 + v3<T>(0, 0, T(0.03))); break;
+    case 22: set_reloc(e, td, 0, v3<T>(T(0.24), T(0.85), 0)); break;
+    case 3: set_reloc(e, td, 0, v3<T>(rv1.x, rv1.y, td.c[6])); break;
+    case 45: set_reloc(e, td, 0, rv1 - v3<T>(0, 0, T(0.3))); break;
+    case 35: set_reloc(e, td, 0, rv1); break;
+    case 36: set_reloc(e, td, 0, rv0); break;
     case 10: set_reloc(e, td, 0, rv1 + v3<T>(0, T(0.22), 0)); break;
     default: break;
     }
@@ -862,6 +1195,12 @@ MW_HD void task_reset_model(const Env<T>& e, const TaskDesc<T>& td) {
     case 23: case 24: case 25: case 26: handle_reset(e, td); break;
     case 27: lever_reset(e, td); break;
     case 48: case 49: window_reset(e, td); break;
+    case 31: case 32: case 33: case 34: plate_reset(e, td); break;
+    case 0: case 12: case 22: wrench_reset(e, td); break;
+    case 1: basketball_reset(e, td); break;
+    case 3: box_close_reset(e, td); break;
+    case 29: case 45: case 35: case 36: misc_reset(e, td); break;
+    case 38: case 39: stick_reset(e, td); break;
     default: reset_hand(e, td); break;
     }
 }
@@ -885,9 +1224,27 @@ MW_HD void task_evaluate(const Env<T>& e, const TaskDesc<T>& td, const T* obs, c
     case 23: case 24: case 25: case 26: o = handle_eval(e, td, obs, act); break;
     case 27: o = lever_eval(e, td, obs, act); break;
     case 48: case 49: o = window_eval(e, td, obs, act); break;
+    case 31: case 32: case 33: case 34: o = plate_eval(e, td, obs, act); break;
+    case 0: case 12: case 22: o = wrench_eval(e, td, obs, act); break;
+    case 1: o = basketball_eval(e, td, obs, act); break;
+    case 3: o = box_close_eval(e, td, obs, act); break;
+    case 29: case 45: case 35: case 36: o = misc_eval(e, td, obs, act); break;
+    case 38: case 39: o = stick_eval(e, td, obs, act); break;
     default: break;
     }
     *reward = T(o.reward); *success = T(o.success); *info = o.info;
+}
+
+// state that survives a reset (only basketball's accumulated goal-site position): called after reset_model / snapshot load
+template <typename T>
+MW_HD void task_after_reset(const Env<T>& e, const TaskDesc<T>& td, V3<T> persist_before, T* obs39) {
+    if (td.kind != 1) return;
+    const V3<T> P = tk3(e, TK_EXTRA), s = persist_before + P * T(2);
+    st3(e, e.L.task + TK_PERSIST, s);
+    set_tk3(e, TK_TARGET, P + s);
+    // the reset observation is built from the FK that precedes the last site write: it shows s (= 2P + s_before), the
+    // episode itself sees P + s
+    if (!td.partially_observable) { obs39[36] = s.x; obs39[37] = s.y; obs39[38] = s.z; }
 }
 
 // =========================================================================== env-level reset / step
@@ -899,10 +1256,12 @@ MW_HD void env_reset(const Env<T>& e, const TaskDesc<T>& td, T* obs39) {
     reset_data(e);
     TK(e, TK_PATHLEN) = 0; TK(e, TK_ELAPSED) = 0; TK(e, TK_EPRET) = 0; TK(e, TK_EPLEN) = 0; TK(e, TK_SUCCESS) = 0;
     for (int k = 0; k < 16; k++) TK(e, TK_EXTRA + k) = 0;
+    const V3<T> persist = tk3(e, TK_PERSIST0);
     task_model_writes(e, td);
     task_reset_model(e, td);
     get_obs(e, td, obs39);
     for (int k = 0; k < 18; k++) { obs39[18 + k] = obs39[k]; TK(e, TK_PREVOBS + k) = obs39[k]; }
+    task_after_reset(e, td, persist, obs39);
 }
 
 // SawyerXYZEnv.step (:579-642) up to (obs, reward, success, info); wrappers are applied by the caller

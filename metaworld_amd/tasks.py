@@ -71,6 +71,27 @@ TASK_DEFS = {
     "lever-pull-v3": dict(objs=[_obj((S, "leverStart"), (G, "objGeom"), QUAT_SCIPY)], reloc=["lever"], joints=["LeverAxis"]),
     "window-open-v3": dict(objs=[_obj((S, "handleOpenStart"), None, QUAT_ZERO)], reloc=["window"], joints=["window_slide"]),
     "window-close-v3": dict(objs=[_obj((S, "handleCloseStart"), None, QUAT_ZERO)], reloc=["window"], joints=["window_slide"]),
+    "plate-slide-v3": dict(objs=[_obj((G, "puck"), (G, "puck"), QUAT_SCIPY)], reloc=["puck_goal"], geom="puck"),
+    "plate-slide-side-v3": dict(objs=[_obj((G, "puck"), (G, "puck"), QUAT_SCIPY)], geom="puck"),
+    "plate-slide-back-v3": dict(objs=[_obj((G, "puck"), (G, "puck"), QUAT_SCIPY)], reloc=["puck_goal"], geom="puck"),
+    "plate-slide-back-side-v3": dict(objs=[_obj((G, "puck"), (G, "puck"), QUAT_SCIPY)], reloc=["puck_goal"], geom="puck"),
+    "assembly-v3": dict(objs=[_obj((S, "RoundNut-8"), (B, "RoundNut"), QUAT_MUJOCO)], extra=[(S, "RoundNut")], reloc=["peg"], geom="WrenchHandle"),
+    "disassemble-v3": dict(objs=[_obj((S, "RoundNut-8"), (B, "RoundNut"), QUAT_MUJOCO)], extra=[(S, "RoundNut")], reloc=["peg"], geom="WrenchHandle"),
+    "hammer-v3": dict(objs=[_obj((B, "hammer"), (B, "hammer"), QUAT_MUJOCO), _obj((B, "nail_link"), (B, "nail_link"), QUAT_MUJOCO)],
+                      extra=[(S, "goal")], reloc=["box"], joints=["NailSlideJoint"], geom="HammerHandle"),
+    "basketball-v3": dict(objs=[_obj((B, "bsktball"), (B, "bsktball"), QUAT_MUJOCO)], extra=[(S, "goal")], reloc=["basket_goal"]),
+    "box-close-v3": dict(objs=[_obj((B, "top_link"), (B, "top_link"), QUAT_MUJOCO)], reloc=["boxbody"], geom="BoxHandleGeom",
+                         c_model=[("body_pos", "boxbody", 2)]),
+    "pick-out-of-hole-v3": dict(objs=[_obj((B, "obj"), (B, "obj"), QUAT_MUJOCO)]),
+    "shelf-place-v3": dict(objs=[_obj((B, "obj"), (G, "objGeom"), QUAT_SCIPY)], reloc=["shelf"], c_model=[("site_pos", "goal", None)]),
+    "peg-insert-side-v3": dict(objs=[_obj((S, "pegGrasp"), (S, "pegGrasp"), QUAT_SCIPY)], reloc=["box"],
+                               extra=[(S, "pegHead"), (S, "bottom_right_corner_collision_box_1"), (S, "top_left_corner_collision_box_1"),
+                                      (S, "bottom_right_corner_collision_box_2"), (S, "top_left_corner_collision_box_2")]),
+    "peg-unplug-side-v3": dict(objs=[_obj((S, "pegEnd"), (B, "plug1"), QUAT_MUJOCO)], reloc=["box"]),
+    "stick-push-v3": dict(objs=[_obj((B, "stick"), (B, "stick"), QUAT_SCIPY), _obj((S, "insertion"), None, QUAT_ZERO, (0, 0.09, 0))],
+                          extra=[(B, "object"), (S, "stick_end")], c=[0.02]),
+    "stick-pull-v3": dict(objs=[_obj((B, "stick"), (B, "stick"), QUAT_SCIPY), _obj((S, "insertion"), None, QUAT_ZERO)],
+                          extra=[(B, "object"), (S, "stick_end")], c=[0.02]),
 }
 
 with open(os.path.join(_HERE, "data", "task_constants.json")) as _f:
@@ -180,6 +201,14 @@ def task_struct(task, model_index, roles, reloc, onehot_id, partially_observable
     for i in range(3):
         t.c[i] = oi[i] if i < len(oi) else 0.0
         t.c[3 + i] = c["goal"][i] if i < len(c["goal"]) else 0.0
-    for i, v in enumerate(d.get("c", [])):
-        t.c[6 + i] = v
+    k = 6
+    for v in d.get("c", []):
+        t.c[k] = v
+        k += 1
+    for arr, name, comp in d.get("c_model", []):      # constants read from the compiled model (XML values)
+        kind = "body" if arr == "body_pos" else "site"
+        vals = m.arrays[arr][m.names[kind][name]]
+        for v in ([vals[comp]] if comp is not None else vals):
+            t.c[k] = float(v)
+            k += 1
     return t
