@@ -541,6 +541,33 @@ MW_HD int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>*
     return n;
 }
 
+// conservative oriented-box test on the 6 face axes of the two geoms' local bounding boxes (never culls a touching pair)
+template <typename T>
+MW_HD bool obb_overlap(const Env<T>& e, int g1, int g2, T margin) {
+    const Model<T>& m = *e.m;
+    const M3<T> R1 = ld9(e, e.L.geom_xmat + 9 * g1), R2 = ld9(e, e.L.geom_xmat + 9 * g2);
+    const T *a = m.geom_aabb + 6 * g1, *b = m.geom_aabb + 6 * g2;
+    const V3<T> c1 = ld3(e, e.L.geom_xpos + 3 * g1) + R1 * mv3(a), c2 = ld3(e, e.L.geom_xpos + 3 * g2) + R2 * mv3(b);
+    const V3<T> d = c2 - c1;
+    T Rm[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            Rm[3 * i + j] = R1.m[i] * R2.m[j] + R1.m[3 + i] * R2.m[3 + j] + R1.m[6 + i] * R2.m[6 + j];   // R1^T R2
+    const V3<T> t1 = mulT(R1, d);
+    const T tt[3] = {t1.x, t1.y, t1.z};
+    const T slack = margin + T(1e-6);
+    for (int i = 0; i < 3; i++) {
+        const T rb = b[3] * mw_abs(Rm[3 * i]) + b[4] * mw_abs(Rm[3 * i + 1]) + b[5] * mw_abs(Rm[3 * i + 2]);
+        if (mw_abs(tt[i]) > a[3 + i] + rb + slack) return false;
+    }
+    for (int j = 0; j < 3; j++) {
+        const T ra = a[3] * mw_abs(Rm[j]) + a[4] * mw_abs(Rm[3 + j]) + a[5] * mw_abs(Rm[6 + j]);
+        const T tj = tt[0] * Rm[j] + tt[1] * Rm[3 + j] + tt[2] * Rm[6 + j];
+        if (mw_abs(tj) > ra + b[3 + j] + slack) return false;
+    }
+    return true;
+}
+
 template <typename T>
 MW_HD void collision(const Env<T>& e) {
     const Model<T>& m = *e.m;
@@ -554,6 +581,7 @@ MW_HD void collision(const Env<T>& e) {
             const T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
             const V3<T> t = p1 - p2;
             if (dot(t, t) > bound * bound) continue;
+            if (!obb_overlap(e, g1, g2, margin)) continue;   // mid-phase: oriented bounding boxes (conservative)
         } else {
             const V3<T> n{e.R(L.geom_xmat + 9 * g1 + 2), e.R(L.geom_xmat + 9 * g1 + 5), e.R(L.geom_xmat + 9 * g1 + 8)};
             if (dot(p2 - p1, n) > m.geom_rbound[g2] + margin) continue;

@@ -59,7 +59,7 @@ struct Model {
     const T *jnt_pos, *jnt_axis, *jnt_range, *jnt_stiffness, *jnt_springref, *jnt_solref, *jnt_solimp, *jnt_margin;
     const T *dof_armature, *dof_damping, *dof_invweight0, *qpos0;
     const T *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solref, *geom_solimp, *geom_solmix;
-    const T *geom_margin, *geom_gap, *geom_rbound, *geom_invweight0;
+    const T *geom_margin, *geom_gap, *geom_rbound, *geom_invweight0, *geom_aabb;
     const T *mesh_vert, *act_kp, *act_ctrlrange, *eq_solref, *eq_solimp, *eq_data, *eq_invweight0;
     const T *probe_pos, *probe_quat;
 };

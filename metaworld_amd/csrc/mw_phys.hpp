@@ -684,14 +684,21 @@ MW_HD void solve(const Env<T>& e) {
 }
 
 // ------------------------------------------------------------------ pipeline
+#if defined(MW_PROFILE) && !defined(__HIPCC__)
+#include <chrono>
+inline double* mw_prof() { static double t[8] = {0}; return t; }
+#define MW_STAGE(i, call) { auto t0_ = std::chrono::steady_clock::now(); call; mw_prof()[i] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(); }
+#else
+#define MW_STAGE(i, call) call;
+#endif
 template <typename T>
 MW_HD void forward(const Env<T>& e) {
-    kinematics(e);
-    crb(e);
-    collision(e);
-    make_constraints(e);
-    smooth_forces(e);
-    solve(e);
+    MW_STAGE(0, kinematics(e))
+    MW_STAGE(1, crb(e))
+    MW_STAGE(2, collision(e))
+    MW_STAGE(3, make_constraints(e))
+    MW_STAGE(4, smooth_forces(e))
+    MW_STAGE(5, solve(e))
 }
 
 template <typename T>

@@ -76,7 +76,7 @@ struct DeviceModel {
             {"geom_size", &Model<T>::geom_size}, {"geom_pos", &Model<T>::geom_pos}, {"geom_quat", &Model<T>::geom_quat},
             {"geom_friction", &Model<T>::geom_friction}, {"geom_solref", &Model<T>::geom_solref}, {"geom_solimp", &Model<T>::geom_solimp},
             {"geom_solmix", &Model<T>::geom_solmix}, {"geom_margin", &Model<T>::geom_margin}, {"geom_gap", &Model<T>::geom_gap},
-            {"geom_rbound", &Model<T>::geom_rbound}, {"geom_invweight0", &Model<T>::geom_invweight0}, {"mesh_vert", &Model<T>::mesh_vert},
+            {"geom_rbound", &Model<T>::geom_rbound}, {"geom_invweight0", &Model<T>::geom_invweight0}, {"geom_aabb", &Model<T>::geom_aabb}, {"mesh_vert", &Model<T>::mesh_vert},
             {"act_kp", &Model<T>::act_kp}, {"act_ctrlrange", &Model<T>::act_ctrlrange}, {"eq_solref", &Model<T>::eq_solref},
             {"eq_solimp", &Model<T>::eq_solimp}, {"eq_data", &Model<T>::eq_data}, {"eq_invweight0", &Model<T>::eq_invweight0},
             {"probe_pos", &Model<T>::probe_pos}, {"probe_quat", &Model<T>::probe_quat}};

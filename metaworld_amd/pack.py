@@ -33,6 +33,28 @@ def resolve_probe(m: Model, kind: str, name: str):
     raise KeyError(kind)
 
 
+def geom_aabb(m: Model):
+    """[ngeom][6] = (centre, half extents) of each geom's bounding box in its own frame (mid-phase culling only)."""
+    A = m.arrays
+    out = np.zeros((len(A["geom_type"]), 6))
+    for g, t in enumerate(A["geom_type"]):
+        s = A["geom_size"][g]
+        if t == 2:
+            out[g, 3:] = s[0]
+        elif t == 3:
+            out[g, 3:] = [s[0], s[0], s[0] + s[1]]
+        elif t == 5:
+            out[g, 3:] = [s[0], s[0], s[1]]
+        elif t in (4, 6):
+            out[g, 3:] = s
+        elif t == 7:
+            mi = A["geom_meshid"][g]
+            v = A["mesh_vert"][A["mesh_vertadr"][mi]:A["mesh_vertadr"][mi] + A["mesh_vertnum"][mi]]
+            out[g, :3] = 0.5 * (v.max(0) + v.min(0))
+            out[g, 3:] = 0.5 * (v.max(0) - v.min(0))
+    return out
+
+
 def pack_model(m: Model, probes, reloc_bodies=(), maxcon=64, maxefc=256, tolerance=None, iterations=None,
                ls_iterations=50):
     """probes: list of (kind, name); reloc_bodies: names of bodies whose `body_pos` is per-environment state."""
@@ -45,6 +67,7 @@ def pack_model(m: Model, probes, reloc_bodies=(), maxcon=64, maxefc=256, toleran
         relocid[m.names["body"][name]] = i
     ints["body_relocid"] = relocid
     reals["geom_invweight0"] = A["body_invweight0"][A["geom_bodyid"]].ravel()
+    reals["geom_aabb"] = geom_aabb(m).ravel()
     eqw = A["body_invweight0"][A["eq_body1"]] + A["body_invweight0"][A["eq_body2"]]
     reals["eq_invweight0"] = eqw.ravel()
     reals["eq_data"] = np.tile(np.array(REFERENCE_WELD_DATA), len(A["eq_body1"]))

@@ -154,7 +154,14 @@ def model_probes(model_name):
     return probes, roles
 
 
-def packed_model(model_name, maxcon=64, maxefc=256, **kw):
+with open(os.path.join(_HERE, "data", "model_caps.json")) as _f:
+    MODEL_CAPS = json.load(_f)     # per-model contact / constraint-row capacities (measured maxima x 1.5, tools/measure_caps)
+
+
+def packed_model(model_name, maxcon=None, maxefc=None, **kw):
+    caps = MODEL_CAPS.get(model_name, dict(maxcon=64, maxefc=256))
+    maxcon = maxcon or caps["maxcon"]
+    maxefc = maxefc or caps["maxefc"]
     probes, roles = model_probes(model_name)
     reloc = []
     for task, d in TASK_DEFS.items():

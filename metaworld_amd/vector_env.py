@@ -63,7 +63,7 @@ class MetaWorldGpuVectorEnv:
 
     def __init__(self, benchmark="MT1", env_name=None, num_envs=None, seed=None, use_one_hot=False,
                  max_episode_steps=None, terminate_on_success=False, precision="fp32", device_id=0,
-                 rank=0, world_size=1, goal_seed=42, task_names=None, lib=None, maxcon=64, maxefc=256):
+                 rank=0, world_size=1, goal_seed=42, task_names=None, lib=None, maxcon=None, maxefc=None):
         names, goal_key = benchmark_tasks(benchmark, env_name)
         if task_names is not None:          # restrict a benchmark to the tasks that have device code (tests)
             names = [n for n in names if n in task_names]

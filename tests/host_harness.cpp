@@ -36,3 +36,9 @@ struct Backend {
 #include "../include/mwgpu.h"
 #define MW_API(name) mwh_##name
 #include "../metaworld_amd/csrc/mw_abi.inl"
+
+#ifdef MW_PROFILE
+extern "C" void mwh_profile(double* out, int reset) {
+    for (int i = 0; i < 8; i++) { out[i] = mw::mw_prof()[i]; if (reset) mw::mw_prof()[i] = 0; }
+}
+#endif

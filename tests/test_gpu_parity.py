@@ -62,3 +62,28 @@ def test_gpu_full_size_properties(gpulib):
 def test_smoke_entry(gpulib):
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.parametrize("task", ["push-v3", "pick-place-v3", "door-open-v3", "drawer-close-v3", "button-press-v3", "window-open-v3",
+                                  "peg-insert-side-v3", "stick-push-v3", "assembly-v3", "coffee-push-v3"])
+def test_gpu_task_matches_reference_trace(gpulib, task):
+    """MT10 tasks + a few contact-rich ones, fp64 on the GPU, one step from a synchronised state."""
+    G = dict(golden(f"trace_{task}_seed42.npz"))
+    env = make_env(gpulib, task, n=len(G["goal_idx"]), precision="fp64")
+    r = replay_trace(env, G, sync=True, steps=30)
+    env.close()
+    assert r["reset"] < 1e-6 and r["obs"] < 1e-5 and r["reward"] < 1e-5 and r["success_mismatch"] == 0, r
+
+
+def test_gpu_mt50_smoke(gpulib):
+    """MT50 x 200 envs in fp32: finite outputs, one-hot ids cover all 50 tasks, truncation + auto-reset fire together."""
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    env = MetaWorldGpuVectorEnv("MT50", num_envs=200, seed=1, use_one_hot=True, precision="fp32", lib=gpulib, max_episode_steps=10)
+    obs, _ = env.reset()
+    assert obs.shape == (200, 89) and set(obs[:, 39:].argmax(1)) == set(range(50))
+    rng = np.random.default_rng(0)
+    for t in range(10):
+        obs, rew, term, trunc, infos = env.step(rng.uniform(-1, 1, (200, 4)).astype(np.float32))
+        assert np.isfinite(obs).all() and np.isfinite(rew).all() and (rew >= 0).all() and (rew <= 10).all()
+    assert trunc.all() and infos["_final_obs"].all()
+    env.close()
