@@ -228,6 +228,7 @@ def gather_bookkeeping(local: np.ndarray, device=None):
     t = torch.from_numpy(np.ascontiguousarray(local))
     if device is not None:
         t = t.to(device)
-    out = torch.empty((dist.get_world_size(),) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    world = dist.get_world_size()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)   # concatenated along dim 0
     dist.all_gather_into_tensor(out, t)
-    return out.cpu().numpy()
+    return out.reshape((world,) + tuple(t.shape)).cpu().numpy()
