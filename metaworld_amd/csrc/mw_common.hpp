@@ -34,7 +34,7 @@ constexpr int MAX_NV = 24;       // per-lane register vectors are sized by this
 constexpr int CON_STRIDE = 26;   // reals per contact record
 constexpr int CON_ISTRIDE = 4;   // ints per contact record
 constexpr int EFC_EXTRA = 8;     // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv
-constexpr int EFC_ISTRIDE = 3;   // type, id, state
+constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a non-zero Jacobian entry
 
 struct Sizes {
     int nq, nv, nbody, njnt, ngeom, nsite, nmesh, nmeshvert, npair, nu, neq, nprobe, nreloc;
@@ -112,9 +112,9 @@ struct Env {
     Layout L;
     T* col;        // real column store, already offset by the lane
     int* icol;     // int column store, already offset by the lane
-    size_t stride;
-    MW_HD T& R(int i) const { return col[(size_t)i * stride]; }
-    MW_HD int& I(int i) const { return icol[(size_t)i * stride]; }
+    unsigned stride;   // 32-bit index arithmetic: nreal * stride < 2^32 (checked at group creation)
+    MW_HD T& R(int i) const { return col[(unsigned)i * stride]; }
+    MW_HD int& I(int i) const { return icol[(unsigned)i * stride]; }
 };
 
 // ----------------------------------------------------------------------------- small math

@@ -308,23 +308,33 @@ MW_HD void finish_row(const Env<T>& e, int row, const T* solref, const T* solimp
     const T imp = impedance(solimp, r);
     const T R = mw_max(T(1e-15), (1 - imp) / imp * diagApprox);
     T vel = 0;
-    for (int i = 0; i < nv; i++) vel += EJ(e, row, i) * e.R(e.L.qvel + i);
+    for (int i = IEFC(e, row, 3); i <= IEFC(e, row, 4); i++) vel += EJ(e, row, i) * e.R(e.L.qvel + i);
+    (void)nv;
     EX(e, row, 2) = R; EX(e, row, 3) = 1 / R;
     EX(e, row, 4) = -B * vel - K * imp * r;
     if (Rout) { *Rout = R; *Bout = B; *Iout = imp; }
 }
 
+template <typename T>
+MW_HD void row_range(const Env<T>& e, int row, int first, int last) {
+    if (first < IEFC(e, row, 3)) IEFC(e, row, 3) = first;
+    if (last > IEFC(e, row, 4)) IEFC(e, row, 4) = last;
+}
 // J rows (translational/rotational) of a world point on body b: accumulate sign * axis . jac into row
 template <typename T>
 MW_HD void add_jac_row(const Env<T>& e, int row, int body, V3<T> point, V3<T> axis, bool rotational, T sign) {
     const Model<T>& m = *e.m;
-    for (int i = m.body_lastdof[body]; i >= 0; i = m.dof_parentid[i]) {
+    const int last = m.body_lastdof[body];
+    int first = last;
+    for (int i = last; i >= 0; i = m.dof_parentid[i]) {
         V3<T> w = ld3(e, e.L.cdof + 6 * i);
         T val;
         if (rotational) val = dot(axis, w);
         else val = dot(axis, ld3(e, e.L.cdof + 6 * i + 3) + cross(w, point));
         EJ(e, row, i) += sign * val;
+        first = i;
     }
+    if (last >= 0) row_range(e, row, first, last);
 }
 
 template <typename T>
@@ -335,6 +345,7 @@ MW_HD int new_rows(const Env<T>& e, int n, int type, int id) {
     const int r0 = nefc;
     for (int k = 0; k < n; k++) {
         IEFC(e, r0 + k, 0) = type; IEFC(e, r0 + k, 1) = id; IEFC(e, r0 + k, 2) = 0;
+        IEFC(e, r0 + k, 3) = m.sz.nv; IEFC(e, r0 + k, 4) = -1;
         for (int i = 0; i < m.sz.nv; i++) EJ(e, r0 + k, i) = 0;
         EX(e, r0 + k, 0) = 0; EX(e, r0 + k, 1) = 0;
     }
@@ -370,13 +381,16 @@ MW_HD void make_constraints(const Env<T>& e) {
         for (int pass = 0; pass < 2; pass++) {
             const int b = pass ? b2 : b1;
             const T sg = pass ? T(-1) : T(1);
+            int first = m.body_lastdof[b];
             for (int i = m.body_lastdof[b]; i >= 0; i = m.dof_parentid[i]) {
                 V3<T> w = ld3(e, L.cdof + 6 * i);
                 Q4<T> q4 = qmul(qmul(q2n, Q4<T>{0, w.x, w.y, w.z}), qa);
                 EJ(e, r0 + 3, i) += sg * T(0.5) * q4.x * ts;
                 EJ(e, r0 + 4, i) += sg * T(0.5) * q4.y * ts;
                 EJ(e, r0 + 5, i) += sg * T(0.5) * q4.z * ts;
+                first = i;
             }
+            if (m.body_lastdof[b] >= 0) for (int k = 3; k < 6; k++) row_range(e, r0 + k, first, m.body_lastdof[b]);
         }
         const T res[6] = {cp.x, cp.y, cp.z, ts * qr.x, ts * qr.y, ts * qr.z};
         for (int k = 0; k < 6; k++) {
@@ -394,6 +408,7 @@ MW_HD void make_constraints(const Env<T>& e) {
                 const int r = new_rows(e, 1, C_LIMIT, j);
                 if (r < 0) continue;
                 EJ(e, r, m.jnt_dofadr[j]) = T(-side);
+                row_range(e, r, m.jnt_dofadr[j], m.jnt_dofadr[j]);
                 EX(e, r, 0) = dist; EX(e, r, 1) = margin;
                 finish_row(e, r, m.jnt_solref + 2 * j, m.jnt_solimp + 5 * j, m.dof_invweight0[m.jnt_dofadr[j]], (T*)nullptr, (T*)nullptr, (T*)nullptr);
             }
@@ -429,7 +444,7 @@ MW_HD void make_constraints(const Env<T>& e) {
             const T fk = k < 3 ? f0 : f1;
             const T R = R0 * f0 * f0 / (fk * fk);
             T vel = 0;
-            for (int i = 0; i < nv; i++) vel += EJ(e, r0 + k, i) * e.R(L.qvel + i);
+            for (int i = IEFC(e, r0 + k, 3); i <= IEFC(e, r0 + k, 4); i++) vel += EJ(e, r0 + k, i) * e.R(L.qvel + i);
             EX(e, r0 + k, 2) = R; EX(e, r0 + k, 3) = 1 / R; EX(e, r0 + k, 4) = -B * vel;
         }
         CON(e, c, 24) = f0;  // mu = friction[0] * sqrt(R[1]/R[0]) with impratio 1
@@ -503,10 +518,13 @@ MW_HD T update_constraint(const Env<T>& e) {
     }
     T gauss = 0;
     for (int k = 0; k < nv; k++) {
-        T s = 0;
-        for (int i = 0; i < nefc; i++) s += EJ(e, i, k) * EX(e, i, 5);
-        e.R(L.qfrc_c + k) = s;
+        e.R(L.qfrc_c + k) = 0;
         gauss += (e.R(L.Ma + k) - e.R(L.smooth + k)) * (e.R(L.qacc + k) - e.R(L.qacc_smooth + k));
+    }
+    for (int i = 0; i < nefc; i++) {      // J' f over the active rows and their non-zero dof range only
+        const T f = EX(e, i, 5);
+        if (f == 0) continue;
+        for (int k = IEFC(e, i, 3); k <= IEFC(e, i, 4); k++) e.R(L.qfrc_c + k) += EJ(e, i, k) * f;
     }
     return cost + T(0.5) * gauss;
 }
@@ -566,7 +584,7 @@ MW_HD void solve(const Env<T>& e) {
         }
         for (int i = 0; i < nefc; i++) {
             T s = -EX(e, i, 4);
-            for (int j = 0; j < nv; j++) s += EJ(e, i, j) * e.R(L.qacc + j);
+            for (int j = IEFC(e, i, 3); j <= IEFC(e, i, 4); j++) s += EJ(e, i, j) * e.R(L.qacc + j);
             EX(e, i, 6) = s;
         }
     };
@@ -594,11 +612,12 @@ MW_HD void solve(const Env<T>& e) {
             const int st = IEFC(e, i, 2);
             if (st == S_QUADRATIC) {
                 const T D = EX(e, i, 3);
-                for (int a = 0; a < nv; a++) {
+                const int lo = IEFC(e, i, 3), hi = IEFC(e, i, 4);
+                for (int a = lo; a <= hi; a++) {
                     const T ja = EJ(e, i, a);
                     if (ja == 0) continue;
                     const T Da = D * ja;
-                    for (int b = 0; b <= a; b++) e.R(L.qH + a * nv + b) += Da * EJ(e, i, b);
+                    for (int b = lo; b <= a; b++) e.R(L.qH + a * nv + b) += Da * EJ(e, i, b);
                 }
             } else if (st == S_CONE) {
                 const int c = IEFC(e, i, 1);
@@ -615,7 +634,9 @@ MW_HD void solve(const Env<T>& e) {
                         else h = scl * z.U[r] * z.U[s] + (r == s ? dg : T(0));
                         Hc[4 * r + s] = h * Dm * z.fri[r] * z.fri[s];
                     }
-                for (int a = 0; a < nv; a++) {
+                int lo = nv, hi = -1;
+                for (int r = 0; r < z.dim; r++) { lo = IEFC(e, i + r, 3) < lo ? IEFC(e, i + r, 3) : lo; hi = IEFC(e, i + r, 4) > hi ? IEFC(e, i + r, 4) : hi; }
+                for (int a = lo; a <= hi; a++) {
                     T ja[4], t[4];
                     bool any = false;
                     for (int r = 0; r < z.dim; r++) { ja[r] = EJ(e, i + r, a); any |= ja[r] != 0; }
@@ -624,7 +645,7 @@ MW_HD void solve(const Env<T>& e) {
                         t[s] = 0;
                         for (int r = 0; r < z.dim; r++) t[s] += ja[r] * Hc[4 * r + s];
                     }
-                    for (int b = 0; b <= a; b++) {
+                    for (int b = lo; b <= a; b++) {
                         T acc = 0;
                         for (int s = 0; s < z.dim; s++) acc += t[s] * EJ(e, i + s, b);
                         e.R(L.qH + a * nv + b) += acc;
@@ -654,7 +675,7 @@ MW_HD void solve(const Env<T>& e) {
         if (snorm < T(1e-15)) break;
         for (int i = 0; i < nefc; i++) {
             T s = 0;
-            for (int j = 0; j < nv; j++) s += EJ(e, i, j) * e.R(L.search + j);
+            for (int j = IEFC(e, i, 3); j <= IEFC(e, i, 4); j++) s += EJ(e, i, j) * e.R(L.search + j);
             EX(e, i, 7) = s;
         }
         const T gtol = m.tolerance * T(0.01) * snorm / scale;

@@ -145,7 +145,7 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Env<T>* e, int* gid)
     const GroupDev<T>& G = w.groups[g];
     const int lane = (block - G.block0) * BLOCK + thread;
     if (lane >= G.nenv) return false;
-    e->m = &G.m; e->L = G.L; e->col = G.col + lane; e->icol = G.icol + lane; e->stride = G.stride;
+    e->m = &G.m; e->L = G.L; e->col = G.col + lane; e->icol = G.icol + lane; e->stride = (unsigned)G.stride;
     *gid = G.gid[lane];
     return true;
 }
@@ -339,6 +339,7 @@ class Context : public ContextBase {
         g.nenv = (int)gids.size();
         g.gid = gids;
         g.stride = (size_t)((g.nenv + BLOCK - 1) / BLOCK) * BLOCK;
+        if ((double)g.stride * g.L.nreal >= 4294967295.0) throw std::runtime_error("group too large for 32-bit column indexing");
         g.col = (T*)Backend::alloc(sizeof(T) * g.stride * g.L.nreal);
         g.icol = (int*)Backend::alloc(sizeof(int) * g.stride * g.L.nint);
         Backend::zero(g.col, sizeof(T) * g.stride * g.L.nreal);
