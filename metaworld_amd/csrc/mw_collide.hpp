@@ -522,7 +522,7 @@ MW_HD Shape<T> make_shape(const Env<T>& e, int g) {
 }
 
 template <typename T>
-MW_HD int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h) {
+MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h) {
     const int t1 = a_.type, t2 = b_.type;
     int n = -1;
     if (t1 == G_PLANE) n = plane_x(a_, b_, margin, h);
@@ -569,7 +569,7 @@ MW_HD bool obb_overlap(const Env<T>& e, int g1, int g2, T margin) {
 }
 
 template <typename T>
-MW_HD void collision(const Env<T>& e) {
+MW_STAGE_FN void collision(const Env<T>& e) {
     const Model<T>& m = *e.m;
     const Layout& L = e.L;
     int ncon = 0;

@@ -19,8 +19,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MW_HD __host__ __device__ inline
+#define MW_STAGE_FN __host__ __device__ __attribute__((noinline))   // the big stages: one copy each (code size, compile time)
 #else
 #define MW_HD inline
+#define MW_STAGE_FN inline
 #endif
 
 namespace mw {

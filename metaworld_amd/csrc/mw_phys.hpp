@@ -14,11 +14,11 @@
 
 namespace mw {
 
-template <typename T> MW_HD void collision(const Env<T>& e);  // mw_collide.hpp
+template <typename T> MW_STAGE_FN void collision(const Env<T>& e);  // mw_collide.hpp
 
 // ------------------------------------------------------------------ kinematics
 template <typename T>
-MW_HD void kinematics(const Env<T>& e) {
+MW_STAGE_FN void kinematics(const Env<T>& e) {
     const Model<T>& m = *e.m;
     const Layout& L = e.L;
     const int nb = m.sz.nbody;
@@ -162,7 +162,7 @@ MW_HD void chol_solve(const Env<T>& e, int A, int x, int n) {
 
 // ------------------------------------------------------------------ mass matrix
 template <typename T>
-MW_HD void crb(const Env<T>& e) {
+MW_STAGE_FN void crb(const Env<T>& e) {
     const Model<T>& m = *e.m;
     const Layout& L = e.L;
     const int nb = m.sz.nbody, nv = m.sz.nv;
@@ -199,7 +199,7 @@ MW_HD void cross_motion(T* r, const T* v, const T* s) {
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = b.x; r[4] = b.y; r[5] = b.z;
 }
 template <typename T>
-MW_HD void smooth_forces(const Env<T>& e) {
+MW_STAGE_FN void smooth_forces(const Env<T>& e) {
     const Model<T>& m = *e.m;
     const Layout& L = e.L;
     const int nb = m.sz.nbody, nv = m.sz.nv;
@@ -354,7 +354,7 @@ MW_HD int new_rows(const Env<T>& e, int n, int type, int id) {
 }
 
 template <typename T>
-MW_HD void make_constraints(const Env<T>& e) {
+MW_STAGE_FN void make_constraints(const Env<T>& e) {
     const Model<T>& m = *e.m;
     const Layout& L = e.L;
     const int nv = m.sz.nv;
@@ -530,8 +530,15 @@ MW_HD T update_constraint(const Env<T>& e) {
 }
 
 // constraint part of the cost (no forces written) at jar + alpha*Jv, with 1st/2nd derivatives along the line
+#if defined(MW_PROFILE) && !defined(__HIPCC__)
+inline long* mw_cnt() { static long c[8] = {0}; return c; }
+#define MW_COUNT(i) mw_cnt()[i]++;
+#else
+#define MW_COUNT(i)
+#endif
 template <typename T>
 MW_HD void line_eval(const Env<T>& e, T alpha, const T* quadGauss, T* cost, T* d1, T* d2) {
+    MW_COUNT(0)
     const int nefc = e.I(e.L.icount + 1);
     T C = alpha * alpha * quadGauss[2] + alpha * quadGauss[1] + quadGauss[0];
     T D1 = 2 * alpha * quadGauss[2] + quadGauss[1], D2 = 2 * quadGauss[2];
@@ -566,7 +573,7 @@ MW_HD void line_eval(const Env<T>& e, T alpha, const T* quadGauss, T* cost, T* d
 }
 
 template <typename T>
-MW_HD void solve(const Env<T>& e) {
+MW_STAGE_FN void solve(const Env<T>& e) {
     const Model<T>& m = *e.m;
     const Layout& L = e.L;
     const int nv = m.sz.nv, nefc = e.I(L.icount + 1);
@@ -598,7 +605,9 @@ MW_HD void solve(const Env<T>& e) {
         else { set_point(L.warm); cost = update_constraint(e); }
     }
     const T scale = 1 / (m.meaninertia * T(nv > 1 ? nv : 1));
+    MW_COUNT(2)
     for (int iter = 0; iter < m.sz.iterations; iter++) {
+        MW_COUNT(1)
         T gn = 0;
         for (int k = 0; k < nv; k++) {
             const T g = e.R(L.Ma + k) - e.R(L.smooth + k) - e.R(L.qfrc_c + k);

@@ -236,6 +236,16 @@ MW_HD void lane_debug(const World<T>& w, int what, int n, int block, int thread)
     else if (what == 1) for (int k = 0; k < n; k++) substep(e);
     else if (what == 2) reset_data(e);
     else if (what == 3) kinematics(e);
+    else if (what >= 10)            // stage timing: run stages 0..(what-10) of one dynamics evaluation, n times
+        for (int it = 0; it < n; it++) {
+            const int k = what - 10;
+            kinematics(e);
+            if (k >= 1) crb(e);
+            if (k >= 2) collision(e);
+            if (k >= 3) make_constraints(e);
+            if (k >= 4) smooth_forces(e);
+            if (k >= 5) solve(e);
+        }
 }
 
 // ------------------------------------------------------------------ host-side context

@@ -188,7 +188,8 @@ class Context:
         self._check(self.lib.write(self.ptr, env, what.encode(), a.ctypes.data, a.size))
 
     def debug(self, what, n=0):
-        self._check(self.lib.debug(self.ptr, {"forward": 0, "substeps": 1, "reset_data": 2, "kinematics": 3}[what], n))
+        code = what if isinstance(what, int) else {"forward": 0, "substeps": 1, "reset_data": 2, "kinematics": 3}[what]
+        self._check(self.lib.debug(self.ptr, code, n))
 
     def close(self):
         if self.ptr:

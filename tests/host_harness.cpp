@@ -42,3 +42,8 @@ extern "C" void mwh_profile(double* out, int reset) {
     for (int i = 0; i < 8; i++) { out[i] = mw::mw_prof()[i]; if (reset) mw::mw_prof()[i] = 0; }
 }
 #endif
+#ifdef MW_PROFILE
+extern "C" void mwh_counters(long* out, int reset) {
+    for (int i = 0; i < 8; i++) { out[i] = mw::mw_cnt()[i]; if (reset) mw::mw_cnt()[i] = 0; }
+}
+#endif
