@@ -505,12 +505,12 @@ MW_HD int face_upgrade(const Shape<T>& c, const Shape<T>& box, Hit<T>* h, T marg
 }
 
 template <typename T>
-MW_HD Shape<T> make_shape(const Env<T>& e, int g) {
-    const Model<T>& m = *e.m;
+MW_HD Shape<T> make_shape(const Env<T> e, int g) {
+    CModel<T>& m = e.model();
     Shape<T> s;
     s.type = m.geom_type[g];
-    s.pos = ld3(e, e.L.geom_xpos + 3 * g);
-    s.mat = ld9(e, e.L.geom_xmat + 9 * g);
+    s.pos = ld3(e, e.lay().geom_xpos + 3 * g);
+    s.mat = ld9(e, e.lay().geom_xmat + 9 * g);
     for (int k = 0; k < 3; k++) s.size[k] = m.geom_size[3 * g + k];
     s.margin = 0; s.vert = nullptr; s.nvert = 0;
     if (s.type == G_MESH) {
@@ -543,11 +543,11 @@ MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, H
 
 // conservative oriented-box test on the 6 face axes of the two geoms' local bounding boxes (never culls a touching pair)
 template <typename T>
-MW_HD bool obb_overlap(const Env<T>& e, int g1, int g2, T margin) {
-    const Model<T>& m = *e.m;
-    const M3<T> R1 = ld9(e, e.L.geom_xmat + 9 * g1), R2 = ld9(e, e.L.geom_xmat + 9 * g2);
+MW_HD bool obb_overlap(const Env<T> e, int g1, int g2, T margin) {
+    CModel<T>& m = e.model();
+    const M3<T> R1 = ld9(e, e.lay().geom_xmat + 9 * g1), R2 = ld9(e, e.lay().geom_xmat + 9 * g2);
     const T *a = m.geom_aabb + 6 * g1, *b = m.geom_aabb + 6 * g2;
-    const V3<T> c1 = ld3(e, e.L.geom_xpos + 3 * g1) + R1 * mv3(a), c2 = ld3(e, e.L.geom_xpos + 3 * g2) + R2 * mv3(b);
+    const V3<T> c1 = ld3(e, e.lay().geom_xpos + 3 * g1) + R1 * mv3(a), c2 = ld3(e, e.lay().geom_xpos + 3 * g2) + R2 * mv3(b);
     const V3<T> d = c2 - c1;
     T Rm[9];
     for (int i = 0; i < 3; i++)
@@ -569,9 +569,9 @@ MW_HD bool obb_overlap(const Env<T>& e, int g1, int g2, T margin) {
 }
 
 template <typename T>
-MW_STAGE_FN void collision(const Env<T>& e) {
-    const Model<T>& m = *e.m;
-    const Layout& L = e.L;
+MW_STAGE_FN void collision(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
     int ncon = 0;
     for (int p = 0; p < m.sz.npair; p++) {
         const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];

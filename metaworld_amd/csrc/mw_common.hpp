@@ -27,12 +27,36 @@
 
 namespace mw {
 
+// Address spaces and uniformity (device only).  Pointers reach the lane code as generic (flat) pointers, which cost
+// flat_load/flat_store and hide wave-uniformity from the compiler.  The column store is therefore accessed through
+// references into the GLOBAL address space (global_load/store), and the model tables -- read at wave-uniform
+// addresses, every wave being model-uniform -- through the CONSTANT address space (scalar s_load into SGPRs).
+// mw_uniform() (v_readfirstlane) tells the compiler a value is wave-uniform.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MW_GLOBAL __attribute__((address_space(1)))
+#define MW_CONST __attribute__((address_space(4)))
+__device__ inline unsigned mw_uniform(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ inline int mw_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ inline unsigned long long mw_uniform(unsigned long long v) {
+    const unsigned lo = mw_uniform((unsigned)v), hi = mw_uniform((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+#else
+#define MW_GLOBAL
+#define MW_CONST
+inline unsigned mw_uniform(unsigned x) { return x; }
+inline int mw_uniform(int x) { return x; }
+inline unsigned long long mw_uniform(unsigned long long v) { return v; }
+#endif
+template <typename T> using GRef = MW_GLOBAL T&;          // reference into the column store
+template <typename T> using CP = const MW_CONST T*;       // read-only model table
+
 enum { G_PLANE = 0, G_HFIELD, G_SPHERE, G_CAPSULE, G_ELLIPSOID, G_CYLINDER, G_BOX, G_MESH };
 enum { J_FREE = 0, J_BALL, J_SLIDE, J_HINGE };
 enum { C_EQUALITY = 0, C_LIMIT = 3, C_CONTACT = 7 };
 enum { S_SATISFIED = 0, S_QUADRATIC = 1, S_CONE = 4 };
 
-constexpr int MAX_NV = 24;       // per-lane register vectors are sized by this
+constexpr int MAX_NV = 17;       // register-resident solver arrays are sized by this (NV_LARGE in mw_phys.hpp)
 constexpr int CON_STRIDE = 26;   // reals per contact record
 constexpr int CON_ISTRIDE = 4;   // ints per contact record
 constexpr int EFC_EXTRA = 8;     // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv
@@ -41,29 +65,6 @@ constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a n
 struct Sizes {
     int nq, nv, nbody, njnt, ngeom, nsite, nmesh, nmeshvert, npair, nu, neq, nprobe, nreloc;
     int maxcon, maxefc, iterations, ls_iterations;
-};
-
-// Device-resident model tables (one per compiled MJCF scene).  Field names follow
-// metaworld_amd/mjcf.py (which follows MuJoCo's mjModel).
-template <typename T>
-struct Model {
-    Sizes sz;
-    T timestep, tolerance, meaninertia, gravity[3];
-    // ints
-    const int *body_parentid, *body_mocap, *body_jntadr, *body_jntnum, *body_lastdof, *body_relocid;
-    const int *jnt_type, *jnt_bodyid, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
-    const int *dof_bodyid, *dof_jntid, *dof_parentid;
-    const int *geom_type, *geom_bodyid, *geom_meshid, *geom_condim;
-    const int *mesh_vertadr, *mesh_vertnum, *pair_geom;
-    const int *act_dofid, *act_qposid, *eq_body1, *eq_body2, *probe_body;
-    // reals
-    const T *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia;
-    const T *jnt_pos, *jnt_axis, *jnt_range, *jnt_stiffness, *jnt_springref, *jnt_solref, *jnt_solimp, *jnt_margin;
-    const T *dof_armature, *dof_damping, *dof_invweight0, *qpos0;
-    const T *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solref, *geom_solimp, *geom_solmix;
-    const T *geom_margin, *geom_gap, *geom_rbound, *geom_invweight0, *geom_aabb;
-    const T *mesh_vert, *act_kp, *act_ctrlrange, *eq_solref, *eq_solimp, *eq_data, *eq_invweight0;
-    const T *probe_pos, *probe_quat;
 };
 
 // Offsets (in elements) of every per-environment array inside the column store.
@@ -79,6 +80,30 @@ struct Layout {
     // int columns
     int icon, iefc, icount;   // icount: ncon, nefc, niter, flags
     int nint;
+};
+
+// Device-resident model tables (one per compiled MJCF scene).  Field names follow
+// metaworld_amd/mjcf.py (which follows MuJoCo's mjModel).
+template <typename T>
+struct Model {
+    Sizes sz;
+    T timestep, tolerance, meaninertia, gravity[3];
+    // ints
+    CP<int> body_parentid, body_mocap, body_jntadr, body_jntnum, body_lastdof, body_relocid;
+    CP<int> jnt_type, jnt_bodyid, jnt_qposadr, jnt_dofadr, jnt_limited;
+    CP<int> dof_bodyid, dof_jntid, dof_parentid;
+    CP<int> geom_type, geom_bodyid, geom_meshid, geom_condim;
+    CP<int> mesh_vertadr, mesh_vertnum, pair_geom;
+    CP<int> act_dofid, act_qposid, eq_body1, eq_body2, probe_body;
+    // reals
+    CP<T> body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia;
+    CP<T> jnt_pos, jnt_axis, jnt_range, jnt_stiffness, jnt_springref, jnt_solref, jnt_solimp, jnt_margin;
+    CP<T> dof_armature, dof_damping, dof_invweight0, qpos0;
+    CP<T> geom_size, geom_pos, geom_quat, geom_friction, geom_solref, geom_solimp, geom_solmix;
+    CP<T> geom_margin, geom_gap, geom_rbound, geom_invweight0, geom_aabb;
+    CP<T> mesh_vert, act_kp, act_ctrlrange, eq_solref, eq_solimp, eq_data, eq_invweight0;
+    CP<T> probe_pos, probe_quat;
+    Layout L;        // make_layout(sz)
 };
 
 constexpr int TASK_NREAL = 96;   // per-env task/episode block, see mw_tasks.hpp
@@ -107,16 +132,20 @@ inline Layout make_layout(const Sizes& s) {
     return L;
 }
 
-// Per-lane view of one environment.
+template <typename T> using CModel = const MW_CONST Model<T>;
+using CLayout = const MW_CONST Layout;
+
+// Per-lane view of one environment (passed BY VALUE: the fields stay in registers across the non-inlined stages).
 template <typename T>
 struct Env {
     const Model<T>* m;
-    Layout L;
     T* col;        // real column store, already offset by the lane
     int* icol;     // int column store, already offset by the lane
     unsigned stride;   // 32-bit index arithmetic: nreal * stride < 2^32 (checked at group creation)
-    MW_HD T& R(int i) const { return col[(unsigned)i * stride]; }
-    MW_HD int& I(int i) const { return icol[(unsigned)i * stride]; }
+    MW_HD CModel<T>& model() const { return *(CModel<T>*)mw_uniform((unsigned long long)m); }
+    MW_HD CLayout& lay() const { return model().L; }
+    MW_HD GRef<T> R(int i) const { return ((MW_GLOBAL T*)col)[(unsigned)i * mw_uniform(stride)]; }
+    MW_HD GRef<int> I(int i) const { return ((MW_GLOBAL int*)icol)[(unsigned)i * mw_uniform(stride)]; }
 };
 
 // ----------------------------------------------------------------------------- small math
@@ -179,19 +208,26 @@ template <typename T> MW_HD V3<T> mulT(const M3<T>& a, V3<T> v) {
 template <typename T> MW_HD V3<T> col(const M3<T>& a, int k) { return {a.m[k], a.m[3 + k], a.m[6 + k]}; }
 
 // column-store load/store helpers
-template <typename T> MW_HD V3<T> ld3(const Env<T>& e, int i) { return {e.R(i), e.R(i + 1), e.R(i + 2)}; }
-template <typename T> MW_HD void st3(const Env<T>& e, int i, V3<T> v) { e.R(i) = v.x; e.R(i + 1) = v.y; e.R(i + 2) = v.z; }
-template <typename T> MW_HD Q4<T> ld4(const Env<T>& e, int i) { return {e.R(i), e.R(i + 1), e.R(i + 2), e.R(i + 3)}; }
-template <typename T> MW_HD void st4(const Env<T>& e, int i, Q4<T> q) { e.R(i) = q.w; e.R(i + 1) = q.x; e.R(i + 2) = q.y; e.R(i + 3) = q.z; }
-template <typename T> MW_HD M3<T> ld9(const Env<T>& e, int i) {
+template <typename T> MW_HD V3<T> ld3(const Env<T> e, int i) { return {e.R(i), e.R(i + 1), e.R(i + 2)}; }
+template <typename T> MW_HD void st3(const Env<T> e, int i, V3<T> v) { e.R(i) = v.x; e.R(i + 1) = v.y; e.R(i + 2) = v.z; }
+template <typename T> MW_HD Q4<T> ld4(const Env<T> e, int i) { return {e.R(i), e.R(i + 1), e.R(i + 2), e.R(i + 3)}; }
+template <typename T> MW_HD void st4(const Env<T> e, int i, Q4<T> q) { e.R(i) = q.w; e.R(i + 1) = q.x; e.R(i + 2) = q.y; e.R(i + 3) = q.z; }
+template <typename T> MW_HD M3<T> ld9(const Env<T> e, int i) {
     M3<T> r;
     for (int k = 0; k < 9; k++) r.m[k] = e.R(i + k);
     return r;
 }
-template <typename T> MW_HD void st9(const Env<T>& e, int i, const M3<T>& a) {
+template <typename T> MW_HD void st9(const Env<T> e, int i, const M3<T>& a) {
     for (int k = 0; k < 9; k++) e.R(i + k) = a.m[k];
 }
-template <typename T> MW_HD V3<T> mv3(const T* p) { return {p[0], p[1], p[2]}; }
-template <typename T> MW_HD Q4<T> mq4(const T* p) { return {p[0], p[1], p[2], p[3]}; }
+// 3-/4-vector from any pointer (model table in constant memory, local array, ...)
+template <typename T> struct elem_of;
+template <typename T> struct elem_of<const T*> { typedef T type; };
+template <typename T> struct elem_of<T*> { typedef T type; };
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T> struct elem_of<const MW_CONST T*> { typedef T type; };
+#endif
+template <typename P> MW_HD V3<typename elem_of<P>::type> mv3(P p) { return {p[0], p[1], p[2]}; }
+template <typename P> MW_HD Q4<typename elem_of<P>::type> mq4(P p) { return {p[0], p[1], p[2], p[3]}; }
 
 }  // namespace mw

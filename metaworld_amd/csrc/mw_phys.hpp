@@ -14,13 +14,13 @@
 
 namespace mw {
 
-template <typename T> MW_STAGE_FN void collision(const Env<T>& e);  // mw_collide.hpp
+template <typename T> MW_STAGE_FN void collision(const Env<T> e);  // mw_collide.hpp
 
 // ------------------------------------------------------------------ kinematics
 template <typename T>
-MW_STAGE_FN void kinematics(const Env<T>& e) {
-    const Model<T>& m = *e.m;
-    const Layout& L = e.L;
+MW_STAGE_FN void kinematics(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
     const int nb = m.sz.nbody;
     st3(e, L.xpos, v3<T>(0, 0, 0));
     st4(e, L.xquat, Q4<T>{1, 0, 0, 0});
@@ -111,15 +111,15 @@ MW_STAGE_FN void kinematics(const Env<T>& e) {
 
 // world pose of probe `p` (named body / geom / site frames the task layer reads)
 template <typename T>
-MW_HD V3<T> probe_pos(const Env<T>& e, int p) {
-    const Model<T>& m = *e.m;
+MW_HD V3<T> probe_pos(const Env<T> e, int p) {
+    CModel<T>& m = e.model();
     const int b = m.probe_body[p];
-    return ld3(e, e.L.xpos + 3 * b) + ld9(e, e.L.xmat + 9 * b) * mv3(m.probe_pos + 3 * p);
+    return ld3(e, e.lay().xpos + 3 * b) + ld9(e, e.lay().xmat + 9 * b) * mv3(m.probe_pos + 3 * p);
 }
 template <typename T>
-MW_HD Q4<T> probe_quat(const Env<T>& e, int p) {
-    const Model<T>& m = *e.m;
-    return qmul(ld4(e, e.L.xquat + 4 * m.probe_body[p]), mq4(m.probe_quat + 4 * p));
+MW_HD Q4<T> probe_quat(const Env<T> e, int p) {
+    CModel<T>& m = e.model();
+    return qmul(ld4(e, e.lay().xquat + 4 * m.probe_body[p]), mq4(m.probe_quat + 4 * p));
 }
 
 // f[6] = I10 * s[6]  (spatial inertia about origin times motion vector [w; v])
@@ -136,7 +136,7 @@ MW_HD void inertia_mul(T* f, const T* I, const T* s) {
 
 // in-place Cholesky of the lower triangle of the n x n matrix at offset A (row-major, stride n)
 template <typename T>
-MW_HD void chol_factor(const Env<T>& e, int A, int n) {
+MW_HD void chol_factor(const Env<T> e, int A, int n) {
     for (int i = 0; i < n; i++) {
         for (int j = 0; j <= i; j++) {
             T s = e.R(A + i * n + j);
@@ -147,7 +147,7 @@ MW_HD void chol_factor(const Env<T>& e, int A, int n) {
     }
 }
 template <typename T>
-MW_HD void chol_solve(const Env<T>& e, int A, int x, int n) {
+MW_HD void chol_solve(const Env<T> e, int A, int x, int n) {
     for (int i = 0; i < n; i++) {
         T s = e.R(x + i);
         for (int k = 0; k < i; k++) s -= e.R(A + i * n + k) * e.R(x + k);
@@ -160,11 +160,118 @@ MW_HD void chol_solve(const Env<T>& e, int A, int x, int n) {
     }
 }
 
+// ---- register-resident dense helpers -------------------------------------------------------------------------
+// On the GPU a read-modify-write loop over a lane's global column serialises on memory latency (every iteration is
+// a dependent round trip).  The solver's dense pieces (H assembly, Cholesky, triangular solves, J'f, M x) therefore
+// run on compile-time-sized register arrays: NV is an upper bound on nv (instantiated for 11 and 17), every loop
+// is fully unrolled, rows/columns >= nv are identity/zero padding, and the arithmetic order matches the in-memory
+// routines above so the results are bit-identical.
+constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+template <typename T, int NV>
+MW_HD void vec_load(const Env<T> e, int off, int n, T* x) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) { const T v = e.R(off + (k < n ? k : 0)); x[k] = k < n ? v : T(0); }   // branch-free
+}
+template <typename T, int NV>
+MW_HD void vec_store(const Env<T> e, int off, int n, const T* x) {
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        if (k < n) e.R(off + k) = x[k];
+}
+// lower triangle of the row-major n x n matrix at A -> packed registers, identity padded
+template <typename T, int NV>
+MW_HD void tri_load(const Env<T> e, int A, int n, T* h) {
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            const T v = e.R(A + (i < n ? i * n + j : 0));
+            h[tri(i, j)] = i < n ? v : (i == j ? T(1) : T(0));
+        }
+}
+template <typename T, int NV>
+MW_HD void tri_store(const Env<T> e, int A, int n, const T* h) {
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++)
+            if (i < n) e.R(A + i * n + j) = h[tri(i, j)];
+}
+template <typename T, int NV>
+MW_HD void chol_reg(T* h) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            T s = h[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= h[tri(i, k)] * h[tri(j, k)];
+            if (i == j) h[tri(i, i)] = mw_sqrt(s < T(1e-15) ? T(1e-15) : s);
+            else h[tri(i, j)] = s / h[tri(j, j)];
+        }
+    }
+}
+template <typename T, int NV>
+MW_HD void chol_solve_reg(const T* h, T* x) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        T s = x[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= h[tri(i, k)] * x[k];
+        x[i] = s / h[tri(i, i)];
+    }
+#pragma unroll
+    for (int i = NV - 1; i >= 0; i--) {
+        T s = x[i];
+#pragma unroll
+        for (int k = i + 1; k < NV; k++) s -= h[tri(k, i)] * x[k];
+        x[i] = s / h[tri(i, i)];
+    }
+}
+// y = M x with M the full row-major n x n matrix at A (loads only)
+template <typename T, int NV>
+MW_HD void mat_vec(const Env<T> e, int A, int n, const T* x, T* y) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) {      // x is zero beyond n; rows beyond n give unused values
+        T s = 0;
+#pragma unroll
+        for (int j = 0; j < NV; j++) s += e.R(A + ((k < n && j < n) ? k * n + j : 0)) * x[j];
+        y[k] = s;
+    }
+}
+// factor the n x n matrix at A in place / solve with the factor at A, through registers
+template <typename T, int NV>
+MW_HD void chol_factor_via_reg(const Env<T> e, int A, int n) {
+    T h[NV * (NV + 1) / 2];
+    tri_load<T, NV>(e, A, n, h);
+    chol_reg<T, NV>(h);
+    tri_store<T, NV>(e, A, n, h);
+}
+template <typename T, int NV>
+MW_HD void chol_solve_via_reg(const Env<T> e, int A, int x, int n) {
+    T h[NV * (NV + 1) / 2], v[NV];
+    tri_load<T, NV>(e, A, n, h);
+    vec_load<T, NV>(e, x, n, v);
+    chol_solve_reg<T, NV>(h, v);
+    vec_store<T, NV>(e, x, n, v);
+}
+template <typename T, int NV>
+MW_HD void chol_factor_solve_via_reg(const Env<T> e, int A, int x, int n) {   // the factor is not written back
+    T h[NV * (NV + 1) / 2], v[NV];
+    tri_load<T, NV>(e, A, n, h);
+    vec_load<T, NV>(e, x, n, v);
+    chol_reg<T, NV>(h);
+    chol_solve_reg<T, NV>(h, v);
+    vec_store<T, NV>(e, x, n, v);
+}
+constexpr int NV_SMALL = 11, NV_LARGE = 17;   // nv of the 36 models is 10, 11, 15, 16 or 17
+
 // ------------------------------------------------------------------ mass matrix
 template <typename T>
-MW_STAGE_FN void crb(const Env<T>& e) {
-    const Model<T>& m = *e.m;
-    const Layout& L = e.L;
+MW_STAGE_FN void crb(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
     const int nb = m.sz.nbody, nv = m.sz.nv;
     for (int i = 0; i < 10 * nb; i++) e.R(L.crb + i) = e.R(L.cinert + i);
     for (int b = nb - 1; b > 0; b--) {
@@ -188,7 +295,8 @@ MW_STAGE_FN void crb(const Env<T>& e) {
         }
     }
     for (int i = 0; i < nv * nv; i++) e.R(L.qL + i) = e.R(L.qM + i);
-    chol_factor(e, L.qL, nv);
+    if (nv <= NV_SMALL) chol_factor_via_reg<T, NV_SMALL>(e, L.qL, nv);
+    else chol_factor_via_reg<T, NV_LARGE>(e, L.qL, nv);
 }
 
 // ------------------------------------------------------------------ bias forces (RNE), passive, actuation
@@ -199,9 +307,9 @@ MW_HD void cross_motion(T* r, const T* v, const T* s) {
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = b.x; r[4] = b.y; r[5] = b.z;
 }
 template <typename T>
-MW_STAGE_FN void smooth_forces(const Env<T>& e) {
-    const Model<T>& m = *e.m;
-    const Layout& L = e.L;
+MW_STAGE_FN void smooth_forces(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
     const int nb = m.sz.nbody, nv = m.sz.nv;
     for (int k = 0; k < 6; k++) { e.R(L.cvel + k) = 0; e.R(L.cfrc + k) = 0; }
     e.R(L.cacc) = 0; e.R(L.cacc + 1) = 0; e.R(L.cacc + 2) = 0;
@@ -268,20 +376,33 @@ MW_STAGE_FN void smooth_forces(const Env<T>& e) {
         e.R(L.smooth + m.act_dofid[u]) += m.act_kp[u] * (c - e.R(L.qpos + m.act_qposid[u]));
     }
     for (int i = 0; i < nv; i++) e.R(L.qacc_smooth + i) = e.R(L.smooth + i);
-    chol_solve(e, L.qL, L.qacc_smooth, nv);
+    if (nv <= NV_SMALL) chol_solve_via_reg<T, NV_SMALL>(e, L.qL, L.qacc_smooth, nv);
+    else chol_solve_via_reg<T, NV_LARGE>(e, L.qL, L.qacc_smooth, nv);
 }
 
 // ------------------------------------------------------------------ constraint rows
 // efcX per row: 0 pos, 1 margin, 2 R, 3 D, 4 aref, 5 force, 6 jar, 7 Jv
-template <typename T> MW_HD T& EX(const Env<T>& e, int row, int k) { return e.R(e.L.efcX + EFC_EXTRA * row + k); }
-template <typename T> MW_HD T& EJ(const Env<T>& e, int row, int i) { return e.R(e.L.efcJ + row * e.m->sz.nv + i); }
-template <typename T> MW_HD T& CON(const Env<T>& e, int c, int k) { return e.R(e.L.con + CON_STRIDE * c + k); }
+template <typename T> MW_HD GRef<T> EX(const Env<T> e, int row, int k) { return e.R(e.lay().efcX + EFC_EXTRA * row + k); }
+template <typename T> MW_HD GRef<T> EJ(const Env<T> e, int row, int i) { return e.R(e.lay().efcJ + row * e.model().sz.nv + i); }
+template <typename T> MW_HD GRef<T> CON(const Env<T> e, int c, int k) { return e.R(e.lay().con + CON_STRIDE * c + k); }
 // contact record: 0 dist, 1-3 pos, 4-12 frame, 13 includemargin, 14-16 friction(slide,torsion,roll), 17-18 solref, 19-23 solimp, 24 mu
-template <typename T> MW_HD int& ICON(const Env<T>& e, int c, int k) { return e.I(e.L.icon + CON_ISTRIDE * c + k); }  // g1,g2,dim,efc_address
-template <typename T> MW_HD int& IEFC(const Env<T>& e, int r, int k) { return e.I(e.L.iefc + EFC_ISTRIDE * r + k); }  // type,id,state
+template <typename T> MW_HD GRef<int> ICON(const Env<T> e, int c, int k) { return e.I(e.lay().icon + CON_ISTRIDE * c + k); }  // g1,g2,dim,efc_address
+template <typename T> MW_HD GRef<int> IEFC(const Env<T> e, int r, int k) { return e.I(e.lay().iefc + EFC_ISTRIDE * r + k); }  // type,id,state
 
+// dense load of constraint row `row` of J into registers (rows are zero outside their dof range; entries >= nv
+// re-read column 0 and are never used -- no per-element branches, so the loads issue back to back)
+template <typename T, int NV>
+MW_HD void jrow_load(const Env<T> e, int row, int nv, T* j) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) j[k] = EJ(e, row, k < nv ? k : 0);
+}
+// true for the first row of a contact's cone block (rows are visited with a wave-uniform counter; the other rows
+// of a block are skipped instead of advancing the counter by a per-lane amount)
 template <typename T>
-MW_HD T impedance(const T* solimp, T x) {
+MW_HD bool cone_leader(const Env<T> e, int row, int c) { return ICON(e, c, 3) == row; }
+
+template <typename T, typename P>
+MW_HD T impedance(P solimp, T x) {
     T d0 = mw_clamp(solimp[0], T(0.0001), T(0.9999)), dw = mw_clamp(solimp[1], T(0.0001), T(0.9999));
     T width = solimp[2], mid = mw_clamp(solimp[3], T(0.0001), T(0.9999)), power = mw_max(solimp[4], T(1));
     if (width < T(1e-15) || d0 == dw) return T(0.5) * (d0 + dw);
@@ -296,9 +417,9 @@ MW_HD T impedance(const T* solimp, T x) {
 }
 
 // finish a row whose J / pos / margin are set: regulariser R, D, reference acceleration
-template <typename T>
-MW_HD void finish_row(const Env<T>& e, int row, const T* solref, const T* solimp, T diagApprox, T* Rout, T* Bout, T* Iout) {
-    const Model<T>& m = *e.m;
+template <typename T, typename P1, typename P2>
+MW_HD void finish_row(const Env<T> e, int row, P1 solref, P2 solimp, T diagApprox, T* Rout, T* Bout, T* Iout) {
+    CModel<T>& m = e.model();
     const int nv = m.sz.nv;
     T tc = solref[0], dr = solref[1];
     if (tc > 0) tc = mw_max(tc, 2 * m.timestep);
@@ -308,7 +429,7 @@ MW_HD void finish_row(const Env<T>& e, int row, const T* solref, const T* solimp
     const T imp = impedance(solimp, r);
     const T R = mw_max(T(1e-15), (1 - imp) / imp * diagApprox);
     T vel = 0;
-    for (int i = IEFC(e, row, 3); i <= IEFC(e, row, 4); i++) vel += EJ(e, row, i) * e.R(e.L.qvel + i);
+    for (int i = IEFC(e, row, 3); i <= IEFC(e, row, 4); i++) vel += EJ(e, row, i) * e.R(e.lay().qvel + i);
     (void)nv;
     EX(e, row, 2) = R; EX(e, row, 3) = 1 / R;
     EX(e, row, 4) = -B * vel - K * imp * r;
@@ -316,21 +437,21 @@ MW_HD void finish_row(const Env<T>& e, int row, const T* solref, const T* solimp
 }
 
 template <typename T>
-MW_HD void row_range(const Env<T>& e, int row, int first, int last) {
+MW_HD void row_range(const Env<T> e, int row, int first, int last) {
     if (first < IEFC(e, row, 3)) IEFC(e, row, 3) = first;
     if (last > IEFC(e, row, 4)) IEFC(e, row, 4) = last;
 }
 // J rows (translational/rotational) of a world point on body b: accumulate sign * axis . jac into row
 template <typename T>
-MW_HD void add_jac_row(const Env<T>& e, int row, int body, V3<T> point, V3<T> axis, bool rotational, T sign) {
-    const Model<T>& m = *e.m;
+MW_HD void add_jac_row(const Env<T> e, int row, int body, V3<T> point, V3<T> axis, bool rotational, T sign) {
+    CModel<T>& m = e.model();
     const int last = m.body_lastdof[body];
     int first = last;
     for (int i = last; i >= 0; i = m.dof_parentid[i]) {
-        V3<T> w = ld3(e, e.L.cdof + 6 * i);
+        V3<T> w = ld3(e, e.lay().cdof + 6 * i);
         T val;
         if (rotational) val = dot(axis, w);
-        else val = dot(axis, ld3(e, e.L.cdof + 6 * i + 3) + cross(w, point));
+        else val = dot(axis, ld3(e, e.lay().cdof + 6 * i + 3) + cross(w, point));
         EJ(e, row, i) += sign * val;
         first = i;
     }
@@ -338,10 +459,10 @@ MW_HD void add_jac_row(const Env<T>& e, int row, int body, V3<T> point, V3<T> ax
 }
 
 template <typename T>
-MW_HD int new_rows(const Env<T>& e, int n, int type, int id) {
-    const Model<T>& m = *e.m;
-    int& nefc = e.I(e.L.icount + 1);
-    if (nefc + n > m.sz.maxefc) { e.I(e.L.icount + 3) |= 1; return -1; }
+MW_HD int new_rows(const Env<T> e, int n, int type, int id) {
+    CModel<T>& m = e.model();
+    GRef<int> nefc = e.I(e.lay().icount + 1);
+    if (nefc + n > m.sz.maxefc) { e.I(e.lay().icount + 3) |= 1; return -1; }
     const int r0 = nefc;
     for (int k = 0; k < n; k++) {
         IEFC(e, r0 + k, 0) = type; IEFC(e, r0 + k, 1) = id; IEFC(e, r0 + k, 2) = 0;
@@ -354,9 +475,9 @@ MW_HD int new_rows(const Env<T>& e, int n, int type, int id) {
 }
 
 template <typename T>
-MW_STAGE_FN void make_constraints(const Env<T>& e) {
-    const Model<T>& m = *e.m;
-    const Layout& L = e.L;
+MW_STAGE_FN void make_constraints(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
     const int nv = m.sz.nv;
     e.I(L.icount + 1) = 0;
     // ---- weld(mocap, hand): 3 translational + 3 rotational rows ----
@@ -456,17 +577,21 @@ MW_STAGE_FN void make_constraints(const Env<T>& e) {
 template <typename T>
 struct ConeEval { T mu, fri[4], U[4], N, Tn; int dim, zone; };   // zone: 0 top, 1 bottom(quadratic), 2 middle
 template <typename T>
-MW_HD ConeEval<T> cone_eval(const Env<T>& e, int r0, int c, T alpha) {
+MW_HD ConeEval<T> cone_eval(const Env<T> e, int r0, int c, T alpha) {
+    // fixed 4-row form (rows >= dim are masked and re-read row r0): all indices are compile-time, so U / fri stay
+    // in registers instead of a dynamically indexed private array
     ConeEval<T> z;
     z.dim = ICON(e, c, 2);
     z.mu = CON(e, c, 24);
-    z.fri[0] = z.mu;
     const T f0 = CON(e, c, 14), f1 = CON(e, c, 15);
     T tt = 0;
-    for (int k = 0; k < z.dim; k++) {
-        if (k > 0) z.fri[k] = k < 3 ? f0 : f1;
-        const T x = EX(e, r0 + k, 6) + alpha * EX(e, r0 + k, 7);
-        z.U[k] = x * z.fri[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool on = k < z.dim;
+        const int r = on ? r0 + k : r0;
+        z.fri[k] = k == 0 ? z.mu : (k < 3 ? f0 : f1);
+        const T x = EX(e, r, 6) + alpha * EX(e, r, 7);
+        z.U[k] = on ? x * z.fri[k] : T(0);
         if (k > 0) tt += z.U[k] * z.U[k];
     }
     z.N = z.U[0];
@@ -478,10 +603,10 @@ MW_HD ConeEval<T> cone_eval(const Env<T>& e, int r0, int c, T alpha) {
 }
 
 // cost, forces, states at the current jar; qfrc_constraint = J' force; returns total cost incl. Gauss term
-template <typename T>
-MW_HD T update_constraint(const Env<T>& e) {
-    const Model<T>& m = *e.m;
-    const Layout& L = e.L;
+template <typename T, int NV>
+MW_STAGE_FN T update_constraint(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
     const int nv = m.sz.nv, nefc = e.I(L.icount + 1);
     T cost = 0;
     for (int i = 0; i < nefc; i++) {
@@ -493,39 +618,49 @@ MW_HD T update_constraint(const Env<T>& e) {
             EX(e, i, 5) = 0; IEFC(e, i, 2) = S_SATISFIED;
         } else {
             const int c = IEFC(e, i, 1);
+            if (!cone_leader(e, i, c)) continue;
             ConeEval<T> z = cone_eval(e, i, c, T(0));
             int st;
+            T f[4] = {0, 0, 0, 0};
             if (z.zone == 0) {
                 st = S_SATISFIED;
-                for (int k = 0; k < z.dim; k++) EX(e, i + k, 5) = 0;
             } else if (z.zone == 1) {
                 st = S_QUADRATIC;
-                for (int k = 0; k < z.dim; k++) {
-                    const T Dk = EX(e, i + k, 3), x = EX(e, i + k, 6);
-                    EX(e, i + k, 5) = -Dk * x; cost += T(0.5) * Dk * x * x;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int r = k < z.dim ? i + k : i;
+                    const T Dk = EX(e, r, 3), x = EX(e, r, 6);
+                    if (k < z.dim) { f[k] = -Dk * x; cost += T(0.5) * Dk * x * x; }
                 }
             } else {
                 st = S_CONE;
                 const T Dm = D / (z.mu * z.mu * (1 + z.mu * z.mu)), NmT = z.N - z.mu * z.Tn;
                 cost += T(0.5) * Dm * NmT * NmT;
                 const T f0 = -Dm * NmT * z.mu;
-                EX(e, i, 5) = f0;
-                for (int k = 1; k < z.dim; k++) EX(e, i + k, 5) = -f0 / z.Tn * z.U[k] * z.fri[k];
+                f[0] = f0;
+#pragma unroll
+                for (int k = 1; k < 4; k++) f[k] = -f0 / z.Tn * z.U[k] * z.fri[k];
             }
-            for (int k = 0; k < z.dim; k++) IEFC(e, i + k, 2) = st;
-            i += z.dim - 1;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < z.dim) { EX(e, i + k, 5) = f[k]; IEFC(e, i + k, 2) = st; }
         }
     }
     T gauss = 0;
-    for (int k = 0; k < nv; k++) {
-        e.R(L.qfrc_c + k) = 0;
+    for (int k = 0; k < nv; k++)
         gauss += (e.R(L.Ma + k) - e.R(L.smooth + k)) * (e.R(L.qacc + k) - e.R(L.qacc_smooth + k));
-    }
-    for (int i = 0; i < nefc; i++) {      // J' f over the active rows and their non-zero dof range only
+    T qf[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) qf[k] = 0;
+    for (int i = 0; i < nefc; i++) {      // J' f over the active rows, accumulated in registers
         const T f = EX(e, i, 5);
         if (f == 0) continue;
-        for (int k = IEFC(e, i, 3); k <= IEFC(e, i, 4); k++) e.R(L.qfrc_c + k) += EJ(e, i, k) * f;
+        T j[NV];
+        jrow_load<T, NV>(e, i, nv, j);
+#pragma unroll
+        for (int k = 0; k < NV; k++) qf[k] += j[k] * f;
     }
+    vec_store<T, NV>(e, L.qfrc_c, nv, qf);
     return cost + T(0.5) * gauss;
 }
 
@@ -533,158 +668,188 @@ MW_HD T update_constraint(const Env<T>& e) {
 #if defined(MW_PROFILE) && !defined(__HIPCC__)
 inline long* mw_cnt() { static long c[8] = {0}; return c; }
 #define MW_COUNT(i) mw_cnt()[i]++;
+inline long* mw_hist() { static long h[2 * 64] = {0}; return h; }
+#define MW_HIST(w, v) mw_hist()[(w) * 64 + ((v) < 63 ? (v) : 63)]++;
 #else
 #define MW_COUNT(i)
+#define MW_HIST(w, v)
 #endif
 template <typename T>
-MW_HD void line_eval(const Env<T>& e, T alpha, const T* quadGauss, T* cost, T* d1, T* d2) {
+MW_HD void line_eval(const Env<T> e, T alpha, const T* quadGauss, T* cost, T* d1, T* d2, T* mag = nullptr) {
+    // *mag: sum of the magnitudes that cancel inside d1 (rounding-noise scale of the derivative, fp32 termination)
     MW_COUNT(0)
-    const int nefc = e.I(e.L.icount + 1);
+    const int nefc = e.I(e.lay().icount + 1);
     T C = alpha * alpha * quadGauss[2] + alpha * quadGauss[1] + quadGauss[0];
     T D1 = 2 * alpha * quadGauss[2] + quadGauss[1], D2 = 2 * quadGauss[2];
+    T A1 = mw_abs(2 * alpha * quadGauss[2]) + mw_abs(quadGauss[1]);
     for (int i = 0; i < nefc; i++) {
         const int type = IEFC(e, i, 0);
-        const T D = EX(e, i, 3), jv = EX(e, i, 7), x = EX(e, i, 6) + alpha * jv;
+        const T D = EX(e, i, 3), jv = EX(e, i, 7), x0 = EX(e, i, 6), x = x0 + alpha * jv;
         if (type == C_EQUALITY || (type == C_LIMIT && x < 0)) {
             C += T(0.5) * D * x * x; D1 += D * x * jv; D2 += D * jv * jv;
+            A1 += D * (mw_abs(x0) + mw_abs(alpha * jv)) * mw_abs(jv);
         } else if (type == C_CONTACT) {
             const int c = IEFC(e, i, 1);
+            if (!cone_leader(e, i, c)) continue;
             ConeEval<T> z = cone_eval(e, i, c, alpha);
             if (z.zone == 1) {
-                for (int k = 0; k < z.dim; k++) {
-                    const T Dk = EX(e, i + k, 3), jk = EX(e, i + k, 7), xk = EX(e, i + k, 6) + alpha * jk;
-                    C += T(0.5) * Dk * xk * xk; D1 += Dk * xk * jk; D2 += Dk * jk * jk;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int r = k < z.dim ? i + k : i;
+                    const T Dk = EX(e, r, 3), jk = EX(e, r, 7), xk = EX(e, r, 6) + alpha * jk;
+                    if (k < z.dim) { C += T(0.5) * Dk * xk * xk; D1 += Dk * xk * jk; D2 += Dk * jk * jk; A1 += Dk * mw_abs(xk * jk); }
                 }
             } else if (z.zone == 2) {
                 T UV = 0, VV = 0;
-                for (int k = 1; k < z.dim; k++) {
-                    const T v = EX(e, i + k, 7) * z.fri[k];
+#pragma unroll
+                for (int k = 1; k < 4; k++) {
+                    const T jk = EX(e, k < z.dim ? i + k : i, 7);
+                    const T v = k < z.dim ? jk * z.fri[k] : T(0);
                     UV += z.U[k] * v; VV += v * v;
                 }
                 const T Dm = D / (z.mu * z.mu * (1 + z.mu * z.mu));
                 const T N1 = EX(e, i, 7) * z.mu, T1 = UV / z.Tn, T2 = VV / z.Tn - UV * T1 / (z.Tn * z.Tn);
                 const T NmT = z.N - z.mu * z.Tn, g = N1 - z.mu * T1;
                 C += T(0.5) * Dm * NmT * NmT; D1 += Dm * NmT * g; D2 += Dm * (g * g - NmT * z.mu * T2);
+                A1 += Dm * (mw_abs(z.N) + z.mu * z.Tn) * (mw_abs(N1) + z.mu * mw_abs(T1));
             }
-            i += z.dim - 1;
         }
     }
     *cost = C; *d1 = D1; *d2 = D2;
+    if (mag) *mag = A1;
 }
 
-template <typename T>
-MW_STAGE_FN void solve(const Env<T>& e) {
-    const Model<T>& m = *e.m;
-    const Layout& L = e.L;
+template <typename T, int NV>
+MW_HD void solve_impl(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
     const int nv = m.sz.nv, nefc = e.I(L.icount + 1);
-    e.I(L.icount + 2) = 0;
-    if (nefc == 0) {
-        for (int k = 0; k < nv; k++) { e.R(L.qacc + k) = e.R(L.qacc_smooth + k); e.R(L.qfrc_c + k) = 0; }
-        return;
-    }
+    constexpr int NT = NV * (NV + 1) / 2;
     auto set_point = [&](int src) {   // qacc <- src ; Ma, jar
-        for (int k = 0; k < nv; k++) e.R(L.qacc + k) = e.R(src + k);
-        for (int k = 0; k < nv; k++) {
-            T s = 0;
-            for (int j = 0; j < nv; j++) s += e.R(L.qM + k * nv + j) * e.R(L.qacc + j);
-            e.R(L.Ma + k) = s;
-        }
+        T x[NV], y[NV];
+        vec_load<T, NV>(e, src, nv, x);
+        mat_vec<T, NV>(e, L.qM, nv, x, y);
+        vec_store<T, NV>(e, L.qacc, nv, x);
+        vec_store<T, NV>(e, L.Ma, nv, y);
         for (int i = 0; i < nefc; i++) {
-            T s = -EX(e, i, 4);
-            for (int j = IEFC(e, i, 3); j <= IEFC(e, i, 4); j++) s += EJ(e, i, j) * e.R(L.qacc + j);
+            T j[NV], s = -EX(e, i, 4);
+            jrow_load<T, NV>(e, i, nv, j);
+#pragma unroll
+            for (int k = 0; k < NV; k++) s += j[k] * x[k];
             EX(e, i, 6) = s;
         }
     };
-    // warm start: the better of qacc_warmstart and qacc_smooth
+    // warm start: the better of qacc_warmstart and qacc_smooth (ties go to the warm start)
+    set_point(L.qacc_smooth);
+    const T cs = update_constraint<T, NV>(e);
     set_point(L.warm);
-    T cost = update_constraint(e);
-    {
-        set_point(L.qacc_smooth);
-        const T cs = update_constraint(e);
-        if (cost > cs) cost = cs;
-        else { set_point(L.warm); cost = update_constraint(e); }
-    }
+    T cost = update_constraint<T, NV>(e);
+    if (cost > cs) { set_point(L.qacc_smooth); cost = update_constraint<T, NV>(e); }
     const T scale = 1 / (m.meaninertia * T(nv > 1 ? nv : 1));
     MW_COUNT(2)
     for (int iter = 0; iter < m.sz.iterations; iter++) {
         MW_COUNT(1)
-        T gn = 0;
-        for (int k = 0; k < nv; k++) {
-            const T g = e.R(L.Ma + k) - e.R(L.smooth + k) - e.R(L.qfrc_c + k);
-            e.R(L.grad + k) = g; gn += g * g;
-        }
-        if (scale * mw_sqrt(gn) < m.tolerance) break;
-        // H = M + J' D J over quadratic rows (+ dense cone blocks), lower triangle, then Cholesky in place
-        for (int a = 0; a < nv; a++)
-            for (int b = 0; b <= a; b++) e.R(L.qH + a * nv + b) = e.R(L.qM + a * nv + b);
-        for (int i = 0; i < nefc; i++) {
-            const int st = IEFC(e, i, 2);
-            if (st == S_QUADRATIC) {
-                const T D = EX(e, i, 3);
-                const int lo = IEFC(e, i, 3), hi = IEFC(e, i, 4);
-                for (int a = lo; a <= hi; a++) {
-                    const T ja = EJ(e, i, a);
-                    if (ja == 0) continue;
-                    const T Da = D * ja;
-                    for (int b = lo; b <= a; b++) e.R(L.qH + a * nv + b) += Da * EJ(e, i, b);
-                }
-            } else if (st == S_CONE) {
-                const int c = IEFC(e, i, 1);
-                ConeEval<T> z = cone_eval(e, i, c, T(0));
-                const T Dm = EX(e, i, 3) / (z.mu * z.mu * (1 + z.mu * z.mu));
-                T Hc[16];
-                const T scl = z.mu * z.N / (z.Tn * z.Tn * z.Tn), dg = z.mu * z.mu - z.mu * z.N / z.Tn;
-                for (int r = 0; r < z.dim; r++)
-                    for (int s = 0; s < z.dim; s++) {
-                        T h;
-                        if (r == 0 && s == 0) h = 1;
-                        else if (r == 0) h = -z.mu * z.U[s] / z.Tn;
-                        else if (s == 0) h = -z.mu * z.U[r] / z.Tn;
-                        else h = scl * z.U[r] * z.U[s] + (r == s ? dg : T(0));
-                        Hc[4 * r + s] = h * Dm * z.fri[r] * z.fri[s];
-                    }
-                int lo = nv, hi = -1;
-                for (int r = 0; r < z.dim; r++) { lo = IEFC(e, i + r, 3) < lo ? IEFC(e, i + r, 3) : lo; hi = IEFC(e, i + r, 4) > hi ? IEFC(e, i + r, 4) : hi; }
-                for (int a = lo; a <= hi; a++) {
-                    T ja[4], t[4];
-                    bool any = false;
-                    for (int r = 0; r < z.dim; r++) { ja[r] = EJ(e, i + r, a); any |= ja[r] != 0; }
-                    if (!any) continue;
-                    for (int s = 0; s < z.dim; s++) {
-                        t[s] = 0;
-                        for (int r = 0; r < z.dim; r++) t[s] += ja[r] * Hc[4 * r + s];
-                    }
-                    for (int b = lo; b <= a; b++) {
-                        T acc = 0;
-                        for (int s = 0; s < z.dim; s++) acc += t[s] * EJ(e, i + s, b);
-                        e.R(L.qH + a * nv + b) += acc;
-                    }
-                }
-                i += z.dim - 1;
-            } else if (IEFC(e, i, 0) == C_CONTACT) {
-                i += ICON(e, IEFC(e, i, 1), 2) - 1;
+        T gn = 0, sr[NV];             // sr: gradient, then the search direction
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            sr[k] = 0;
+            if (k < nv) {
+                const T g = e.R(L.Ma + k) - e.R(L.smooth + k) - e.R(L.qfrc_c + k);
+                sr[k] = -g; gn += g * g;
             }
         }
-        chol_factor(e, L.qH, nv);
-        for (int k = 0; k < nv; k++) e.R(L.search + k) = -e.R(L.grad + k);
-        chol_solve(e, L.qH, L.search, nv);
+        if (scale * mw_sqrt(gn) < m.tolerance) break;
+        {
+            // H = M + J' D J over quadratic rows (+ dense cone blocks): lower triangle in registers, Cholesky, solve
+            T H[NT];
+            tri_load<T, NV>(e, L.qM, nv, H);
+            for (int i = 0; i < nefc; i++) {
+                const int st = IEFC(e, i, 2);
+                if (st == S_QUADRATIC) {
+                    const T D = EX(e, i, 3);
+                    T j[NV];
+                    jrow_load<T, NV>(e, i, nv, j);
+#pragma unroll
+                    for (int a = 0; a < NV; a++) j[a] = a < nv ? j[a] : T(0);
+#pragma unroll
+                    for (int a = 0; a < NV; a++) {
+                        const T Da = D * j[a];
+#pragma unroll
+                        for (int b = 0; b <= a; b++) H[tri(a, b)] += Da * j[b];
+                    }
+                } else if (st == S_CONE) {
+                    const int c = IEFC(e, i, 1);
+                    if (!cone_leader(e, i, c)) continue;
+                    ConeEval<T> z = cone_eval(e, i, c, T(0));
+                    const T Dm = EX(e, i, 3) / (z.mu * z.mu * (1 + z.mu * z.mu));
+                    T Hc[16];
+                    const T scl = z.mu * z.N / (z.Tn * z.Tn * z.Tn), dg = z.mu * z.mu - z.mu * z.N / z.Tn;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int s = 0; s < 4; s++) {
+                            T h;
+                            if (r == 0 && s == 0) h = 1;
+                            else if (r == 0) h = -z.mu * z.U[s] / z.Tn;
+                            else if (s == 0) h = -z.mu * z.U[r] / z.Tn;
+                            else h = scl * z.U[r] * z.U[s] + (r == s ? dg : T(0));
+                            Hc[4 * r + s] = (r < z.dim && s < z.dim) ? h * Dm * z.fri[r] * z.fri[s] : T(0);
+                        }
+                    T j[4][NV];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const bool on = r < z.dim;
+                        jrow_load<T, NV>(e, on ? i + r : i, nv, j[r]);
+#pragma unroll
+                        for (int a = 0; a < NV; a++) j[r][a] = (on && a < nv) ? j[r][a] : T(0);
+                    }
+#pragma unroll
+                    for (int a = 0; a < NV; a++) {
+                        T t[4];
+#pragma unroll
+                        for (int s = 0; s < 4; s++) {
+                            t[s] = 0;
+#pragma unroll
+                            for (int r = 0; r < 4; r++) t[s] += j[r][a] * Hc[4 * r + s];
+                        }
+#pragma unroll
+                        for (int b = 0; b <= a; b++) {
+                            T acc = 0;
+#pragma unroll
+                            for (int s = 0; s < 4; s++) acc += t[s] * j[s][b];
+                            H[tri(a, b)] += acc;
+                        }
+                    }
+                }
+            }
+            chol_reg<T, NV>(H);
+            chol_solve_reg<T, NV>(H, sr);
+        }
         // ---- exact line search (safeguarded Newton on the 1-D convex cost) ----
         T snorm = 0, quadGauss[3] = {0, 0, 0};
-        for (int k = 0; k < nv; k++) {
-            T s = 0;
-            for (int j = 0; j < nv; j++) s += e.R(L.qM + k * nv + j) * e.R(L.search + j);
-            e.R(L.Mv + k) = s;
-            const T sk = e.R(L.search + k);
-            snorm += sk * sk;
-            quadGauss[1] += sk * (e.R(L.Ma + k) - e.R(L.smooth + k));
-            quadGauss[2] += T(0.5) * sk * s;
-            quadGauss[0] += T(0.5) * (e.R(L.Ma + k) - e.R(L.smooth + k)) * (e.R(L.qacc + k) - e.R(L.qacc_smooth + k));
+        {
+            T Mv[NV];
+            mat_vec<T, NV>(e, L.qM, nv, sr, Mv);
+            vec_store<T, NV>(e, L.search, nv, sr);
+            vec_store<T, NV>(e, L.Mv, nv, Mv);
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                if (k < nv) {
+                    const T sk = sr[k], r = e.R(L.Ma + k) - e.R(L.smooth + k);
+                    snorm += sk * sk;
+                    quadGauss[1] += sk * r;
+                    quadGauss[2] += T(0.5) * sk * Mv[k];
+                    quadGauss[0] += T(0.5) * r * (e.R(L.qacc + k) - e.R(L.qacc_smooth + k));
+                }
+            }
         }
         snorm = mw_sqrt(snorm);
         if (snorm < T(1e-15)) break;
         for (int i = 0; i < nefc; i++) {
-            T s = 0;
-            for (int j = IEFC(e, i, 3); j <= IEFC(e, i, 4); j++) s += EJ(e, i, j) * e.R(L.search + j);
+            T j[NV], s = 0;
+            jrow_load<T, NV>(e, i, nv, j);
+#pragma unroll
+            for (int k = 0; k < NV; k++) s += j[k] * sr[k];
             EX(e, i, 7) = s;
         }
         const T gtol = m.tolerance * T(0.01) * snorm / scale;
@@ -692,25 +857,51 @@ MW_STAGE_FN void solve(const Env<T>& e) {
         line_eval(e, T(0), quadGauss, &c0, &d1, &d2);
         if (d1 >= 0 || d2 <= 0) break;
         T lo = 0, hi = -1, alpha = -d1 / d2;
+        int nls = 0;
         for (int it = 0; it < m.sz.ls_iterations; it++) {
-            T ca, da, dda;
-            line_eval(e, alpha, quadGauss, &ca, &da, &dda);
+            T ca, da, dda, mag;
+            nls++;
+            line_eval(e, alpha, quadGauss, &ca, &da, &dda, &mag);
             if (mw_abs(da) < gtol) break;
+            // single precision: the derivative cannot be resolved below its own rounding noise (a few ulp of the
+            // magnitudes that cancel inside it); without this test ~10 % of the searches ran to ls_iterations and,
+            // 64 lanes to a wave, so did every wave
+            if (sizeof(T) == 4 && mw_abs(da) <= T(1e-6) * mag) break;
             if (da < 0) lo = alpha; else hi = alpha;
             T an = alpha - da / dda;
             if (hi < 0) { if (an <= lo) an = 2 * alpha; }
             else if (!(an > lo && an < hi)) an = T(0.5) * (lo + hi);
-            if (hi > 0 && (hi - lo) <= T(1e-7) * hi * (sizeof(T) == 8 ? T(1e-9) : T(1))) { alpha = T(0.5) * (lo + hi); break; }
+            if (hi > 0 && (hi - lo) <= (sizeof(T) == 8 ? T(1e-16) : T(5e-7)) * hi) { alpha = T(0.5) * (lo + hi); break; }
+            if (an == alpha) break;
             alpha = an;
         }
+        MW_HIST(1, nls)
+        (void)nls;
         if (alpha == 0) break;
-        for (int k = 0; k < nv; k++) { e.R(L.qacc + k) += alpha * e.R(L.search + k); e.R(L.Ma + k) += alpha * e.R(L.Mv + k); }
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            if (k < nv) { e.R(L.qacc + k) += alpha * sr[k]; e.R(L.Ma + k) += alpha * e.R(L.Mv + k); }
         for (int i = 0; i < nefc; i++) EX(e, i, 6) += alpha * EX(e, i, 7);
         const T old = cost;
-        cost = update_constraint(e);
+        cost = update_constraint<T, NV>(e);
         e.I(L.icount + 2) = iter + 1;
         if (scale * (old - cost) < m.tolerance) break;
     }
+    MW_HIST(0, e.I(L.icount + 2))
+}
+
+template <typename T>
+MW_STAGE_FN void solve(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
+    const int nv = m.sz.nv;
+    e.I(L.icount + 2) = 0;
+    if (e.I(L.icount + 1) == 0) {
+        for (int k = 0; k < nv; k++) { e.R(L.qacc + k) = e.R(L.qacc_smooth + k); e.R(L.qfrc_c + k) = 0; }
+        return;
+    }
+    if (nv <= NV_SMALL) solve_impl<T, NV_SMALL>(e);
+    else solve_impl<T, NV_LARGE>(e);
 }
 
 // ------------------------------------------------------------------ pipeline
@@ -722,7 +913,7 @@ inline double* mw_prof() { static double t[8] = {0}; return t; }
 #define MW_STAGE(i, call) call;
 #endif
 template <typename T>
-MW_HD void forward(const Env<T>& e) {
+MW_STAGE_FN void forward(const Env<T> e) {
     MW_STAGE(0, kinematics(e))
     MW_STAGE(1, crb(e))
     MW_STAGE(2, collision(e))
@@ -732,9 +923,9 @@ MW_HD void forward(const Env<T>& e) {
 }
 
 template <typename T>
-MW_HD void substep(const Env<T>& e) {
-    const Model<T>& m = *e.m;
-    const Layout& L = e.L;
+MW_STAGE_FN void substep(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
     const int nv = m.sz.nv;
     const T h = m.timestep;
     forward(e);
@@ -745,8 +936,8 @@ MW_HD void substep(const Env<T>& e) {
         e.R(L.qH + a * nv + a) += h * m.dof_damping[a];
         e.R(L.search + a) = e.R(L.smooth + a) + e.R(L.qfrc_c + a);
     }
-    chol_factor(e, L.qH, nv);
-    chol_solve(e, L.qH, L.search, nv);
+    if (nv <= NV_SMALL) chol_factor_solve_via_reg<T, NV_SMALL>(e, L.qH, L.search, nv);
+    else chol_factor_solve_via_reg<T, NV_LARGE>(e, L.qH, L.search, nv);
     for (int k = 0; k < nv; k++) e.R(L.qvel + k) += h * e.R(L.search + k);
     for (int j = 0; j < m.sz.njnt; j++) {
         const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
@@ -768,9 +959,9 @@ MW_HD void substep(const Env<T>& e) {
 
 // mj_resetData
 template <typename T>
-MW_HD void reset_data(const Env<T>& e) {
-    const Model<T>& m = *e.m;
-    const Layout& L = e.L;
+MW_HD void reset_data(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
     for (int i = 0; i < m.sz.nq; i++) e.R(L.qpos + i) = m.qpos0[i];
     for (int i = 0; i < m.sz.nv; i++) { e.R(L.qvel + i) = 0; e.R(L.warm + i) = 0; }
     for (int i = 0; i < m.sz.nu; i++) e.R(L.ctrl + i) = 0;

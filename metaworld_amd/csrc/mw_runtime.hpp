@@ -8,6 +8,7 @@
 //   template <class F> static void launch(int nblocks, F lane_program);   // F(block, thread) for 64 threads / block
 //   static void sync();
 #pragma once
+#include <string.h>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -56,8 +57,8 @@ struct DeviceModel {
     int* iblob = nullptr;
     T* rblob = nullptr;
     explicit DeviceModel(const ModelData& d) {
-        struct IF { const char* name; const int* Model<T>::*p; };
-        struct RF { const char* name; const T* Model<T>::*p; };
+        struct IF { const char* name; CP<int> Model<T>::*p; };
+        struct RF { const char* name; CP<T> Model<T>::*p; };
         const IF ifs[] = {{"body_parentid", &Model<T>::body_parentid}, {"body_mocap", &Model<T>::body_mocap},
             {"body_jntadr", &Model<T>::body_jntadr}, {"body_jntnum", &Model<T>::body_jntnum}, {"body_lastdof", &Model<T>::body_lastdof},
             {"body_relocid", &Model<T>::body_relocid}, {"jnt_type", &Model<T>::jnt_type}, {"jnt_bodyid", &Model<T>::jnt_bodyid},
@@ -90,10 +91,11 @@ struct DeviceModel {
         Backend::h2d(iblob, ib.data(), ib.size() * sizeof(int));
         Backend::h2d(rblob, rb.data(), rb.size() * sizeof(T));
         size_t k = 0;
-        for (auto& f : ifs) m.*(f.p) = iblob + ioff[k++];
+        for (auto& f : ifs) { const int* q = iblob + ioff[k++]; ::memcpy(&(m.*(f.p)), &q, sizeof(q)); }
         k = 0;
-        for (auto& f : rfs) m.*(f.p) = rblob + roff[k++];
+        for (auto& f : rfs) { const T* q = rblob + roff[k++]; ::memcpy(&(m.*(f.p)), &q, sizeof(q)); }
         m.sz = d.sz;
+        m.L = make_layout(d.sz);
         m.timestep = (T)d.timestep; m.tolerance = (T)d.tolerance; m.meaninertia = (T)d.meaninertia;
         for (int c = 0; c < 3; c++) m.gravity[c] = (T)d.gravity[c];
     }
@@ -145,7 +147,7 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Env<T>* e, int* gid)
     const GroupDev<T>& G = w.groups[g];
     const int lane = (block - G.block0) * BLOCK + thread;
     if (lane >= G.nenv) return false;
-    e->m = &G.m; e->L = G.L; e->col = G.col + lane; e->icol = G.icol + lane; e->stride = (unsigned)G.stride;
+    e->m = &G.m; e->col = G.col + lane; e->icol = G.icol + lane; e->stride = (unsigned)G.stride;
     *gid = G.gid[lane];
     return true;
 }
@@ -158,9 +160,9 @@ MW_HD void write_obs(const World<T>& w, const TaskDesc<T>& td, double* dst, cons
 }
 
 template <typename T>
-MW_HD void load_snapshot(const World<T>& w, const Env<T>& e, int task, int goal, T* obs39) {
+MW_HD void load_snapshot(const World<T>& w, const Env<T> e, int task, int goal, T* obs39) {
     const T* s = w.snap + w.snap_off[task] + (long long)goal * w.snap_stride[task];
-    const int ns = e.L.nstate;
+    const int ns = e.lay().nstate;
     const V3<T> persist = tk3(e, TK_PERSIST0);
     for (int k = 0; k < ns; k++) e.R(k) = s[k];
     for (int k = 0; k < 39; k++) obs39[k] = s[ns + k];

@@ -98,18 +98,18 @@ MW_HD void scipy_quat(const M3<T>& R, T* q) {
     for (int c = 0; c < 4; c++) q[c] /= n;
 }
 
-template <typename T> MW_HD T& TK(const Env<T>& e, int k) { return e.R(e.L.task + k); }
-template <typename T> MW_HD V3<T> tk3(const Env<T>& e, int k) { return ld3(e, e.L.task + k); }
-template <typename T> MW_HD void set_tk3(const Env<T>& e, int k, V3<T> v) { st3(e, e.L.task + k, v); }
+template <typename T> MW_HD GRef<T> TK(const Env<T> e, int k) { return e.R(e.lay().task + k); }
+template <typename T> MW_HD V3<T> tk3(const Env<T> e, int k) { return ld3(e, e.lay().task + k); }
+template <typename T> MW_HD void set_tk3(const Env<T> e, int k, V3<T> v) { st3(e, e.lay().task + k, v); }
 
 template <typename T>
-MW_HD V3<T> tcp_center(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD V3<T> tcp_center(const Env<T> e, const TaskDesc<T>& td) {
     return (probe_pos(e, td.probe[P_RTCP]) + probe_pos(e, td.probe[P_LTCP])) * T(0.5);
 }
 
 // _get_curr_obs_combined_no_goal (sawyer_xyz_env.py:475-511)
 template <typename T>
-MW_HD void curr_obs(const Env<T>& e, const TaskDesc<T>& td, T* o18) {
+MW_HD void curr_obs(const Env<T> e, const TaskDesc<T>& td, T* o18) {
     const V3<T> hand = probe_pos(e, td.probe[P_HAND]);
     o18[0] = hand.x; o18[1] = hand.y; o18[2] = hand.z;
     const T gd = norm(probe_pos(e, td.probe[P_RCLAW]) - probe_pos(e, td.probe[P_LCLAW]));
@@ -119,7 +119,7 @@ MW_HD void curr_obs(const Env<T>& e, const TaskDesc<T>& td, T* o18) {
         T* o = o18 + 4 + 7 * i;
         V3<T> p = probe_pos(e, td.probe[P_OBJ0 + 2 * i]);
         if (td.kind == 11) {   // dial-turn: dial centre + 0.05 * [sin q, -cos q, 0]  (envs/sawyer_dial_turn_v3.py:87-98)
-            const T q = e.R(e.L.qpos + td.qadr[0]);
+            const T q = e.R(e.lay().qpos + td.qadr[0]);
             p = p + v3<T>(T(0.05) * sin(q), T(-0.05) * cos(q), 0);
         }
         o[0] = p.x + td.obj_off[i][0]; o[1] = p.y + td.obj_off[i][1]; o[2] = p.z + td.obj_off[i][2];
@@ -133,7 +133,7 @@ MW_HD void curr_obs(const Env<T>& e, const TaskDesc<T>& td, T* o18) {
 
 // _get_obs (:513-527): [curr18, prev18, goal3]; updates _prev_obs
 template <typename T>
-MW_HD void get_obs(const Env<T>& e, const TaskDesc<T>& td, T* obs39) {
+MW_HD void get_obs(const Env<T> e, const TaskDesc<T>& td, T* obs39) {
     curr_obs(e, td, obs39);
     for (int k = 0; k < 18; k++) { obs39[18 + k] = TK(e, TK_PREVOBS + k); TK(e, TK_PREVOBS + k) = obs39[k]; }
     for (int k = 0; k < 3; k++) obs39[36 + k] = td.partially_observable ? T(0) : TK(e, TK_TARGET + k);
@@ -153,10 +153,10 @@ MW_HD void clip_obs(const TaskDesc<T>& td, T* o) {
 
 // _reset_hand (:684-695): 50 x { mocap <- hand_init_pos ; do_simulation([-1, 1], 5) }; init_tcp from the lagged FK
 template <typename T>
-MW_HD void reset_hand(const Env<T>& e, const TaskDesc<T>& td, int steps = 50) {
+MW_HD void reset_hand(const Env<T> e, const TaskDesc<T>& td, int steps = 50) {
     for (int s = 0; s < steps; s++) {
-        st3(e, e.L.mocap, v3(td.hand_init[0], td.hand_init[1], td.hand_init[2]));
-        e.R(e.L.ctrl) = -1; e.R(e.L.ctrl + 1) = 1;
+        st3(e, e.lay().mocap, v3(td.hand_init[0], td.hand_init[1], td.hand_init[2]));
+        e.R(e.lay().ctrl) = -1; e.R(e.lay().ctrl + 1) = 1;
         for (int k = 0; k < 5; k++) substep(e);
     }
     set_tk3(e, TK_INITTCP, tcp_center(e, td));
@@ -164,9 +164,9 @@ MW_HD void reset_hand(const Env<T>& e, const TaskDesc<T>& td, int steps = 50) {
 
 // default _set_obj_xyz (:351-361): qpos[9:12] <- pos ; qvel[9:15] <- 0 ; set_state -> mj_forward
 template <typename T>
-MW_HD void set_obj_xyz(const Env<T>& e, V3<T> p) {
-    st3(e, e.L.qpos + 9, p);
-    for (int k = 9; k < 15; k++) e.R(e.L.qvel + k) = 0;
+MW_HD void set_obj_xyz(const Env<T> e, V3<T> p) {
+    st3(e, e.lay().qpos + 9, p);
+    for (int k = 9; k < 15; k++) e.R(e.lay().qvel + k) = 0;
     forward(e);
 }
 
@@ -184,8 +184,8 @@ enum { G_OBJ = 0, G_LPAD = 1, G_RPAD = 2 };
 // touching_object (sawyer_xyz_env.py:401-440): both pads have positive summed normal force against the geom.
 // Faithful to the reference's `efc_force[contact.efc_address]` including efc_address == -1 reading the LAST row.
 template <typename T>
-MW_HD bool touching_object(const Env<T>& e, const TaskDesc<T>& td, int objgeom) {
-    const int ncon = e.I(e.L.icount), nefc = e.I(e.L.icount + 1);
+MW_HD bool touching_object(const Env<T> e, const TaskDesc<T>& td, int objgeom) {
+    const int ncon = e.I(e.lay().icount), nefc = e.I(e.lay().icount + 1);
     T fl = 0, fr = 0;
     for (int c = 0; c < ncon; c++) {
         const int g1 = ICON(e, c, 0), g2 = ICON(e, c, 1);
@@ -203,7 +203,7 @@ MW_HD bool touching_object(const Env<T>& e, const TaskDesc<T>& td, int objgeom) 
 
 // base SawyerXYZEnv._gripper_caging_reward (sawyer_xyz_env.py:721-858); `ref` plays obj_init_pos (stick tasks pass stick_init_pos)
 template <typename T>
-MW_HD T caging_base(const Env<T>& e, const TaskDesc<T>& td, const T* act, V3<T> obj, V3<T> ref, T obj_radius, T pad_success_thresh,
+MW_HD T caging_base(const Env<T> e, const TaskDesc<T>& td, const T* act, V3<T> obj, V3<T> ref, T obj_radius, T pad_success_thresh,
                     T object_reach_radius, T xz_thresh, T desired_effort, bool high_density, bool medium_density) {
     const V3<T> lp = probe_pos(e, td.probe[P_LPAD]), rp = probe_pos(e, td.probe[P_RPAD]);
     const T pad_y[2] = {lp.y, rp.y};
@@ -233,7 +233,7 @@ MW_HD T caging_base(const Env<T>& e, const TaskDesc<T>& td, const T* act, V3<T> 
 // the per-task overrides (pick-place :180-248; push-back/soccer/sweep/sweep-into): the "init" pads are live views,
 // i.e. the CURRENT pad positions.  mode 0 = pick-place, 1 = y-gripping family.
 template <typename T>
-MW_HD T caging_override(const Env<T>& e, const TaskDesc<T>& td, const T* act, V3<T> obj, int mode, T obj_radius, T grip_margin, T xz_margin) {
+MW_HD T caging_override(const Env<T> e, const TaskDesc<T>& td, const T* act, V3<T> obj, int mode, T obj_radius, T grip_margin, T xz_margin) {
     const T pad_margin = T(0.05);
     const V3<T> lp = probe_pos(e, td.probe[P_LPAD]), rp = probe_pos(e, td.probe[P_RPAD]);
     const T dl = lp.y - obj.y, dr = obj.y - rp.y;
@@ -265,14 +265,14 @@ struct Out { double reward, success; Info info; };
 
 // ---- reach-v3 (43) / reach-wall-v3 (44): envs/sawyer_reach_v3.py:119-161, sawyer_reach_wall_v3.py ----
 template <typename T>
-MW_HD void reach_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void reach_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     set_tk3(e, TK_TARGET, tk3(e, TK_RANDVEC + 3));
     set_tk3(e, TK_OBJINIT, tk3(e, TK_RANDVEC));
     set_obj_xyz(e, tk3(e, TK_RANDVEC));
 }
 template <typename T>
-MW_HD Out reach_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out reach_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> tcp = tcp_center(e, td), target = tk3(e, TK_TARGET);
     const T d = norm(tcp - target);
     const T in_place = tolerance_lt(d, T(0), T(0.05), norm(v3(td.hand_init[0], td.hand_init[1], td.hand_init[2]) - target));
@@ -284,7 +284,7 @@ MW_HD Out reach_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const
 // ---- the push / pick-place family: free object at qpos[9:16], goal from rand_vec[3:6] ----
 // reset flavours (all after _reset_hand): where obj z and target z come from differs per task.
 template <typename T>
-MW_HD void pushpick_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void pushpick_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     V3<T> oi = rv0, tg = rv1;
@@ -305,7 +305,7 @@ MW_HD void pushpick_reset(const Env<T>& e, const TaskDesc<T>& td) {
     set_obj_xyz(e, oi);
 }
 template <typename T>
-MW_HD Out push_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {   // push-v3 (40)
+MW_HD Out push_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {   // push-v3 (40)
     const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
     const T opened = obs[3], tcp_to_obj = norm(obj - tcp_center(e, td)), t2o = norm(obj - target);
     const T in_place = tolerance_lt(t2o, T(0), T(0.05), norm(oi - target));
@@ -317,7 +317,7 @@ MW_HD Out push_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const 
     return Out{double(reward), double(t2o <= T(0.05)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, t2o, reward)};
 }
 template <typename T>
-MW_HD Out pick_place_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {   // pick-place-v3 (30)
+MW_HD Out pick_place_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {   // pick-place-v3 (30)
     const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
     const T opened = obs[3], o2t = norm(obj - target), tcp_to_obj = norm(obj - tcp_center(e, td));
     const T in_place = tolerance_lt(o2t, T(0), T(0.05), norm(oi - target));
@@ -329,7 +329,7 @@ MW_HD Out pick_place_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, 
     return Out{double(reward), double(o2t <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, o2t, reward)};
 }
 template <typename T>
-MW_HD Out push_back_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {   // push-back-v3 (42)
+MW_HD Out push_back_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {   // push-back-v3 (42)
     const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
     const T opened = obs[3], tcp_to_obj = norm(obj - tcp_center(e, td)), t2o = norm(obj - target), t2oi = norm(oi - target);
     const T in_place = tolerance_lt(t2o, T(0), T(0.05), t2oi);
@@ -341,7 +341,7 @@ MW_HD Out push_back_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, c
     return Out{double(reward), double(t2o <= T(0.07)), make_info(tcp_to_obj <= T(0.03), gs, grasped, in_place, t2o, reward)};
 }
 template <typename T>
-MW_HD Out wall_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {   // push-wall (41) / pick-place-wall (28)
+MW_HD Out wall_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {   // push-wall (41) / pick-place-wall (28)
     const bool pick = td.kind == 28;
     const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
     const T opened = obs[3], tcp_to_obj = norm(obj - tcp_center(e, td));
@@ -373,7 +373,7 @@ MW_HD Out wall_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const 
 
 // ---- sweep-v3 (47), sweep-into-v3 (46), soccer-v3 (37), hand-insert-v3 (17) ----
 template <typename T>
-MW_HD void sweepfam_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void sweepfam_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     V3<T> oi, tg;
@@ -383,7 +383,7 @@ MW_HD void sweepfam_reset(const Env<T>& e, const TaskDesc<T>& td) {
         oi = V3<T>{rv0.x, rv0.y, probe_pos(e, td.probe[P_OBJ0]).z}; tg = c3(td, 3);
     } else if (td.kind == 37) {     // soccer: goal_whole body relocated to the target
         oi = V3<T>{rv0.x, rv0.y, td.c[2]}; tg = rv1;
-        st3(e, e.L.reloc + 3 * td.reloc[0], tg);
+        st3(e, e.lay().reloc + 3 * td.reloc[0], tg);
     } else {                        // hand-insert
         oi = V3<T>{rv0.x, rv0.y, td.c[2]}; tg = rv1;
     }
@@ -392,7 +392,7 @@ MW_HD void sweepfam_reset(const Env<T>& e, const TaskDesc<T>& td) {
     set_obj_xyz(e, oi);
 }
 template <typename T>
-MW_HD Out sweepfam_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out sweepfam_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> obj = obs3(obs, 4), oi = tk3(e, TK_OBJINIT);
     V3<T> target = tk3(e, TK_TARGET);
     const T opened = obs[3], tcp_to_obj = norm(obj - tcp_center(e, td));
@@ -431,7 +431,7 @@ MW_HD Out sweepfam_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, co
 
 // ---- bin-picking-v3 (2): envs/sawyer_bin_picking_v3.py ; TK_EXTRA[0] = _target_to_obj_init latch (-1 = None) ----
 template <typename T>
-MW_HD void bin_picking_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void bin_picking_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC);
     const V3<T> oi{rv0.x, rv0.y, probe_pos(e, td.probe[P_OBJ0]).z};
@@ -441,7 +441,7 @@ MW_HD void bin_picking_reset(const Env<T>& e, const TaskDesc<T>& td) {
     TK(e, TK_EXTRA) = -1;
 }
 template <typename T>
-MW_HD Out bin_picking_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out bin_picking_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> hand = obs3(obs, 0), obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
     const T t2o = norm(obj - target);
     if (TK(e, TK_EXTRA) < 0) TK(e, TK_EXTRA) = t2o;
@@ -463,18 +463,18 @@ MW_HD Out bin_picking_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs,
 
 // ---- generic helpers for fixture tasks ----
 // per-env model write: model.body(X).pos = v  (reloc slot k)
-template <typename T> MW_HD void set_reloc(const Env<T>& e, const TaskDesc<T>& td, int k, V3<T> v) { st3(e, e.L.reloc + 3 * td.reloc[k], v); }
+template <typename T> MW_HD void set_reloc(const Env<T> e, const TaskDesc<T>& td, int k, V3<T> v) { st3(e, e.lay().reloc + 3 * td.reloc[k], v); }
 // joint-level _set_obj_xyz variants: qpos[adr] <- q ; qvel[dadr] <- 0 ; set_state -> mj_forward
-template <typename T> MW_HD void set_joint(const Env<T>& e, int qadr, int dadr, T q) {
-    e.R(e.L.qpos + qadr) = q;
-    if (dadr >= 0) e.R(e.L.qvel + dadr) = 0;
+template <typename T> MW_HD void set_joint(const Env<T> e, int qadr, int dadr, T q) {
+    e.R(e.lay().qpos + qadr) = q;
+    if (dadr >= 0) e.R(e.lay().qvel + dadr) = 0;
     forward(e);
 }
 
 // ---- button-press-topdown (4), -topdown-wall (5), button-press (6), -wall (7) ----
 // probes: P_X0 = site hole, P_X1 = site buttonStart ; reloc0 = body box ; TK_EXTRA[0] = _obj_to_target_init
 template <typename T>
-MW_HD void button_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void button_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> oi = tk3(e, TK_RANDVEC);
     set_tk3(e, TK_OBJINIT, oi);
@@ -487,7 +487,7 @@ MW_HD void button_reset(const Env<T>& e, const TaskDesc<T>& td) {
     TK(e, TK_EXTRA) = mw_abs(comp(target, ax) - comp(bs, ax));
 }
 template <typename T>
-MW_HD Out button_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out button_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> obj = obs3(obs, 4), tcp = tcp_center(e, td), target = tk3(e, TK_TARGET);
     const T tcp_to_obj = norm(obj - tcp), tcp_to_obj_init = norm(obj - tk3(e, TK_INITTCP));
     const int ax = (td.kind == 4 || td.kind == 5) ? 2 : 1;
@@ -520,13 +520,13 @@ MW_HD Out button_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, cons
 
 // ---- coffee-button (8), coffee-pull (9), coffee-push (10): mug free joint FIRST (qpos[0:7]); reloc0 = coffee_machine ----
 template <typename T>
-MW_HD void coffee_set_mug(const Env<T>& e, V3<T> p) {      // qpos[0:3] <- pos ; qvel[9:15] <- 0 (robot dofs: reference quirk)
-    st3(e, e.L.qpos, p);
-    for (int k = 9; k < 15; k++) e.R(e.L.qvel + k) = 0;
+MW_HD void coffee_set_mug(const Env<T> e, V3<T> p) {      // qpos[0:3] <- pos ; qvel[9:15] <- 0 (robot dofs: reference quirk)
+    st3(e, e.lay().qpos, p);
+    for (int k = 9; k < 15; k++) e.R(e.lay().qvel + k) = 0;
     forward(e);
 }
 template <typename T>
-MW_HD void coffee_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void coffee_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     if (td.kind == 8) {
@@ -542,7 +542,7 @@ MW_HD void coffee_reset(const Env<T>& e, const TaskDesc<T>& td) {
     }
 }
 template <typename T>
-MW_HD Out coffee_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out coffee_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> obj = obs3(obs, 4), tcp = tcp_center(e, td), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
     const T tcp_to_obj = norm(obj - tcp);
     if (td.kind == 8) {
@@ -566,21 +566,21 @@ MW_HD Out coffee_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, cons
 
 // ---- dial-turn (11): obs pos = B(dial) + 0.05*[sin q, -cos q, 0] ; reloc0 = dial ; qadr0 = knob_Joint_1 ; P_X0 = body dial ----
 template <typename T>
-MW_HD V3<T> dial_pos(const Env<T>& e, const TaskDesc<T>& td) {
-    const T q = e.R(e.L.qpos + td.qadr[0]);
+MW_HD V3<T> dial_pos(const Env<T> e, const TaskDesc<T>& td) {
+    const T q = e.R(e.lay().qpos + td.qadr[0]);
     return probe_pos(e, td.probe[P_X0]) + v3<T>(T(0.05) * sin(q), T(-0.05) * cos(q), 0);
 }
 template <typename T>
-MW_HD void dial_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void dial_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC);
     set_tk3(e, TK_OBJINIT, rv0);
     set_tk3(e, TK_TARGET, rv0 + v3<T>(0, T(0.03), T(0.03)));
     set_reloc(e, td, 0, rv0);
-    st3(e, e.L.task + TK_EXTRA, dial_pos(e, td) + v3<T>(T(0.05), T(0.02), T(0.09)));   // dial_push_position (stale FK, like the reference)
+    st3(e, e.lay().task + TK_EXTRA, dial_pos(e, td) + v3<T>(T(0.05), T(0.02), T(0.09)));   // dial_push_position (stale FK, like the reference)
 }
 template <typename T>
-MW_HD Out dial_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out dial_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> obj = dial_pos(e, td), push = obj + v3<T>(T(0.05), T(0.02), T(0.09)), tcp = tcp_center(e, td), target = tk3(e, TK_TARGET);
     const V3<T> push0 = tk3(e, TK_EXTRA);
     const T t2o = norm(obj - target), t2oi = norm(push0 - target);
@@ -595,7 +595,7 @@ MW_HD Out dial_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const 
 // ---- door-close (13), door-open (15) [sawyer_door_pull], door-lock (14), door-unlock (16) [sawyer_door_lock] ----
 // reloc0 = door ; qadr0/dadr0 = doorjoint ; P_X0 = body lock_link
 template <typename T>
-MW_HD void door_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void door_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC);
     if (td.kind == 13 || td.kind == 15) {
@@ -618,7 +618,7 @@ MW_HD void door_reset(const Env<T>& e, const TaskDesc<T>& td) {
     }
 }
 template <typename T>
-MW_HD Out door_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out door_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET);
     if (td.kind == 13) {
         const V3<T> tcp = tcp_center(e, td);
@@ -631,7 +631,7 @@ MW_HD Out door_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const 
         return Out{double(reward), double(o2t <= T(0.08)), make_info(0.0, 1.0, 1.0, hand_in_place, o2t, reward)};
     }
     if (td.kind == 15) {
-        const T theta = e.R(e.L.qpos + td.qadr[0]);
+        const T theta = e.R(e.lay().qpos + td.qadr[0]);
         const T grab = (mw_clamp(act[3], T(-1), T(1)) + 1) / 2;
         const V3<T> hand = obs3(obs, 0), door = obj + v3<T>(T(-0.05), 0, 0);
         const T thr = T(0.12), radius = mw_sqrt((hand.x - door.x) * (hand.x - door.x) + (hand.y - door.y) * (hand.y - door.y));
@@ -669,7 +669,7 @@ MW_HD Out door_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const 
 
 // ---- drawer-close (18), drawer-open (19): reloc0 = drawer ; obs pos = B(drawer_link) + offset ----
 template <typename T>
-MW_HD void drawer_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void drawer_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC);
     set_reloc(e, td, 0, rv0);
@@ -683,7 +683,7 @@ MW_HD void drawer_reset(const Env<T>& e, const TaskDesc<T>& td) {
     }
 }
 template <typename T>
-MW_HD Out drawer_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out drawer_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> obj = obs3(obs, 4), target = tk3(e, TK_TARGET);
     if (td.kind == 18) {
         const V3<T> oi = tk3(e, TK_OBJINIT), tcp = tcp_center(e, td);
@@ -710,7 +710,7 @@ MW_HD Out drawer_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, cons
 
 // ---- faucet-open (20), faucet-close (21): reloc0 = faucetBase ----
 template <typename T>
-MW_HD void faucet_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void faucet_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC);
     set_tk3(e, TK_OBJINIT, rv0);
@@ -719,7 +719,7 @@ MW_HD void faucet_reset(const Env<T>& e, const TaskDesc<T>& td) {
     if (td.kind == 21) forward(e);
 }
 template <typename T>
-MW_HD Out faucet_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out faucet_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     V3<T> obj = obs3(obs, 4);
     if (td.kind == 20) obj = obj + v3<T>(T(-0.04), 0, T(0.03));
     const V3<T> tcp = tcp_center(e, td), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
@@ -735,7 +735,7 @@ MW_HD Out faucet_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, cons
 // ---- handle-press-side (23), handle-press (24), handle-pull-side (25), handle-pull (26): reloc0 = box ----
 // probes: P_X0 = goal site (goalPress / goalPull) ; TK_EXTRA[0..2] = _handle_init_pos
 template <typename T>
-MW_HD void handle_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void handle_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC);
     set_tk3(e, TK_OBJINIT, rv0);
@@ -743,11 +743,11 @@ MW_HD void handle_reset(const Env<T>& e, const TaskDesc<T>& td) {
     set_joint(e, 9, 9, (td.kind == 23 || td.kind == 24) ? T(-0.001) : T(-0.1));
     set_tk3(e, TK_TARGET, probe_pos(e, td.probe[P_X0]));
     const V3<T> h0 = probe_pos(e, td.probe[P_OBJ0]);
-    st3(e, e.L.task + TK_EXTRA, h0);
+    st3(e, e.lay().task + TK_EXTRA, h0);
     if (td.kind == 25) set_tk3(e, TK_OBJINIT, h0);      // handle-pull-side re-captures obj_init_pos; handle-pull keeps rand_vec
 }
 template <typename T>
-MW_HD Out handle_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out handle_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> target = tk3(e, TK_TARGET), tcp = tcp_center(e, td);
     if (td.kind == 23 || td.kind == 24) {
         const V3<T> obj = probe_pos(e, td.probe[P_OBJ0]), h0 = tk3(e, TK_EXTRA);
@@ -784,22 +784,22 @@ MW_HD Out handle_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, cons
 
 // ---- lever-pull (27): reloc0 = lever ; qadr0 = LeverAxis ; TK_EXTRA[0..2] = _lever_pos_init ----
 template <typename T>
-MW_HD void lever_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void lever_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC);
     set_tk3(e, TK_OBJINIT, rv0);
     set_reloc(e, td, 0, rv0);
-    st3(e, e.L.task + TK_EXTRA, rv0 + v3<T>(T(0.12), T(-0.2), T(0.25)));
+    st3(e, e.lay().task + TK_EXTRA, rv0 + v3<T>(T(0.12), T(-0.2), T(0.25)));
     set_tk3(e, TK_TARGET, rv0 + v3<T>(T(0.12), 0, T(0.25 + 0.2)));
 }
 template <typename T>
-MW_HD Out lever_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out lever_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> gripper = obs3(obs, 0), lever = obs3(obs, 4), off = v3<T>(0, T(0.055), T(0.07)), l0 = tk3(e, TK_EXTRA), target = tk3(e, TK_TARGET);
     const T s2l = norm(scale3(gripper + off - lever, T(4), T(1), T(4)));
     const T s2li = norm(scale3(tk3(e, TK_INITTCP) + off - l0, T(4), T(1), T(4)));
     const T ready = tolerance_lt(s2l, T(0), T(0.02), s2li);
     const T pi = T(3.14159265358979323846);
-    const T angle = -e.R(e.L.qpos + td.qadr[0]), err = mw_abs(angle - pi / 2);
+    const T angle = -e.R(e.lay().qpos + td.qadr[0]), err = mw_abs(angle - pi / 2);
     const T engagement = tolerance_lt(err, T(0), pi / 48, pi / 2 - pi / 12);
     const T in_place = tolerance_lt(norm(lever - target), T(0), T(0.04), norm(l0 - target));
     const T reward = 10 * hamacher(ready, in_place);
@@ -808,7 +808,7 @@ MW_HD Out lever_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const
 
 // ---- window-open (48), window-close (49): reloc0 = window ; qadr0 = window_slide ; TK_EXTRA[0..2] = window_handle_pos_init ----
 template <typename T>
-MW_HD void window_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void window_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     if (td.kind == 49) set_tk3(e, TK_INITTCP, tcp_center(e, td));
     const V3<T> rv0 = tk3(e, TK_RANDVEC);
@@ -816,11 +816,11 @@ MW_HD void window_reset(const Env<T>& e, const TaskDesc<T>& td) {
     set_tk3(e, TK_TARGET, td.kind == 48 ? rv0 + v3<T>(T(0.2), 0, 0) : rv0);
     set_reloc(e, td, 0, rv0);
     const V3<T> h = probe_pos(e, td.probe[P_OBJ0]);                      // stale FK, like the reference
-    st3(e, e.L.task + TK_EXTRA, td.kind == 48 ? h : h + v3<T>(T(0.2), 0, 0));
-    e.R(e.L.qpos + td.qadr[0]) = td.kind == 48 ? T(0) : T(0.2);          // data.joint("window_slide").qpos = ... (no forward)
+    st3(e, e.lay().task + TK_EXTRA, td.kind == 48 ? h : h + v3<T>(T(0.2), 0, 0));
+    e.R(e.lay().qpos + td.qadr[0]) = td.kind == 48 ? T(0) : T(0.2);          // data.joint("window_slide").qpos = ... (no forward)
 }
 template <typename T>
-MW_HD Out window_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out window_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> obj = probe_pos(e, td.probe[P_OBJ0]), tcp = tcp_center(e, td), target = tk3(e, TK_TARGET), h0 = tk3(e, TK_EXTRA);
     const T t2o = mw_abs(obj.x - target.x);
     const T t2oi = td.kind == 48 ? mw_abs(TK(e, TK_OBJINIT) - target.x) : mw_abs(h0.x - target.x);
@@ -834,7 +834,7 @@ MW_HD Out window_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, cons
 
 // ---- plate-slide (31), -side (32), -back (33), -back-side (34): puck on two slide joints qpos[9:11]; reloc0 = puck_goal ----
 template <typename T>
-MW_HD void plate_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void plate_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     set_tk3(e, TK_OBJINIT, rv0);
@@ -842,7 +842,7 @@ MW_HD void plate_reset(const Env<T>& e, const TaskDesc<T>& td) {
     if (td.kind == 31) set_reloc(e, td, 0, rv1);
     if (td.kind == 34) set_reloc(e, td, 0, rv0);
     const T q0 = td.kind == 34 ? T(-0.15) : T(0), q1 = td.kind == 33 ? T(0.15) : T(0);
-    e.R(e.L.qpos + 9) = q0; e.R(e.L.qpos + 10) = q1;          // _set_obj_xyz: qpos[9:11], qvel untouched
+    e.R(e.lay().qpos + 9) = q0; e.R(e.lay().qpos + 10) = q1;          // _set_obj_xyz: qpos[9:11], qvel untouched
     forward(e);
 }
 template <typename T>
@@ -850,7 +850,7 @@ MW_HD T tolerance_lt_checked(T x, T lo, T hi, T margin) {   // the reference rai
     return tolerance_lt(x, lo, hi, margin < 0 ? T(0) : margin);
 }
 template <typename T>
-MW_HD Out plate_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out plate_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> tcp = tcp_center(e, td), obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
     const T o2t = norm(obj - target), tcp_to_obj = norm(tcp - obj);
     const T m1 = norm(oi - target), m2 = norm(tk3(e, TK_INITTCP) - oi);
@@ -872,7 +872,7 @@ MW_HD Out plate_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const
 // ---- assembly (0), disassemble (12) [sawyer_assembly_peg], hammer (22) ----
 // probes: P_X0 = site RoundNut (wrench centre) ; reloc0 = peg (assembly/disassemble), box (hammer) ; qadr0 = NailSlideJoint
 template <typename T>
-MW_HD void wrench_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void wrench_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     set_tk3(e, TK_OBJINIT, rv0);
@@ -892,7 +892,7 @@ MW_HD void wrench_reset(const Env<T>& e, const TaskDesc<T>& td) {
     }
 }
 template <typename T>
-MW_HD Out wrench_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out wrench_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> hand = obs3(obs, 0), obj = obs3(obs, 4), target = tk3(e, TK_TARGET);
     V3<T> threshed = obj;
     const T half = td.kind == 22 ? T(0.07) : T(0.01);
@@ -922,7 +922,7 @@ MW_HD Out wrench_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, cons
     } else {
         const V3<T> head = obj + v3<T>(T(0.16), T(0.06), 0);
         in_place = T(0.1) * T(head.z > T(0.02)) + T(0.9) * tolerance_lt(norm(target - head), T(0), T(0.02), T(0.2));
-        success = e.R(e.L.qpos + td.qadr[0]) > T(0.09);
+        success = e.R(e.lay().qpos + td.qadr[0]) > T(0.09);
     }
     T reward = (2 * grab + 6 * in_place) * rquat;
     if (td.kind == 22 ? (success && reward > 5) : success) reward = 10;
@@ -934,17 +934,17 @@ MW_HD Out wrench_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, cons
 // 2*(hoop position) per reset.  TK_PERSIST[0..2] = accumulated model.site("goal").pos (survives resets). ----
 enum { TK_PERSIST = TK_PERSIST0 };
 template <typename T>
-MW_HD void basketball_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void basketball_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     const V3<T> oi{rv0.x, rv0.y, td.c[2]};
     set_tk3(e, TK_OBJINIT, oi);
     set_reloc(e, td, 0, rv1);
     set_obj_xyz(e, oi);
-    st3(e, e.L.task + TK_EXTRA, probe_pos(e, td.probe[P_X0]));   // hoop site position for local pos 0 (= B + c)
+    st3(e, e.lay().task + TK_EXTRA, probe_pos(e, td.probe[P_X0]));   // hoop site position for local pos 0 (= B + c)
 }
 template <typename T>
-MW_HD Out basketball_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out basketball_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> obj = obs3(obs, 4), oi = tk3(e, TK_OBJINIT);
     V3<T> target = tk3(e, TK_TARGET);
     target.z = T(0.3);
@@ -963,7 +963,7 @@ MW_HD Out basketball_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, 
 
 // ---- box-close (3): reloc0 = boxbody ; c[6] = model z of boxbody ----
 template <typename T>
-MW_HD void box_close_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void box_close_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     const V3<T> oi{rv0.x, rv0.y, td.c[2]};
@@ -974,7 +974,7 @@ MW_HD void box_close_reset(const Env<T>& e, const TaskDesc<T>& td) {
     set_obj_xyz(e, oi);
 }
 template <typename T>
-MW_HD Out box_close_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out box_close_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> hand = obs3(obs, 0), lid = obs3(obs, 4) + v3<T>(0, 0, T(0.02)), target = tk3(e, TK_TARGET);
     const T grab = mw_clamp((mw_clamp(act[3], T(-1), T(1)) + 1) / 2, T(0), T(1));
     const T ideal[4] = {T(0.707), 0, 0, T(0.707)};
@@ -996,7 +996,7 @@ MW_HD Out box_close_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, c
 
 // ---- pick-out-of-hole (29), shelf-place (45), peg-insert-side (35), peg-unplug-side (36) ----
 template <typename T>
-MW_HD void misc_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void misc_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     if (td.kind == 29) {
@@ -1011,16 +1011,16 @@ MW_HD void misc_reset(const Env<T>& e, const TaskDesc<T>& td) {
         set_obj_xyz(e, oi);
     } else if (td.kind == 35) {
         set_tk3(e, TK_OBJINIT, rv0);
-        st3(e, e.L.task + TK_EXTRA, probe_pos(e, td.probe[P_X0]));           // peg_head_pos_init (before the peg is placed)
+        st3(e, e.lay().task + TK_EXTRA, probe_pos(e, td.probe[P_X0]));           // peg_head_pos_init (before the peg is placed)
         set_obj_xyz(e, rv0);
         set_reloc(e, td, 0, rv1);
         set_tk3(e, TK_TARGET, rv1 + v3<T>(T(0.03), 0, T(0.13)));
     } else {
         set_reloc(e, td, 0, rv0);
         const V3<T> plug = rv0 + v3<T>(T(0.044), 0, T(0.131));
-        st3(e, e.L.qpos + 9, plug);
-        st4(e, e.L.qpos + 12, Q4<T>{1, 0, 0, 0});
-        for (int k = 9; k < 12; k++) e.R(e.L.qvel + k) = 0;
+        st3(e, e.lay().qpos + 9, plug);
+        st4(e, e.lay().qpos + 12, Q4<T>{1, 0, 0, 0});
+        for (int k = 9; k < 12; k++) e.R(e.lay().qvel + k) = 0;
         forward(e);
         set_tk3(e, TK_OBJINIT, probe_pos(e, td.probe[P_OBJ0]));
         set_tk3(e, TK_TARGET, plug + v3<T>(T(0.15), 0, 0));
@@ -1036,7 +1036,7 @@ MW_HD T rect_prism_tolerance(V3<T> curr, V3<T> zero, V3<T> one) {
     return 1;
 }
 template <typename T>
-MW_HD Out misc_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out misc_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> tcp = tcp_center(e, td), obj = obs3(obs, 4), target = tk3(e, TK_TARGET), oi = tk3(e, TK_OBJINIT);
     const T opened = obs[3], tcp_to_obj = norm(obj - tcp);
     if (td.kind == 29) {
@@ -1098,20 +1098,20 @@ MW_HD Out misc_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const 
 // probes: OBJ0 = body stick, OBJ1 = body stick (scipy quat), OBJ2 = site insertion ; P_X0 = body object, P_X1 = site stick_end
 // TK_EXTRA[0..2] = stick_init_pos ; c[6] = stick_init z
 template <typename T>
-MW_HD void stick_reset(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void stick_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     const V3<T> si{rv0.x, rv0.y, td.c[6]};
-    st3(e, e.L.task + TK_EXTRA, si);
+    st3(e, e.lay().task + TK_EXTRA, si);
     set_tk3(e, TK_TARGET, v3<T>(rv1.x, rv1.y, td.kind == 38 ? probe_pos(e, td.probe[P_OBJ2]).z : si.z));
     set_obj_xyz(e, si);                                           // _set_stick_xyz
-    e.R(e.L.qpos + 16) = 0; e.R(e.L.qpos + 17) = td.kind == 38 ? T(0) : T(0.09);
-    e.R(e.L.qvel + 15) = e.R(e.L.qvel + 15); e.R(e.L.qvel + 16) = 0;   // qvel[16:18] = 0 (index 17 is out of range for nv = 17)
+    e.R(e.lay().qpos + 16) = 0; e.R(e.lay().qpos + 17) = td.kind == 38 ? T(0) : T(0.09);
+    e.R(e.lay().qvel + 15) = e.R(e.lay().qvel + 15); e.R(e.lay().qvel + 16) = 0;   // qvel[16:18] = 0 (index 17 is out of range for nv = 17)
     forward(e);
     set_tk3(e, TK_OBJINIT, probe_pos(e, td.probe[P_X0]));
 }
 template <typename T>
-MW_HD Out stick_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act) {
+MW_HD Out stick_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
     const V3<T> tcp = tcp_center(e, td), target = tk3(e, TK_TARGET), si = tk3(e, TK_EXTRA), oi = tk3(e, TK_OBJINIT);
     const T opened = obs[3];
     const bool touch = touching_object(e, td, td.geom[G_OBJ]);
@@ -1158,7 +1158,7 @@ MW_HD Out stick_eval(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const
 // model writes that the FIRST reset_model pass leaves behind (the physics of that pass is discarded by mj_resetData,
 // its `model.body(X).pos = ...` writes are not): apply them before the replayed second pass.
 template <typename T>
-MW_HD void task_model_writes(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void task_model_writes(const Env<T> e, const TaskDesc<T>& td) {
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     switch (td.kind) {
     case 37: set_reloc(e, td, 0, rv1); break;
@@ -1180,7 +1180,7 @@ MW_HD void task_model_writes(const Env<T>& e, const TaskDesc<T>& td) {
 }
 
 template <typename T>
-MW_HD void task_reset_model(const Env<T>& e, const TaskDesc<T>& td) {
+MW_HD void task_reset_model(const Env<T> e, const TaskDesc<T>& td) {
     switch (td.kind) {
     case 43: case 44: reach_reset(e, td); break;
     case 40: case 41: case 42: case 30: case 28: pushpick_reset(e, td); break;
@@ -1205,7 +1205,7 @@ MW_HD void task_reset_model(const Env<T>& e, const TaskDesc<T>& td) {
     }
 }
 template <typename T>
-MW_HD void task_evaluate(const Env<T>& e, const TaskDesc<T>& td, const T* obs, const T* act, T* reward, T* success, Info* info) {
+MW_HD void task_evaluate(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act, T* reward, T* success, Info* info) {
     Out o{0, 0, Info{0, 0, 0, 0, 0, 0}};
     switch (td.kind) {
     case 43: case 44: o = reach_eval(e, td, obs, act); break;
@@ -1237,10 +1237,10 @@ MW_HD void task_evaluate(const Env<T>& e, const TaskDesc<T>& td, const T* obs, c
 
 // state that survives a reset (only basketball's accumulated goal-site position): called after reset_model / snapshot load
 template <typename T>
-MW_HD void task_after_reset(const Env<T>& e, const TaskDesc<T>& td, V3<T> persist_before, T* obs39) {
+MW_HD void task_after_reset(const Env<T> e, const TaskDesc<T>& td, V3<T> persist_before, T* obs39) {
     if (td.kind != 1) return;
     const V3<T> P = tk3(e, TK_EXTRA), s = persist_before + P * T(2);
-    st3(e, e.L.task + TK_PERSIST, s);
+    st3(e, e.lay().task + TK_PERSIST, s);
     set_tk3(e, TK_TARGET, P + s);
     // the reset observation is built from the FK that precedes the last site write: it shows s (= 2P + s_before), the
     // episode itself sees P + s
@@ -1252,7 +1252,7 @@ MW_HD void task_after_reset(const Env<T>& e, const TaskDesc<T>& td, V3<T> persis
 // (The first reset_model pass only leaves model writes behind; they are functions of rand_vec and are
 //  re-applied by the second pass, see DESIGN.md "reset".)
 template <typename T>
-MW_HD void env_reset(const Env<T>& e, const TaskDesc<T>& td, T* obs39) {
+MW_HD void env_reset(const Env<T> e, const TaskDesc<T>& td, T* obs39) {
     reset_data(e);
     TK(e, TK_PATHLEN) = 0; TK(e, TK_ELAPSED) = 0; TK(e, TK_EPRET) = 0; TK(e, TK_EPLEN) = 0; TK(e, TK_SUCCESS) = 0;
     for (int k = 0; k < 16; k++) TK(e, TK_EXTRA + k) = 0;
@@ -1266,15 +1266,15 @@ MW_HD void env_reset(const Env<T>& e, const TaskDesc<T>& td, T* obs39) {
 
 // SawyerXYZEnv.step (:579-642) up to (obs, reward, success, info); wrappers are applied by the caller
 template <typename T>
-MW_HD void env_step(const Env<T>& e, const TaskDesc<T>& td, const T* act, T* obs39, T* reward, T* success, Info* info) {
+MW_HD void env_step(const Env<T> e, const TaskDesc<T>& td, const T* act, T* obs39, T* reward, T* success, Info* info) {
     // set_xyz_action: mocap += clip(a,-1,1)*0.01, clipped to the mocap box
     // (the reference multiplies the float32 action by action_scale in float32: numpy keeps float32 * python-float in float32)
     for (int k = 0; k < 3; k++) {
         const float a = fminf(fmaxf(float(act[k]), -1.0f), 1.0f);
         const float delta = a * 0.01f;
-        e.R(e.L.mocap + k) = mw_clamp(e.R(e.L.mocap + k) + T(delta), td.mocap_low[k], td.mocap_high[k]);
+        e.R(e.lay().mocap + k) = mw_clamp(e.R(e.lay().mocap + k) + T(delta), td.mocap_low[k], td.mocap_high[k]);
     }
-    e.R(e.L.ctrl) = act[3]; e.R(e.L.ctrl + 1) = -act[3];
+    e.R(e.lay().ctrl) = act[3]; e.R(e.lay().ctrl + 1) = -act[3];
     for (int k = 0; k < 5; k++) substep(e);
     TK(e, TK_PATHLEN) += 1;
     forward(e);

@@ -47,3 +47,8 @@ extern "C" void mwh_counters(long* out, int reset) {
     for (int i = 0; i < 8; i++) { out[i] = mw::mw_cnt()[i]; if (reset) mw::mw_cnt()[i] = 0; }
 }
 #endif
+#ifdef MW_PROFILE
+extern "C" void mwh_hist(long* out, int reset) {
+    for (int i = 0; i < 128; i++) { out[i] = mw::mw_hist()[i]; if (reset) mw::mw_hist()[i] = 0; }
+}
+#endif
