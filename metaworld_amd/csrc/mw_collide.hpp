@@ -20,9 +20,17 @@ struct Shape {
     V3<T> pos;
     M3<T> mat;
     T size[3];
-    const T* vert;
+    CP<T> vert;
     int nvert;
     T margin;
+    // everything except pos / mat is a model constant of the (wave-uniform) geom pair being tested
+    MW_HD Shape uniform() const {
+        Shape u = *this;
+        u.type = mw_uniform(type); u.nvert = mw_uniform(nvert); u.margin = mw_uniform(margin);
+        u.vert = (CP<T>)mw_uniform((unsigned long long)vert);
+        for (int k = 0; k < 3; k++) u.size[k] = mw_uniform(size[k]);
+        return u;
+    }
 };
 template <typename T> struct Hit { T dist; V3<T> pos, normal; };
 
@@ -301,6 +309,7 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
     case G_MESH: {
         int best = 0;
         T bd = T(-1e30);
+#pragma unroll 4
         for (int i = 0; i < s.nvert; i++) {
             const T dd = s.vert[3 * i] * dl.x + s.vert[3 * i + 1] * dl.y + s.vert[3 * i + 2] * dl.z;
             if (dd > bd + tie) { bd = dd; best = i; }
@@ -381,7 +390,7 @@ MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V
         v4 = msupport(A, B, dir);
         const T dv4 = dot(v4.v, dir);
         if (dv4 < 0 && !hit) return 0;
-        if (dv4 - dot(v1.v, dir) <= tol || it == maxit - 1) break;
+        if (dv4 - dot(v1.v, dir) <= tol || it == maxit - 1) { MW_HIST(2, it) break; }
         const V3<T> t = cross(v4.v, v0.v);
         if (dot(v1.v, t) > 0) { if (dot(v2.v, t) > 0) v1 = v4; else v3_ = v4; }
         else { if (dot(v3_.v, t) > 0) v2 = v4; else v1 = v4; }
@@ -424,7 +433,8 @@ MW_HD int mpr_refined(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h)
         const T d2 = margin - h2.dist;
         if (d2 > depth) break;
         *h = h2;
-        if (depth - d2 <= rel * depth) break;
+        if (depth - d2 <= rel * depth) { MW_HIST(3, it) break; }
+        if (it == 9) MW_HIST(3, 10)
     }
     return 1;
 }
@@ -523,14 +533,16 @@ MW_HD Shape<T> make_shape(const Env<T> e, int g) {
 
 template <typename T>
 MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h) {
-    const int t1 = a_.type, t2 = b_.type;
+    const Shape<T> ua = a_.uniform(), ub = b_.uniform();
+    margin = mw_uniform(margin);
+    const int t1 = ua.type, t2 = ub.type;
     int n = -1;
-    if (t1 == G_PLANE) n = plane_x(a_, b_, margin, h);
-    else if (t1 == G_SPHERE) n = sphere_x(a_, b_, margin, h);
-    else if (t1 == G_CAPSULE && t2 == G_CAPSULE) n = capsule_capsule(a_, b_, margin, h);
-    else if (t1 == G_BOX && t2 == G_BOX) n = box_box(a_, b_, margin, h, 8);
+    if (t1 == G_PLANE) n = plane_x(ua, ub, margin, h);
+    else if (t1 == G_SPHERE) n = sphere_x(ua, ub, margin, h);
+    else if (t1 == G_CAPSULE && t2 == G_CAPSULE) n = capsule_capsule(ua, ub, margin, h);
+    else if (t1 == G_BOX && t2 == G_BOX) n = box_box(ua, ub, margin, h, 8);
     if (n < 0) {
-        Shape<T> a = a_, b = b_;
+        Shape<T> a = ua, b = ub;
         a.margin = b.margin = T(0.5) * margin;
         n = mpr_refined(a, b, margin, h);
         if (n && (t1 == G_CYLINDER || t1 == G_CAPSULE) && t2 == G_BOX) {
@@ -569,7 +581,8 @@ MW_HD bool obb_overlap(const Env<T> e, int g1, int g2, T margin) {
 }
 
 template <typename T>
-MW_STAGE_FN void collision(const Env<T> e) {
+MW_STAGE_FN void collision(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     int ncon = 0;

@@ -27,6 +27,18 @@
 
 namespace mw {
 
+// iteration counters / histograms of the host profile build (tests/host_harness.cpp with -DMW_PROFILE)
+#if defined(MW_PROFILE) && !defined(__HIPCC__)
+inline long* mw_cnt() { static long c[8] = {0}; return c; }
+#define MW_COUNT(i) mw_cnt()[i]++;
+inline long* mw_hist() { static long h[4 * 64] = {0}; return h; }
+#define MW_HIST(w, v) mw_hist()[(w) * 64 + ((v) < 63 ? (v) : 63)]++;
+#else
+#define MW_COUNT(i) {}
+#define MW_HIST(w, v) {}
+#endif
+
+
 // Address spaces and uniformity (device only).  Pointers reach the lane code as generic (flat) pointers, which cost
 // flat_load/flat_store and hide wave-uniformity from the compiler.  The column store is therefore accessed through
 // references into the GLOBAL address space (global_load/store), and the model tables -- read at wave-uniform
@@ -41,9 +53,13 @@ __device__ inline unsigned long long mw_uniform(unsigned long long v) {
     const unsigned lo = mw_uniform((unsigned)v), hi = mw_uniform((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
+__device__ inline float mw_uniform(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+__device__ inline double mw_uniform(double x) { return __builtin_bit_cast(double, mw_uniform(__builtin_bit_cast(unsigned long long, x))); }
 #else
 #define MW_GLOBAL
 #define MW_CONST
+inline float mw_uniform(float x) { return x; }
+inline double mw_uniform(double x) { return x; }
 inline unsigned mw_uniform(unsigned x) { return x; }
 inline int mw_uniform(int x) { return x; }
 inline unsigned long long mw_uniform(unsigned long long v) { return v; }
@@ -135,17 +151,31 @@ inline Layout make_layout(const Sizes& s) {
 template <typename T> using CModel = const MW_CONST Model<T>;
 using CLayout = const MW_CONST Layout;
 
-// Per-lane view of one environment (passed BY VALUE: the fields stay in registers across the non-inlined stages).
+// Per-lane view of one environment.  Passed BY VALUE so the fields stay in registers across the non-inlined stage
+// functions; each stage starts with `e = e_.uniform()`, which marks everything except the two lane pointers as
+// wave-uniform ONCE (readfirstlane is not hoisted out of divergent control flow, so it must not sit in accessors).
 template <typename T>
 struct Env {
     const Model<T>* m;
     T* col;        // real column store, already offset by the lane
     int* icol;     // int column store, already offset by the lane
     unsigned stride;   // 32-bit index arithmetic: nreal * stride < 2^32 (checked at group creation)
-    MW_HD CModel<T>& model() const { return *(CModel<T>*)mw_uniform((unsigned long long)m); }
+    int nv, o_efcJ, o_efcX, o_con, o_icon, o_iefc, o_icount, o_task;   // hot layout offsets (copied from Layout)
+    MW_HD void cache_layout(const Layout& L, int nv_) {
+        nv = nv_; o_efcJ = L.efcJ; o_efcX = L.efcX; o_con = L.con; o_icon = L.icon; o_iefc = L.iefc; o_icount = L.icount; o_task = L.task;
+    }
+    MW_HD Env uniform() const {
+        Env u = *this;
+        u.m = (const Model<T>*)mw_uniform((unsigned long long)m);
+        u.stride = mw_uniform(stride);
+        u.nv = mw_uniform(nv); u.o_efcJ = mw_uniform(o_efcJ); u.o_efcX = mw_uniform(o_efcX); u.o_con = mw_uniform(o_con);
+        u.o_icon = mw_uniform(o_icon); u.o_iefc = mw_uniform(o_iefc); u.o_icount = mw_uniform(o_icount); u.o_task = mw_uniform(o_task);
+        return u;
+    }
+    MW_HD CModel<T>& model() const { return *(CModel<T>*)(unsigned long long)m; }
     MW_HD CLayout& lay() const { return model().L; }
-    MW_HD GRef<T> R(int i) const { return ((MW_GLOBAL T*)col)[(unsigned)i * mw_uniform(stride)]; }
-    MW_HD GRef<int> I(int i) const { return ((MW_GLOBAL int*)icol)[(unsigned)i * mw_uniform(stride)]; }
+    MW_HD GRef<T> R(int i) const { return ((MW_GLOBAL T*)col)[(unsigned)i * stride]; }
+    MW_HD GRef<int> I(int i) const { return ((MW_GLOBAL int*)icol)[(unsigned)i * stride]; }
 };
 
 // ----------------------------------------------------------------------------- small math

@@ -18,7 +18,8 @@ template <typename T> MW_STAGE_FN void collision(const Env<T> e);  // mw_collide
 
 // ------------------------------------------------------------------ kinematics
 template <typename T>
-MW_STAGE_FN void kinematics(const Env<T> e) {
+MW_STAGE_FN void kinematics(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nb = m.sz.nbody;
@@ -269,7 +270,8 @@ constexpr int NV_SMALL = 11, NV_LARGE = 17;   // nv of the 36 models is 10, 11, 
 
 // ------------------------------------------------------------------ mass matrix
 template <typename T>
-MW_STAGE_FN void crb(const Env<T> e) {
+MW_STAGE_FN void crb(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nb = m.sz.nbody, nv = m.sz.nv;
@@ -307,7 +309,8 @@ MW_HD void cross_motion(T* r, const T* v, const T* s) {
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = b.x; r[4] = b.y; r[5] = b.z;
 }
 template <typename T>
-MW_STAGE_FN void smooth_forces(const Env<T> e) {
+MW_STAGE_FN void smooth_forces(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nb = m.sz.nbody, nv = m.sz.nv;
@@ -382,12 +385,12 @@ MW_STAGE_FN void smooth_forces(const Env<T> e) {
 
 // ------------------------------------------------------------------ constraint rows
 // efcX per row: 0 pos, 1 margin, 2 R, 3 D, 4 aref, 5 force, 6 jar, 7 Jv
-template <typename T> MW_HD GRef<T> EX(const Env<T> e, int row, int k) { return e.R(e.lay().efcX + EFC_EXTRA * row + k); }
-template <typename T> MW_HD GRef<T> EJ(const Env<T> e, int row, int i) { return e.R(e.lay().efcJ + row * e.model().sz.nv + i); }
-template <typename T> MW_HD GRef<T> CON(const Env<T> e, int c, int k) { return e.R(e.lay().con + CON_STRIDE * c + k); }
+template <typename T> MW_HD GRef<T> EX(const Env<T> e, int row, int k) { return e.R(e.o_efcX + EFC_EXTRA * row + k); }
+template <typename T> MW_HD GRef<T> EJ(const Env<T> e, int row, int i) { return e.R(e.o_efcJ + row * e.nv + i); }
+template <typename T> MW_HD GRef<T> CON(const Env<T> e, int c, int k) { return e.R(e.o_con + CON_STRIDE * c + k); }
 // contact record: 0 dist, 1-3 pos, 4-12 frame, 13 includemargin, 14-16 friction(slide,torsion,roll), 17-18 solref, 19-23 solimp, 24 mu
-template <typename T> MW_HD GRef<int> ICON(const Env<T> e, int c, int k) { return e.I(e.lay().icon + CON_ISTRIDE * c + k); }  // g1,g2,dim,efc_address
-template <typename T> MW_HD GRef<int> IEFC(const Env<T> e, int r, int k) { return e.I(e.lay().iefc + EFC_ISTRIDE * r + k); }  // type,id,state
+template <typename T> MW_HD GRef<int> ICON(const Env<T> e, int c, int k) { return e.I(e.o_icon + CON_ISTRIDE * c + k); }  // g1,g2,dim,efc_address
+template <typename T> MW_HD GRef<int> IEFC(const Env<T> e, int r, int k) { return e.I(e.o_iefc + EFC_ISTRIDE * r + k); }  // type,id,state
 
 // dense load of constraint row `row` of J into registers (rows are zero outside their dof range; entries >= nv
 // re-read column 0 and are never used -- no per-element branches, so the loads issue back to back)
@@ -475,7 +478,8 @@ MW_HD int new_rows(const Env<T> e, int n, int type, int id) {
 }
 
 template <typename T>
-MW_STAGE_FN void make_constraints(const Env<T> e) {
+MW_STAGE_FN void make_constraints(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nv = m.sz.nv;
@@ -604,7 +608,8 @@ MW_HD ConeEval<T> cone_eval(const Env<T> e, int r0, int c, T alpha) {
 
 // cost, forces, states at the current jar; qfrc_constraint = J' force; returns total cost incl. Gauss term
 template <typename T, int NV>
-MW_STAGE_FN T update_constraint(const Env<T> e) {
+MW_STAGE_FN T update_constraint(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nv = m.sz.nv, nefc = e.I(L.icount + 1);
@@ -665,15 +670,6 @@ MW_STAGE_FN T update_constraint(const Env<T> e) {
 }
 
 // constraint part of the cost (no forces written) at jar + alpha*Jv, with 1st/2nd derivatives along the line
-#if defined(MW_PROFILE) && !defined(__HIPCC__)
-inline long* mw_cnt() { static long c[8] = {0}; return c; }
-#define MW_COUNT(i) mw_cnt()[i]++;
-inline long* mw_hist() { static long h[2 * 64] = {0}; return h; }
-#define MW_HIST(w, v) mw_hist()[(w) * 64 + ((v) < 63 ? (v) : 63)]++;
-#else
-#define MW_COUNT(i)
-#define MW_HIST(w, v)
-#endif
 template <typename T>
 MW_HD void line_eval(const Env<T> e, T alpha, const T* quadGauss, T* cost, T* d1, T* d2, T* mag = nullptr) {
     // *mag: sum of the magnitudes that cancel inside d1 (rounding-noise scale of the derivative, fp32 termination)
@@ -891,7 +887,8 @@ MW_HD void solve_impl(const Env<T> e) {
 }
 
 template <typename T>
-MW_STAGE_FN void solve(const Env<T> e) {
+MW_STAGE_FN void solve(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nv = m.sz.nv;
@@ -913,7 +910,8 @@ inline double* mw_prof() { static double t[8] = {0}; return t; }
 #define MW_STAGE(i, call) call;
 #endif
 template <typename T>
-MW_STAGE_FN void forward(const Env<T> e) {
+MW_STAGE_FN void forward(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
     MW_STAGE(0, kinematics(e))
     MW_STAGE(1, crb(e))
     MW_STAGE(2, collision(e))
@@ -923,7 +921,8 @@ MW_STAGE_FN void forward(const Env<T> e) {
 }
 
 template <typename T>
-MW_STAGE_FN void substep(const Env<T> e) {
+MW_STAGE_FN void substep(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nv = m.sz.nv;

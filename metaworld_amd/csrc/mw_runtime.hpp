@@ -148,6 +148,7 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Env<T>* e, int* gid)
     const int lane = (block - G.block0) * BLOCK + thread;
     if (lane >= G.nenv) return false;
     e->m = &G.m; e->col = G.col + lane; e->icol = G.icol + lane; e->stride = (unsigned)G.stride;
+    e->cache_layout(G.L, G.m.sz.nv);
     *gid = G.gid[lane];
     return true;
 }

@@ -98,9 +98,9 @@ MW_HD void scipy_quat(const M3<T>& R, T* q) {
     for (int c = 0; c < 4; c++) q[c] /= n;
 }
 
-template <typename T> MW_HD GRef<T> TK(const Env<T> e, int k) { return e.R(e.lay().task + k); }
-template <typename T> MW_HD V3<T> tk3(const Env<T> e, int k) { return ld3(e, e.lay().task + k); }
-template <typename T> MW_HD void set_tk3(const Env<T> e, int k, V3<T> v) { st3(e, e.lay().task + k, v); }
+template <typename T> MW_HD GRef<T> TK(const Env<T> e, int k) { return e.R(e.o_task + k); }
+template <typename T> MW_HD V3<T> tk3(const Env<T> e, int k) { return ld3(e, e.o_task + k); }
+template <typename T> MW_HD void set_tk3(const Env<T> e, int k, V3<T> v) { st3(e, e.o_task + k, v); }
 
 template <typename T>
 MW_HD V3<T> tcp_center(const Env<T> e, const TaskDesc<T>& td) {
@@ -577,7 +577,7 @@ MW_HD void dial_reset(const Env<T> e, const TaskDesc<T>& td) {
     set_tk3(e, TK_OBJINIT, rv0);
     set_tk3(e, TK_TARGET, rv0 + v3<T>(0, T(0.03), T(0.03)));
     set_reloc(e, td, 0, rv0);
-    st3(e, e.lay().task + TK_EXTRA, dial_pos(e, td) + v3<T>(T(0.05), T(0.02), T(0.09)));   // dial_push_position (stale FK, like the reference)
+    st3(e, e.o_task + TK_EXTRA, dial_pos(e, td) + v3<T>(T(0.05), T(0.02), T(0.09)));   // dial_push_position (stale FK, like the reference)
 }
 template <typename T>
 MW_HD Out dial_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
@@ -743,7 +743,7 @@ MW_HD void handle_reset(const Env<T> e, const TaskDesc<T>& td) {
     set_joint(e, 9, 9, (td.kind == 23 || td.kind == 24) ? T(-0.001) : T(-0.1));
     set_tk3(e, TK_TARGET, probe_pos(e, td.probe[P_X0]));
     const V3<T> h0 = probe_pos(e, td.probe[P_OBJ0]);
-    st3(e, e.lay().task + TK_EXTRA, h0);
+    st3(e, e.o_task + TK_EXTRA, h0);
     if (td.kind == 25) set_tk3(e, TK_OBJINIT, h0);      // handle-pull-side re-captures obj_init_pos; handle-pull keeps rand_vec
 }
 template <typename T>
@@ -789,7 +789,7 @@ MW_HD void lever_reset(const Env<T> e, const TaskDesc<T>& td) {
     const V3<T> rv0 = tk3(e, TK_RANDVEC);
     set_tk3(e, TK_OBJINIT, rv0);
     set_reloc(e, td, 0, rv0);
-    st3(e, e.lay().task + TK_EXTRA, rv0 + v3<T>(T(0.12), T(-0.2), T(0.25)));
+    st3(e, e.o_task + TK_EXTRA, rv0 + v3<T>(T(0.12), T(-0.2), T(0.25)));
     set_tk3(e, TK_TARGET, rv0 + v3<T>(T(0.12), 0, T(0.25 + 0.2)));
 }
 template <typename T>
@@ -816,7 +816,7 @@ MW_HD void window_reset(const Env<T> e, const TaskDesc<T>& td) {
     set_tk3(e, TK_TARGET, td.kind == 48 ? rv0 + v3<T>(T(0.2), 0, 0) : rv0);
     set_reloc(e, td, 0, rv0);
     const V3<T> h = probe_pos(e, td.probe[P_OBJ0]);                      // stale FK, like the reference
-    st3(e, e.lay().task + TK_EXTRA, td.kind == 48 ? h : h + v3<T>(T(0.2), 0, 0));
+    st3(e, e.o_task + TK_EXTRA, td.kind == 48 ? h : h + v3<T>(T(0.2), 0, 0));
     e.R(e.lay().qpos + td.qadr[0]) = td.kind == 48 ? T(0) : T(0.2);          // data.joint("window_slide").qpos = ... (no forward)
 }
 template <typename T>
@@ -941,7 +941,7 @@ MW_HD void basketball_reset(const Env<T> e, const TaskDesc<T>& td) {
     set_tk3(e, TK_OBJINIT, oi);
     set_reloc(e, td, 0, rv1);
     set_obj_xyz(e, oi);
-    st3(e, e.lay().task + TK_EXTRA, probe_pos(e, td.probe[P_X0]));   // hoop site position for local pos 0 (= B + c)
+    st3(e, e.o_task + TK_EXTRA, probe_pos(e, td.probe[P_X0]));   // hoop site position for local pos 0 (= B + c)
 }
 template <typename T>
 MW_HD Out basketball_eval(const Env<T> e, const TaskDesc<T>& td, const T* obs, const T* act) {
@@ -1011,7 +1011,7 @@ MW_HD void misc_reset(const Env<T> e, const TaskDesc<T>& td) {
         set_obj_xyz(e, oi);
     } else if (td.kind == 35) {
         set_tk3(e, TK_OBJINIT, rv0);
-        st3(e, e.lay().task + TK_EXTRA, probe_pos(e, td.probe[P_X0]));           // peg_head_pos_init (before the peg is placed)
+        st3(e, e.o_task + TK_EXTRA, probe_pos(e, td.probe[P_X0]));           // peg_head_pos_init (before the peg is placed)
         set_obj_xyz(e, rv0);
         set_reloc(e, td, 0, rv1);
         set_tk3(e, TK_TARGET, rv1 + v3<T>(T(0.03), 0, T(0.13)));
@@ -1102,7 +1102,7 @@ MW_HD void stick_reset(const Env<T> e, const TaskDesc<T>& td) {
     reset_hand(e, td);
     const V3<T> rv0 = tk3(e, TK_RANDVEC), rv1 = tk3(e, TK_RANDVEC + 3);
     const V3<T> si{rv0.x, rv0.y, td.c[6]};
-    st3(e, e.lay().task + TK_EXTRA, si);
+    st3(e, e.o_task + TK_EXTRA, si);
     set_tk3(e, TK_TARGET, v3<T>(rv1.x, rv1.y, td.kind == 38 ? probe_pos(e, td.probe[P_OBJ2]).z : si.z));
     set_obj_xyz(e, si);                                           // _set_stick_xyz
     e.R(e.lay().qpos + 16) = 0; e.R(e.lay().qpos + 17) = td.kind == 38 ? T(0) : T(0.09);
@@ -1240,7 +1240,7 @@ template <typename T>
 MW_HD void task_after_reset(const Env<T> e, const TaskDesc<T>& td, V3<T> persist_before, T* obs39) {
     if (td.kind != 1) return;
     const V3<T> P = tk3(e, TK_EXTRA), s = persist_before + P * T(2);
-    st3(e, e.lay().task + TK_PERSIST, s);
+    st3(e, e.o_task + TK_PERSIST, s);
     set_tk3(e, TK_TARGET, P + s);
     // the reset observation is built from the FK that precedes the last site write: it shows s (= 2P + s_before), the
     // episode itself sees P + s

@@ -12,13 +12,14 @@ sys.path.insert(0, ROOT)
 from metaworld_amd.vector_env import MetaWorldGpuVectorEnv  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+warm = int(os.environ.get("MW_WARM", "10"))
 reps = 20
 names = ["kin", "crb", "coll", "cons", "smooth", "solve"]
 for task in sys.argv[2:]:
     env = MetaWorldGpuVectorEnv("MT1", task, num_envs=n, seed=0, precision="fp32")
     env.reset()
     rng = np.random.default_rng(0)
-    for _ in range(10):
+    for _ in range(warm):
         env.step(rng.uniform(-1, 1, (n, 4)).astype(np.float32))
     prev, out = 0.0, []
     for k in range(6):
