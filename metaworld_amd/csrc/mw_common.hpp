@@ -27,6 +27,17 @@
 
 namespace mw {
 
+// solver phase timers (shader clock), only in -DMW_SOLVER_TIMING device builds: accumulated in icount[4..11]
+#if defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define MW_TICK(var) const long long var = (long long)__builtin_amdgcn_s_memtime();
+#define MW_TOCK(e, L, slot, t0, t1) e.I(L.icount + 4 + (slot)) += (int)(((t1) - (t0)) >> 4);
+#define MW_TADD(e, L, slot, v) e.I(L.icount + 4 + (slot)) += (v);
+#else
+#define MW_TADD(e, L, slot, v)
+#define MW_TICK(var)
+#define MW_TOCK(e, L, slot, t0, t1)
+#endif
+
 // iteration counters / histograms of the host profile build (tests/host_harness.cpp with -DMW_PROFILE)
 #if defined(MW_PROFILE) && !defined(__HIPCC__)
 inline long* mw_cnt() { static long c[8] = {0}; return c; }
@@ -46,6 +57,8 @@ inline long* mw_hist() { static long h[4 * 64] = {0}; return h; }
 // mw_uniform() (v_readfirstlane) tells the compiler a value is wave-uniform.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MW_GLOBAL __attribute__((address_space(1)))
+#define MW_LDS __attribute__((address_space(3)))
+#define MW_LDS_STRIDE 64        /* words between consecutive scratchpad slots of one lane (= lanes per workgroup) */
 #define MW_CONST __attribute__((address_space(4)))
 __device__ inline unsigned mw_uniform(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ inline int mw_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -58,6 +71,8 @@ __device__ inline double mw_uniform(double x) { return __builtin_bit_cast(double
 #else
 #define MW_GLOBAL
 #define MW_CONST
+#define MW_LDS
+#define MW_LDS_STRIDE 1
 inline float mw_uniform(float x) { return x; }
 inline double mw_uniform(double x) { return x; }
 inline unsigned mw_uniform(unsigned x) { return x; }
@@ -75,7 +90,8 @@ enum { S_SATISFIED = 0, S_QUADRATIC = 1, S_CONE = 4 };
 constexpr int MAX_NV = 17;       // register-resident solver arrays are sized by this (NV_LARGE in mw_phys.hpp)
 constexpr int CON_STRIDE = 26;   // reals per contact record
 constexpr int CON_ISTRIDE = 4;   // ints per contact record
-constexpr int EFC_EXTRA = 8;     // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv
+constexpr int EFC_EXTRA = 11;    // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv, fri, info, state
+constexpr int SR_N = 7;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force
 constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a non-zero Jacobian entry
 
 struct Sizes {
@@ -143,10 +159,14 @@ inline Layout make_layout(const Sizes& s) {
     L.efcX = take(EFC_EXTRA * s.maxefc);
     L.nreal = o;
     o = 0;
-    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(4);
+    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(12);   // + 8 solver phase timers (MW_SOLVER_TIMING builds)
     L.nint = o;
     return L;
 }
+
+// workgroup scratchpad handed to every lane program: LDS on the device (slot k of a lane at base[k * 64 + thread]),
+// a private buffer per host thread in the test harness
+struct Scratchpad { MW_LDS void* base; int words_per_lane; };   // 4-byte words available to each lane
 
 template <typename T> using CModel = const MW_CONST Model<T>;
 using CLayout = const MW_CONST Layout;
@@ -161,6 +181,12 @@ struct Env {
     int* icol;     // int column store, already offset by the lane
     unsigned stride;   // 32-bit index arithmetic: nreal * stride < 2^32 (checked at group creation)
     int nv, o_efcJ, o_efcX, o_con, o_icon, o_iefc, o_icount, o_task;   // hot layout offsets (copied from Layout)
+    MW_LDS T* lds;     // this lane's slice of the workgroup scratchpad (LDS on the device), slot k at lds[k * MW_LDS_STRIDE]
+    int lds_rows;      // constraint rows whose solver scalars fit in the scratchpad (the rest stay in the column store)
+    MW_HD void set_scratchpad(Scratchpad sp, int thread) {
+        lds = (MW_LDS T*)sp.base + (MW_LDS_STRIDE == 1 ? 0 : thread);
+        lds_rows = (int)(sp.words_per_lane * 4 / (SR_N * sizeof(T)));
+    }
     MW_HD void cache_layout(const Layout& L, int nv_) {
         nv = nv_; o_efcJ = L.efcJ; o_efcX = L.efcX; o_con = L.con; o_icon = L.icon; o_iefc = L.iefc; o_icount = L.icount; o_task = L.task;
     }
@@ -170,6 +196,7 @@ struct Env {
         u.stride = mw_uniform(stride);
         u.nv = mw_uniform(nv); u.o_efcJ = mw_uniform(o_efcJ); u.o_efcX = mw_uniform(o_efcX); u.o_con = mw_uniform(o_con);
         u.o_icon = mw_uniform(o_icon); u.o_iefc = mw_uniform(o_iefc); u.o_icount = mw_uniform(o_icount); u.o_task = mw_uniform(o_task);
+        u.lds_rows = mw_uniform(lds_rows);
         return u;
     }
     MW_HD CModel<T>& model() const { return *(CModel<T>*)(unsigned long long)m; }

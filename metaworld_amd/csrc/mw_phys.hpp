@@ -472,6 +472,8 @@ MW_HD int new_rows(const Env<T> e, int n, int type, int id) {
         IEFC(e, r0 + k, 3) = m.sz.nv; IEFC(e, r0 + k, 4) = -1;
         for (int i = 0; i < m.sz.nv; i++) EJ(e, r0 + k, i) = 0;
         EX(e, r0 + k, 0) = 0; EX(e, r0 + k, 1) = 0;
+        // solver row descriptor: type + 16 * (rows in this cone block) + 256 * (index inside the block)
+        EX(e, r0 + k, 8) = 0; EX(e, r0 + k, 9) = T(type + 16 * n + 256 * k);
     }
     nefc += n;
     return r0;
@@ -497,6 +499,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
         Q4<T> qr = qmul(q2n, qa);
         const int r0 = new_rows(e, 6, C_EQUALITY, q);
         if (r0 < 0) continue;
+        for (int k = 0; k < 6; k++) EX(e, r0 + k, 9) = T(C_EQUALITY + 16);
         for (int k = 0; k < 3; k++) {
             V3<T> ax{T(k == 0), T(k == 1), T(k == 2)};
             add_jac_row(e, r0 + k, b1, p1, ax, false, T(1));
@@ -565,8 +568,10 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
         finish_row(e, r0, solref, solimp, wt, &R0, &B, &imp);
         // friction rows: R scaled by friction ratios (impratio 1), aref = -B * vel
         const T f0 = CON(e, c, 14), f1 = CON(e, c, 15);
+        EX(e, r0, 8) = f0;   // mu
         for (int k = 1; k < dim; k++) {
             const T fk = k < 3 ? f0 : f1;
+            EX(e, r0 + k, 8) = fk;
             const T R = R0 * f0 * f0 / (fk * fk);
             T vel = 0;
             for (int i = IEFC(e, r0 + k, 3); i <= IEFC(e, r0 + k, 4); i++) vel += EJ(e, r0 + k, i) * e.R(L.qvel + i);
@@ -577,27 +582,62 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
 }
 
 // ------------------------------------------------------------------ Newton solver
-// cone bookkeeping for one contact at the current jar (offset `off` selects jar (6) or jar + alpha*Jv)
+// Solver row scalars.  The solver sweeps the constraint rows many times (cost/force updates, Hessian assembly and
+// every line-search evaluation); on the GPU each sweep is a chain of dependent memory round trips per row.  The
+// seven scalars a sweep needs (D, jar, Jv, friction scale, descriptor, state, force) therefore live in the
+// workgroup scratchpad (LDS, ~50-cycle reads instead of ~200-900) for the first `lds_rows` rows; rows beyond the
+// scratchpad capacity use slots of the row's record in the column store.  `info` = type + 16 * dim + 256 * k (k-th
+// row of a dim-row cone block); the rows of a block are visited from its first row with a wave-uniform counter.
+enum { SR_D = 0, SR_JAR, SR_JV, SR_FRI, SR_INFO, SR_STATE, SR_FORCE };
+MW_HD constexpr int sr_slot(int f) { return f == SR_D ? 3 : f == SR_JAR ? 6 : f == SR_JV ? 7 : f == SR_FRI ? 8 : f == SR_INFO ? 9 : f == SR_STATE ? 10 : 5; }
 template <typename T>
-struct ConeEval { T mu, fri[4], U[4], N, Tn; int dim, zone; };   // zone: 0 top, 1 bottom(quadratic), 2 middle
+MW_HD T sr_get(const Env<T> e, int i, int f) {
+    if (i < e.lds_rows) return e.lds[(i * SR_N + f) * MW_LDS_STRIDE];
+    return EX(e, i, sr_slot(f));
+}
 template <typename T>
-MW_HD ConeEval<T> cone_eval(const Env<T> e, int r0, int c, T alpha) {
-    // fixed 4-row form (rows >= dim are masked and re-read row r0): all indices are compile-time, so U / fri stay
-    // in registers instead of a dynamically indexed private array
+MW_HD void sr_set(const Env<T> e, int i, int f, T v) {
+    if (i < e.lds_rows) e.lds[(i * SR_N + f) * MW_LDS_STRIDE] = v;
+    else EX(e, i, sr_slot(f)) = v;
+}
+
+// Row accessors for the sweep bodies: Rows<T, true> reads the scratchpad unconditionally (the caller has checked
+// that row i .. i+3 are inside it), Rows<T, false> takes the per-access generic path.  Instantiating each sweep body
+// for both keeps the scratchpad reads of one row in a single basic block (issued back to back, one wait).
+template <typename T, bool IN_LDS>
+struct Rows {
+    Env<T> e;
+    MW_HD T get(int i, int f) const {
+        if (IN_LDS) return e.lds[(i * SR_N + f) * MW_LDS_STRIDE];
+        return sr_get(e, i, f);
+    }
+    MW_HD void set(int i, int f, T v) const {
+        if (IN_LDS) e.lds[(i * SR_N + f) * MW_LDS_STRIDE] = v;
+        else sr_set(e, i, f, v);
+    }
+};
+
+// cone bookkeeping for one contact at jar + alpha * Jv; fixed 4-row form (rows >= dim are masked and re-read row r0):
+// every index is compile-time, so U / fri stay in registers instead of a dynamically indexed private array
+template <typename T>
+struct ConeEval { T mu, fri[4], U[4], D[4], jv[4], x[4], N, Tn; int dim, zone; };   // zone: 0 top, 1 bottom(quadratic), 2 middle
+template <typename T, typename R>
+MW_HD ConeEval<T> cone_eval(const R& rows, int r0, int dim, T alpha) {
     ConeEval<T> z;
-    z.dim = ICON(e, c, 2);
-    z.mu = CON(e, c, 24);
-    const T f0 = CON(e, c, 14), f1 = CON(e, c, 15);
+    z.dim = dim;
     T tt = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const bool on = k < z.dim;
+        const bool on = k < dim;
         const int r = on ? r0 + k : r0;
-        z.fri[k] = k == 0 ? z.mu : (k < 3 ? f0 : f1);
-        const T x = EX(e, r, 6) + alpha * EX(e, r, 7);
-        z.U[k] = on ? x * z.fri[k] : T(0);
+        z.fri[k] = rows.get(r, SR_FRI);
+        z.D[k] = rows.get(r, SR_D);
+        z.jv[k] = rows.get(r, SR_JV);
+        z.x[k] = rows.get(r, SR_JAR) + alpha * z.jv[k];
+        z.U[k] = on ? z.x[k] * z.fri[k] : T(0);
         if (k > 0) tt += z.U[k] * z.U[k];
     }
+    z.mu = z.fri[0];
     z.N = z.U[0];
     z.Tn = mw_sqrt(tt);
     if (z.N >= z.mu * z.Tn || (z.Tn <= 0 && z.N >= 0)) z.zone = 0;
@@ -606,50 +646,57 @@ MW_HD ConeEval<T> cone_eval(const Env<T> e, int r0, int c, T alpha) {
     return z;
 }
 
+// one row (or cone block) of update_constraint: force, state, cost
+template <typename T, typename R>
+MW_HD void uc_row(const R& rows, const Env<T> e, int i, T* cost) {
+    const int info = (int)rows.get(i, SR_INFO), type = info & 15;
+    if (info >= 256) return;                    // inside a cone block: handled from the block's first row
+    const T D = rows.get(i, SR_D), jar = rows.get(i, SR_JAR);
+    if (type == C_EQUALITY || (type == C_LIMIT && jar < 0)) {
+        const T f = -D * jar;
+        *cost += T(0.5) * D * jar * jar;
+        rows.set(i, SR_FORCE, f); rows.set(i, SR_STATE, T(S_QUADRATIC)); EX(e, i, 5) = f;
+    } else if (type == C_LIMIT) {
+        rows.set(i, SR_FORCE, T(0)); rows.set(i, SR_STATE, T(S_SATISFIED)); EX(e, i, 5) = 0;
+    } else {
+        const int dim = (info >> 4) & 15;
+        ConeEval<T> z = cone_eval<T>(rows, i, dim, T(0));
+        int st;
+        T f[4] = {0, 0, 0, 0};
+        if (z.zone == 0) {
+            st = S_SATISFIED;
+        } else if (z.zone == 1) {
+            st = S_QUADRATIC;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < dim) { f[k] = -z.D[k] * z.x[k]; *cost += T(0.5) * z.D[k] * z.x[k] * z.x[k]; }
+        } else {
+            st = S_CONE;
+            const T Dm = D / (z.mu * z.mu * (1 + z.mu * z.mu)), NmT = z.N - z.mu * z.Tn;
+            *cost += T(0.5) * Dm * NmT * NmT;
+            const T f0 = -Dm * NmT * z.mu;
+            f[0] = f0;
+#pragma unroll
+            for (int k = 1; k < 4; k++) f[k] = -f0 / z.Tn * z.U[k] * z.fri[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k < dim) { rows.set(i + k, SR_FORCE, f[k]); rows.set(i + k, SR_STATE, T(st)); EX(e, i + k, 5) = f[k]; }
+    }
+}
+
 // cost, forces, states at the current jar; qfrc_constraint = J' force; returns total cost incl. Gauss term
 template <typename T, int NV>
 MW_STAGE_FN T update_constraint(const Env<T> e_) {
     const Env<T> e = e_.uniform();
-    CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    const int nv = m.sz.nv, nefc = e.I(L.icount + 1);
+    const int nv = e.nv, nefc = e.I(L.icount + 1);
     T cost = 0;
+    const Rows<T, true> fast{e};
+    const Rows<T, false> slow{e};
     for (int i = 0; i < nefc; i++) {
-        const int type = IEFC(e, i, 0);
-        const T D = EX(e, i, 3), jar = EX(e, i, 6);
-        if (type == C_EQUALITY || (type == C_LIMIT && jar < 0)) {
-            EX(e, i, 5) = -D * jar; cost += T(0.5) * D * jar * jar; IEFC(e, i, 2) = S_QUADRATIC;
-        } else if (type == C_LIMIT) {
-            EX(e, i, 5) = 0; IEFC(e, i, 2) = S_SATISFIED;
-        } else {
-            const int c = IEFC(e, i, 1);
-            if (!cone_leader(e, i, c)) continue;
-            ConeEval<T> z = cone_eval(e, i, c, T(0));
-            int st;
-            T f[4] = {0, 0, 0, 0};
-            if (z.zone == 0) {
-                st = S_SATISFIED;
-            } else if (z.zone == 1) {
-                st = S_QUADRATIC;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int r = k < z.dim ? i + k : i;
-                    const T Dk = EX(e, r, 3), x = EX(e, r, 6);
-                    if (k < z.dim) { f[k] = -Dk * x; cost += T(0.5) * Dk * x * x; }
-                }
-            } else {
-                st = S_CONE;
-                const T Dm = D / (z.mu * z.mu * (1 + z.mu * z.mu)), NmT = z.N - z.mu * z.Tn;
-                cost += T(0.5) * Dm * NmT * NmT;
-                const T f0 = -Dm * NmT * z.mu;
-                f[0] = f0;
-#pragma unroll
-                for (int k = 1; k < 4; k++) f[k] = -f0 / z.Tn * z.U[k] * z.fri[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (k < z.dim) { EX(e, i + k, 5) = f[k]; IEFC(e, i + k, 2) = st; }
-        }
+        if (i + 4 <= e.lds_rows) uc_row<T>(fast, e, i, &cost);
+        else uc_row<T>(slow, e, i, &cost);
     }
     T gauss = 0;
     for (int k = 0; k < nv; k++)
@@ -658,7 +705,7 @@ MW_STAGE_FN T update_constraint(const Env<T> e_) {
 #pragma unroll
     for (int k = 0; k < NV; k++) qf[k] = 0;
     for (int i = 0; i < nefc; i++) {      // J' f over the active rows, accumulated in registers
-        const T f = EX(e, i, 5);
+        const T f = sr_get(e, i, SR_FORCE);
         if (f == 0) continue;
         T j[NV];
         jrow_load<T, NV>(e, i, nv, j);
@@ -669,47 +716,55 @@ MW_STAGE_FN T update_constraint(const Env<T> e_) {
     return cost + T(0.5) * gauss;
 }
 
+// one row (or cone block) of the line-search cost: cost C, derivatives D1 / D2, cancellation magnitude A1
+template <typename T, typename R>
+MW_HD void le_row(const R& rows, int i, T alpha, T* C, T* D1, T* D2, T* A1) {
+    const int info = (int)rows.get(i, SR_INFO), type = info & 15;
+    if (info >= 256) return;
+    if (type != C_CONTACT) {
+        const T D = rows.get(i, SR_D), jv = rows.get(i, SR_JV), x0 = rows.get(i, SR_JAR), x = x0 + alpha * jv;
+        if (type == C_EQUALITY || x < 0) {
+            *C += T(0.5) * D * x * x; *D1 += D * x * jv; *D2 += D * jv * jv;
+            *A1 += D * (mw_abs(x0) + mw_abs(alpha * jv)) * mw_abs(jv);
+        }
+        return;
+    }
+    const int dim = (info >> 4) & 15;
+    ConeEval<T> z = cone_eval<T>(rows, i, dim, alpha);
+    if (z.zone == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const T Dk = z.D[k], jk = z.jv[k], xk = z.x[k];
+            if (k < dim) { *C += T(0.5) * Dk * xk * xk; *D1 += Dk * xk * jk; *D2 += Dk * jk * jk; *A1 += Dk * mw_abs(xk * jk); }
+        }
+    } else if (z.zone == 2) {
+        T UV = 0, VV = 0;
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            const T v = k < dim ? z.jv[k] * z.fri[k] : T(0);
+            UV += z.U[k] * v; VV += v * v;
+        }
+        const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu));
+        const T N1 = z.jv[0] * z.mu, T1 = UV / z.Tn, T2 = VV / z.Tn - UV * T1 / (z.Tn * z.Tn);
+        const T NmT = z.N - z.mu * z.Tn, g = N1 - z.mu * T1;
+        *C += T(0.5) * Dm * NmT * NmT; *D1 += Dm * NmT * g; *D2 += Dm * (g * g - NmT * z.mu * T2);
+        *A1 += Dm * (mw_abs(z.N) + z.mu * z.Tn) * (mw_abs(N1) + z.mu * mw_abs(T1));
+    }
+}
+
 // constraint part of the cost (no forces written) at jar + alpha*Jv, with 1st/2nd derivatives along the line
+// *mag: sum of the magnitudes that cancel inside d1 (rounding-noise scale of the derivative, fp32 termination)
 template <typename T>
-MW_HD void line_eval(const Env<T> e, T alpha, const T* quadGauss, T* cost, T* d1, T* d2, T* mag = nullptr) {
-    // *mag: sum of the magnitudes that cancel inside d1 (rounding-noise scale of the derivative, fp32 termination)
+MW_HD void line_eval(const Env<T> e, int nefc, T alpha, const T* quadGauss, T* cost, T* d1, T* d2, T* mag = nullptr) {
     MW_COUNT(0)
-    const int nefc = e.I(e.lay().icount + 1);
     T C = alpha * alpha * quadGauss[2] + alpha * quadGauss[1] + quadGauss[0];
     T D1 = 2 * alpha * quadGauss[2] + quadGauss[1], D2 = 2 * quadGauss[2];
     T A1 = mw_abs(2 * alpha * quadGauss[2]) + mw_abs(quadGauss[1]);
+    const Rows<T, true> fast{e};
+    const Rows<T, false> slow{e};
     for (int i = 0; i < nefc; i++) {
-        const int type = IEFC(e, i, 0);
-        const T D = EX(e, i, 3), jv = EX(e, i, 7), x0 = EX(e, i, 6), x = x0 + alpha * jv;
-        if (type == C_EQUALITY || (type == C_LIMIT && x < 0)) {
-            C += T(0.5) * D * x * x; D1 += D * x * jv; D2 += D * jv * jv;
-            A1 += D * (mw_abs(x0) + mw_abs(alpha * jv)) * mw_abs(jv);
-        } else if (type == C_CONTACT) {
-            const int c = IEFC(e, i, 1);
-            if (!cone_leader(e, i, c)) continue;
-            ConeEval<T> z = cone_eval(e, i, c, alpha);
-            if (z.zone == 1) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int r = k < z.dim ? i + k : i;
-                    const T Dk = EX(e, r, 3), jk = EX(e, r, 7), xk = EX(e, r, 6) + alpha * jk;
-                    if (k < z.dim) { C += T(0.5) * Dk * xk * xk; D1 += Dk * xk * jk; D2 += Dk * jk * jk; A1 += Dk * mw_abs(xk * jk); }
-                }
-            } else if (z.zone == 2) {
-                T UV = 0, VV = 0;
-#pragma unroll
-                for (int k = 1; k < 4; k++) {
-                    const T jk = EX(e, k < z.dim ? i + k : i, 7);
-                    const T v = k < z.dim ? jk * z.fri[k] : T(0);
-                    UV += z.U[k] * v; VV += v * v;
-                }
-                const T Dm = D / (z.mu * z.mu * (1 + z.mu * z.mu));
-                const T N1 = EX(e, i, 7) * z.mu, T1 = UV / z.Tn, T2 = VV / z.Tn - UV * T1 / (z.Tn * z.Tn);
-                const T NmT = z.N - z.mu * z.Tn, g = N1 - z.mu * T1;
-                C += T(0.5) * Dm * NmT * NmT; D1 += Dm * NmT * g; D2 += Dm * (g * g - NmT * z.mu * T2);
-                A1 += Dm * (mw_abs(z.N) + z.mu * z.Tn) * (mw_abs(N1) + z.mu * mw_abs(T1));
-            }
-        }
+        if (i + 4 <= e.lds_rows) le_row<T>(fast, i, alpha, &C, &D1, &D2, &A1);
+        else le_row<T>(slow, i, alpha, &C, &D1, &D2, &A1);
     }
     *cost = C; *d1 = D1; *d2 = D2;
     if (mag) *mag = A1;
@@ -719,8 +774,17 @@ template <typename T, int NV>
 MW_HD void solve_impl(const Env<T> e) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    const int nv = m.sz.nv, nefc = e.I(L.icount + 1);
+    const int nv = e.nv, nefc = e.I(L.icount + 1);
     constexpr int NT = NV * (NV + 1) / 2;
+    MW_TICK(t_a)
+    {   // stage the static row scalars into the scratchpad
+        for (int i = 0; i < nefc; i++) {
+            if (i >= e.lds_rows) { EX(e, i, 7) = 0; continue; }
+            const T D = EX(e, i, 3), fri = EX(e, i, 8), info = EX(e, i, 9);
+            sr_set(e, i, SR_D, D); sr_set(e, i, SR_FRI, fri); sr_set(e, i, SR_INFO, info);
+            sr_set(e, i, SR_JV, T(0));   // read (times alpha = 0) before the first search direction exists
+        }
+    }
     auto set_point = [&](int src) {   // qacc <- src ; Ma, jar
         T x[NV], y[NV];
         vec_load<T, NV>(e, src, nv, x);
@@ -732,7 +796,7 @@ MW_HD void solve_impl(const Env<T> e) {
             jrow_load<T, NV>(e, i, nv, j);
 #pragma unroll
             for (int k = 0; k < NV; k++) s += j[k] * x[k];
-            EX(e, i, 6) = s;
+            sr_set(e, i, SR_JAR, s);
         }
     };
     // warm start: the better of qacc_warmstart and qacc_smooth (ties go to the warm start)
@@ -742,27 +806,29 @@ MW_HD void solve_impl(const Env<T> e) {
     T cost = update_constraint<T, NV>(e);
     if (cost > cs) { set_point(L.qacc_smooth); cost = update_constraint<T, NV>(e); }
     const T scale = 1 / (m.meaninertia * T(nv > 1 ? nv : 1));
+    MW_TICK(t_b)
+    MW_TOCK(e, L, 0, t_a, t_b)
     MW_COUNT(2)
     for (int iter = 0; iter < m.sz.iterations; iter++) {
         MW_COUNT(1)
         T gn = 0, sr[NV];             // sr: gradient, then the search direction
 #pragma unroll
         for (int k = 0; k < NV; k++) {
-            sr[k] = 0;
-            if (k < nv) {
-                const T g = e.R(L.Ma + k) - e.R(L.smooth + k) - e.R(L.qfrc_c + k);
-                sr[k] = -g; gn += g * g;
-            }
+            const int kk = k < nv ? k : 0;
+            const T g = e.R(L.Ma + kk) - e.R(L.smooth + kk) - e.R(L.qfrc_c + kk);
+            sr[k] = k < nv ? -g : T(0);
+            if (k < nv) gn += g * g;
         }
         if (scale * mw_sqrt(gn) < m.tolerance) break;
+        MW_TICK(t_c)
         {
             // H = M + J' D J over quadratic rows (+ dense cone blocks): lower triangle in registers, Cholesky, solve
             T H[NT];
             tri_load<T, NV>(e, L.qM, nv, H);
             for (int i = 0; i < nefc; i++) {
-                const int st = IEFC(e, i, 2);
+                const int st = (int)sr_get(e, i, SR_STATE);
                 if (st == S_QUADRATIC) {
-                    const T D = EX(e, i, 3);
+                    const T D = sr_get(e, i, SR_D);
                     T j[NV];
                     jrow_load<T, NV>(e, i, nv, j);
 #pragma unroll
@@ -774,10 +840,11 @@ MW_HD void solve_impl(const Env<T> e) {
                         for (int b = 0; b <= a; b++) H[tri(a, b)] += Da * j[b];
                     }
                 } else if (st == S_CONE) {
-                    const int c = IEFC(e, i, 1);
-                    if (!cone_leader(e, i, c)) continue;
-                    ConeEval<T> z = cone_eval(e, i, c, T(0));
-                    const T Dm = EX(e, i, 3) / (z.mu * z.mu * (1 + z.mu * z.mu));
+                    const int info = (int)sr_get(e, i, SR_INFO);
+                    if (info >= 256) continue;
+                    const int dim = (info >> 4) & 15;
+                    ConeEval<T> z = cone_eval<T>(Rows<T, false>{e}, i, dim, T(0));
+                    const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu));
                     T Hc[16];
                     const T scl = z.mu * z.N / (z.Tn * z.Tn * z.Tn), dg = z.mu * z.mu - z.mu * z.N / z.Tn;
 #pragma unroll
@@ -789,12 +856,12 @@ MW_HD void solve_impl(const Env<T> e) {
                             else if (r == 0) h = -z.mu * z.U[s] / z.Tn;
                             else if (s == 0) h = -z.mu * z.U[r] / z.Tn;
                             else h = scl * z.U[r] * z.U[s] + (r == s ? dg : T(0));
-                            Hc[4 * r + s] = (r < z.dim && s < z.dim) ? h * Dm * z.fri[r] * z.fri[s] : T(0);
+                            Hc[4 * r + s] = (r < dim && s < dim) ? h * Dm * z.fri[r] * z.fri[s] : T(0);
                         }
                     T j[4][NV];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const bool on = r < z.dim;
+                        const bool on = r < dim;
                         jrow_load<T, NV>(e, on ? i + r : i, nv, j[r]);
 #pragma unroll
                         for (int a = 0; a < NV; a++) j[r][a] = (on && a < nv) ? j[r][a] : T(0);
@@ -818,9 +885,14 @@ MW_HD void solve_impl(const Env<T> e) {
                     }
                 }
             }
+            MW_TICK(t_d)
             chol_reg<T, NV>(H);
             chol_solve_reg<T, NV>(H, sr);
+            MW_TICK(t_e)
+            MW_TOCK(e, L, 1, t_c, t_d)
+            MW_TOCK(e, L, 2, t_d, t_e)
         }
+        MW_TICK(t_f)
         // ---- exact line search (safeguarded Newton on the 1-D convex cost) ----
         T snorm = 0, quadGauss[3] = {0, 0, 0};
         {
@@ -830,12 +902,13 @@ MW_HD void solve_impl(const Env<T> e) {
             vec_store<T, NV>(e, L.Mv, nv, Mv);
 #pragma unroll
             for (int k = 0; k < NV; k++) {
+                const int kk = k < nv ? k : 0;
+                const T sk = sr[k], r = e.R(L.Ma + kk) - e.R(L.smooth + kk), dq = e.R(L.qacc + kk) - e.R(L.qacc_smooth + kk);
                 if (k < nv) {
-                    const T sk = sr[k], r = e.R(L.Ma + k) - e.R(L.smooth + k);
                     snorm += sk * sk;
                     quadGauss[1] += sk * r;
                     quadGauss[2] += T(0.5) * sk * Mv[k];
-                    quadGauss[0] += T(0.5) * r * (e.R(L.qacc + k) - e.R(L.qacc_smooth + k));
+                    quadGauss[0] += T(0.5) * r * dq;
                 }
             }
         }
@@ -846,18 +919,20 @@ MW_HD void solve_impl(const Env<T> e) {
             jrow_load<T, NV>(e, i, nv, j);
 #pragma unroll
             for (int k = 0; k < NV; k++) s += j[k] * sr[k];
-            EX(e, i, 7) = s;
+            sr_set(e, i, SR_JV, s);
         }
         const T gtol = m.tolerance * T(0.01) * snorm / scale;
+        MW_TICK(t_g)
+        MW_TOCK(e, L, 3, t_f, t_g)
         T c0, d1, d2;
-        line_eval(e, T(0), quadGauss, &c0, &d1, &d2);
+        line_eval(e, nefc, T(0), quadGauss, &c0, &d1, &d2);
         if (d1 >= 0 || d2 <= 0) break;
         T lo = 0, hi = -1, alpha = -d1 / d2;
         int nls = 0;
         for (int it = 0; it < m.sz.ls_iterations; it++) {
             T ca, da, dda, mag;
             nls++;
-            line_eval(e, alpha, quadGauss, &ca, &da, &dda, &mag);
+            line_eval(e, nefc, alpha, quadGauss, &ca, &da, &dda, &mag);
             if (mw_abs(da) < gtol) break;
             // single precision: the derivative cannot be resolved below its own rounding noise (a few ulp of the
             // magnitudes that cancel inside it); without this test ~10 % of the searches ran to ls_iterations and,
@@ -873,13 +948,19 @@ MW_HD void solve_impl(const Env<T> e) {
         }
         MW_HIST(1, nls)
         (void)nls;
+        MW_TICK(t_h)
+        MW_TOCK(e, L, 4, t_g, t_h)
+        MW_TADD(e, L, 6, nls)
         if (alpha == 0) break;
 #pragma unroll
         for (int k = 0; k < NV; k++)
             if (k < nv) { e.R(L.qacc + k) += alpha * sr[k]; e.R(L.Ma + k) += alpha * e.R(L.Mv + k); }
-        for (int i = 0; i < nefc; i++) EX(e, i, 6) += alpha * EX(e, i, 7);
+        for (int i = 0; i < nefc; i++) sr_set(e, i, SR_JAR, sr_get(e, i, SR_JAR) + alpha * sr_get(e, i, SR_JV));
         const T old = cost;
         cost = update_constraint<T, NV>(e);
+        MW_TICK(t_i)
+        MW_TOCK(e, L, 5, t_h, t_i)
+        MW_TADD(e, L, 7, 1)
         e.I(L.icount + 2) = iter + 1;
         if (scale * (old - cost) < m.tolerance) break;
     }
@@ -889,9 +970,8 @@ MW_HD void solve_impl(const Env<T> e) {
 template <typename T>
 MW_STAGE_FN void solve(const Env<T> e_) {
     const Env<T> e = e_.uniform();
-    CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    const int nv = m.sz.nv;
+    const int nv = e.nv;
     e.I(L.icount + 2) = 0;
     if (e.I(L.icount + 1) == 0) {
         for (int k = 0; k < nv; k++) { e.R(L.qacc + k) = e.R(L.qacc_smooth + k); e.R(L.qfrc_c + k) = 0; }

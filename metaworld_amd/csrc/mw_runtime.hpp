@@ -5,7 +5,7 @@
 // The including file must define, before inclusion, a `Backend` struct with:
 //   static void* alloc(size_t bytes);  static void free(void*);  static void zero(void*, size_t);
 //   static void h2d(void* dst, const void* src, size_t);  static void d2h(void* dst, const void* src, size_t);
-//   template <class F> static void launch(int nblocks, F lane_program);   // F(block, thread) for 64 threads / block
+//   template <class F> static void launch(int nblocks, F lane_program);   // F(block, thread, Scratchpad) for 64 threads / block
 //   static void sync();
 #pragma once
 #include <string.h>
@@ -141,7 +141,8 @@ struct World {
 };
 
 template <typename T>
-MW_HD bool locate(const World<T>& w, int block, int thread, Env<T>* e, int* gid) {
+MW_HD bool locate(const World<T>& w, int block, int thread, Scratchpad sp, Env<T>* e, int* gid) {
+    e->set_scratchpad(sp, thread);
     int g = 0;
     while (g + 1 < w.ngroups && block >= w.groups[g + 1].block0) g++;
     const GroupDev<T>& G = w.groups[g];
@@ -173,9 +174,9 @@ MW_HD void load_snapshot(const World<T>& w, const Env<T> e, int task, int goal, 
 // ---- lane programs -------------------------------------------------------------------------
 // faithful reset (slow path; builds snapshots and serves explicit mw_reset_full)
 template <typename T>
-MW_HD void lane_reset_full(const World<T>& w, int block, int thread) {
+MW_HD void lane_reset_full(const World<T>& w, int block, int thread, Scratchpad sp) {
     Env<T> e; int gid;
-    if (!locate(w, block, thread, &e, &gid)) return;
+    if (!locate(w, block, thread, sp, &e, &gid)) return;
     const int task = (int)TK(e, TK_TASK);
     const TaskDesc<T>& td = w.tasks[task];
     T obs[39];
@@ -185,9 +186,9 @@ MW_HD void lane_reset_full(const World<T>& w, int block, int thread) {
 
 // reset from snapshot for masked envs (mask may be null = all); goal from io.next_goal
 template <typename T>
-MW_HD void lane_reset_snap(const World<T>& w, const uint8_t* mask, int block, int thread) {
+MW_HD void lane_reset_snap(const World<T>& w, const uint8_t* mask, int block, int thread, Scratchpad sp) {
     Env<T> e; int gid;
-    if (!locate(w, block, thread, &e, &gid)) return;
+    if (!locate(w, block, thread, sp, &e, &gid)) return;
     if (mask && !mask[gid]) return;
     const int task = (int)TK(e, TK_TASK);
     const TaskDesc<T>& td = w.tasks[task];
@@ -199,9 +200,9 @@ MW_HD void lane_reset_snap(const World<T>& w, const uint8_t* mask, int block, in
 // one VectorEnv.step for one env: SawyerXYZEnv.step + TimeLimit + AutoTerminateOnSuccess + OneHot +
 // RecordEpisodeStatistics + SAME_STEP auto-reset (metaworld/__init__.py:430-454, :465)
 template <typename T>
-MW_HD void lane_step(const World<T>& w, int block, int thread) {
+MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     Env<T> e; int gid;
-    if (!locate(w, block, thread, &e, &gid)) return;
+    if (!locate(w, block, thread, sp, &e, &gid)) return;
     const int task = (int)TK(e, TK_TASK);
     const TaskDesc<T>& td = w.tasks[task];
     T act[4], obs[39], reward, success;
@@ -232,9 +233,9 @@ MW_HD void lane_step(const World<T>& w, int block, int thread) {
 
 // debugging / parity hooks: run raw physics on every lane
 template <typename T>
-MW_HD void lane_debug(const World<T>& w, int what, int n, int block, int thread) {
+MW_HD void lane_debug(const World<T>& w, int what, int n, int block, int thread, Scratchpad sp) {
     Env<T> e; int gid;
-    if (!locate(w, block, thread, &e, &gid)) return;
+    if (!locate(w, block, thread, sp, &e, &gid)) return;
     if (what == 0) forward(e);
     else if (what == 1) for (int k = 0; k < n; k++) substep(e);
     else if (what == 2) reset_data(e);
@@ -455,7 +456,7 @@ public:
             double* d_o = (double*)Backend::alloc(sizeof(double) * g.nenv * D);
             World<T> w = world(false);
             w.groups = d_g; w.ngroups = 1; w.io.obs = d_o; w.io.D = D;
-            Backend::launch((g.nenv + BLOCK - 1) / BLOCK, [w] MW_LAMBDA(int b, int t) { lane_reset_full(w, b, t); });
+            Backend::launch((g.nenv + BLOCK - 1) / BLOCK, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_full(w, b, t, sp); });
             Backend::sync();
             Backend::d2h(host.data(), g.col, host.size() * sizeof(T));
             std::vector<double> obs((size_t)g.nenv * D);
@@ -482,7 +483,7 @@ public:
         const uint8_t* dm = nullptr;
         if (mask) { Backend::h2d(d_mask_, mask, N_); dm = d_mask_; }
         World<T> w = world();
-        Backend::launch(nblocks_, [w, dm] MW_LAMBDA(int b, int t) { lane_reset_snap(w, dm, b, t); });
+        Backend::launch(nblocks_, [w, dm] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_snap(w, dm, b, t, sp); });
         Backend::sync();
         if (obs_out) Backend::d2h(obs_out, d_obs_, sizeof(double) * N_ * obs_dim());
     }
@@ -492,7 +493,7 @@ public:
         Backend::h2d(d_act_, act, sizeof(float) * 4 * N_);
         if (next_goal) Backend::h2d(d_next_goal_, next_goal, sizeof(int) * N_);
         World<T> w = world();
-        Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t) { lane_step(w, b, t); });
+        Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
         Backend::sync();
         const int D = obs_dim();
         if (obs) Backend::d2h(obs, d_obs_, sizeof(double) * N_ * D);
@@ -522,7 +523,7 @@ public:
         Backend::timed_begin();
         for (int s = 0; s < nsteps; s++) {
             w.io.act = base + (size_t)(act_steps > 0 ? s % act_steps : 0) * 4 * N_;
-            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t) { lane_step(w, b, t); });
+            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
         }
         float ms = Backend::timed_end();
         if (kernel_ms) *kernel_ms = ms;
@@ -530,7 +531,7 @@ public:
 
     void debug(int what, int n) override {
         World<T> w = world();
-        Backend::launch(nblocks_, [w, what, n] MW_LAMBDA(int b, int t) { lane_debug(w, what, n, b, t); });
+        Backend::launch(nblocks_, [w, what, n] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_debug(w, what, n, b, t, sp); });
         Backend::sync();
     }
 
@@ -549,7 +550,7 @@ public:
     static int ioffset_of(const Layout& L, const Sizes& s, const std::string& k, int* n) {
         if (k == "icon") { *n = CON_ISTRIDE * s.maxcon; return L.icon; }
         if (k == "iefc") { *n = EFC_ISTRIDE * s.maxefc; return L.iefc; }
-        if (k == "icount") { *n = 4; return L.icount; }
+        if (k == "icount") { *n = 12; return L.icount; }
         throw std::runtime_error("unknown int column " + k);
     }
     int layout_size(int gid, const char* what) override {

@@ -5,6 +5,8 @@
 // mw_common.hpp, so each per-env load/store of a wave is one coalesced request.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <stdexcept>
 #include <string>
 
@@ -14,8 +16,15 @@ namespace {
 inline void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
+}  // namespace
+#include "mw_common.hpp"
+namespace {
+// one wavefront per workgroup; the dynamic LDS allocation is the lanes' scratchpad (solver row scalars, mw_phys.hpp)
 template <class F>
-__global__ void __launch_bounds__(64) k_lanes(F f) { f((int)blockIdx.x, (int)threadIdx.x); }
+__global__ void __launch_bounds__(64) k_lanes(F f, int words_per_lane) {
+    extern __shared__ float mw_scratchpad[];
+    f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, words_per_lane});
+}
 
 struct Backend {
     static hipStream_t& stream() { static hipStream_t s = nullptr; return s; }
@@ -25,6 +34,8 @@ struct Backend {
         hip_check(hipGetDeviceCount(&n), "hipGetDeviceCount");
         if (n <= 0) throw std::runtime_error("libmwgpu: no HIP device visible (this library has no CPU fallback)");
         hip_check(hipSetDevice(device), "hipSetDevice");
+        hip_check(hipDeviceGetAttribute(&max_lds(), hipDeviceAttributeMaxSharedMemoryPerBlock, device), "hipDeviceGetAttribute");
+        hip_check(hipDeviceGetAttribute(&num_cu(), hipDeviceAttributeMultiprocessorCount, device), "hipDeviceGetAttribute");
         if (!stream()) {
             hip_check(hipStreamCreateWithFlags(&stream(), hipStreamNonBlocking), "hipStreamCreate");
             hip_check(hipEventCreate(&events()[0]), "hipEventCreate");
@@ -42,9 +53,27 @@ struct Backend {
         hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream()), "hipMemcpy D2H");
         hip_check(hipStreamSynchronize(stream()), "sync");
     }
+    // LDS per workgroup: everything a CU has when the grid leaves one wave per CU, an equal share when several
+    // workgroups must share a CU (the 512-VGPR lane programs allow at most one wave per SIMD, i.e. 4 per CU).
+    // MW_LDS_BYTES overrides (experiments / tests of the column-store fallback rows).
+    static int& max_lds() { static int v = 65536; return v; }
+    static int& num_cu() { static int v = 256; return v; }
+    static int lds_bytes(int nblocks) {
+        static const char* ov = getenv("MW_LDS_BYTES");
+        if (ov) return atoi(ov);
+        int per_cu = (nblocks + num_cu() - 1) / num_cu();
+        per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+        return (max_lds() / per_cu) & ~1023;
+    }
     template <class F>
     static void launch(int nblocks, F f) {
-        hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), 0, stream(), f);
+        static int configured = 0;
+        const int bytes = lds_bytes(nblocks);
+        if (bytes > configured) {
+            hip_check(hipFuncSetAttribute((const void*)k_lanes<F>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute(LDS)");
+            configured = bytes;
+        }
+        hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), bytes, stream(), f, bytes / 4 / 64);
         hip_check(hipGetLastError(), "kernel launch");
     }
     static void sync() { hip_check(hipStreamSynchronize(stream()), "hipStreamSynchronize"); }

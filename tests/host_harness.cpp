@@ -3,12 +3,15 @@
 // the wavefronts, so that the kernel logic can be checked against the oracle in a container without a GPU.
 // Exports the ABI of include/mwgpu.h under the prefix mwh_.  Never loaded by the product path.
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #define MW_LAMBDA
+#include "../metaworld_amd/csrc/mw_common.hpp"
 
 namespace {
 struct Backend {
@@ -18,11 +21,19 @@ struct Backend {
     static void zero(void* p, size_t bytes) { std::memset(p, 0, bytes); }
     static void h2d(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     static void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+    // scratchpad rows per lane: MW_LDS_ROWS (default 24, so that typical scenes exercise both the scratchpad rows
+    // and the column-store fallback rows of the solver)
+    static int lds_rows() { static int r = std::getenv("MW_LDS_ROWS") ? std::atoi(std::getenv("MW_LDS_ROWS")) : 24; return r; }
     template <class F>
     static void launch(int nblocks, F f) {
-#pragma omp parallel for schedule(dynamic)
-        for (int b = 0; b < nblocks; b++)
-            for (int t = 0; t < 64; t++) f(b, t);
+        const int words = lds_rows() * 7 * 2;   // SR_N doubles per row
+#pragma omp parallel
+        {
+            std::vector<double> pad((size_t)lds_rows() * 7 + 1, std::nan(""));   // LDS is not zero-initialised either
+#pragma omp for schedule(dynamic)
+            for (int b = 0; b < nblocks; b++)
+                for (int t = 0; t < 64; t++) f(b, t, mw::Scratchpad{pad.data(), words});
+        }
     }
     static void sync() {}
     static std::chrono::steady_clock::time_point& t0() { static std::chrono::steady_clock::time_point t; return t; }
