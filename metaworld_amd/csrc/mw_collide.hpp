@@ -23,11 +23,18 @@ struct Shape {
     CP<T> vert;
     int nvert;
     T margin;
+    // hill-climbing support for big hulls (metaworld_amd/mjcf.py add_mesh_graph): CSR adjacency of this mesh's vertices
+    // (local ids), 32 start candidates, and the vertex the previous support call on this shape ended at
+    CP<int> nbradr, nbr, start;
+    int hill;
+    mutable int hint;
     // everything except pos / mat is a model constant of the (wave-uniform) geom pair being tested
     MW_HD Shape uniform() const {
         Shape u = *this;
         u.type = mw_uniform(type); u.nvert = mw_uniform(nvert); u.margin = mw_uniform(margin);
         u.vert = (CP<T>)mw_uniform((unsigned long long)vert);
+        u.nbradr = (CP<int>)mw_uniform((unsigned long long)nbradr); u.nbr = (CP<int>)mw_uniform((unsigned long long)nbr);
+        u.start = (CP<int>)mw_uniform((unsigned long long)start); u.hill = mw_uniform(hill);
         for (int k = 0; k < 3; k++) u.size[k] = mw_uniform(size[k]);
         return u;
     }
@@ -309,10 +316,49 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
     case G_MESH: {
         int best = 0;
         T bd = T(-1e30);
+        if (s.hill) {
+            // steepest-ascent walk over the hull graph (MuJoCo's mesh-graph support): from the previous result on this
+            // shape, else from the best of the fixed start candidates; strict improvement only.  An exhaustive scan
+            // of the 884-vertex gripper hull cost ~20k cycles per call; the walk visits a few dozen vertices.
+            int cur;
+            if (s.hint >= 0) {
+                cur = s.hint;
+                bd = s.vert[3 * cur] * dl.x + s.vert[3 * cur + 1] * dl.y + s.vert[3 * cur + 2] * dl.z;
+            } else {
+                cur = s.start[0];
+                bd = s.vert[3 * cur] * dl.x + s.vert[3 * cur + 1] * dl.y + s.vert[3 * cur + 2] * dl.z;
+#pragma unroll 8
+                for (int k = 1; k < 32; k++) {
+                    const int c = s.start[k];
+                    const T dd = s.vert[3 * c] * dl.x + s.vert[3 * c + 1] * dl.y + s.vert[3 * c + 2] * dl.z;
+                    if (dd > bd) { bd = dd; cur = c; }
+                }
+            }
+            for (int it = 0; it < s.nvert; it++) {
+                int nxt = cur;
+                const int j0 = s.nbradr[cur], j1 = s.nbradr[cur + 1];
+                for (int jb = j0; jb < j1; jb += 8) {        // neighbours in batches of 8: ids, then coordinates, issued together
+                    int id[8];
+                    T dd[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) id[q] = s.nbr[jb + q < j1 ? jb + q : j1 - 1];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) dd[q] = s.vert[3 * id[q]] * dl.x + s.vert[3 * id[q] + 1] * dl.y + s.vert[3 * id[q] + 2] * dl.z;
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                        if (jb + q < j1 && dd[q] > bd) { bd = dd[q]; nxt = id[q]; }
+                }
+                if (nxt == cur) break;
+                cur = nxt;
+            }
+            s.hint = cur;
+            best = cur;
+        } else {
 #pragma unroll 4
-        for (int i = 0; i < s.nvert; i++) {
-            const T dd = s.vert[3 * i] * dl.x + s.vert[3 * i + 1] * dl.y + s.vert[3 * i + 2] * dl.z;
-            if (dd > bd + tie) { bd = dd; best = i; }
+            for (int i = 0; i < s.nvert; i++) {
+                const T dd = s.vert[3 * i] * dl.x + s.vert[3 * i + 1] * dl.y + s.vert[3 * i + 2] * dl.z;
+                if (dd > bd + tie) { bd = dd; best = i; }
+            }
         }
         pl = mv3(s.vert + 3 * best);
         break;
@@ -461,6 +507,7 @@ MW_HD int face_upgrade(const Shape<T>& c, const Shape<T>& box, Hit<T>* h, T marg
     pl.mat.m[3] = fy.y; pl.mat.m[4] = fz.y; pl.mat.m[5] = nf.y;
     pl.mat.m[6] = fy.z; pl.mat.m[7] = fz.z; pl.mat.m[8] = nf.z;
     pl.size[0] = pl.size[1] = pl.size[2] = 0; pl.vert = nullptr; pl.nvert = 0; pl.margin = 0;
+    pl.nbradr = nullptr; pl.nbr = nullptr; pl.start = nullptr; pl.hill = 0; pl.hint = -1;
     Hit<T> t[8];
     int cnt = 0;
     V3<T> cax = col(c.mat, 2);
@@ -523,10 +570,17 @@ MW_HD Shape<T> make_shape(const Env<T> e, int g) {
     s.mat = ld9(e, e.lay().geom_xmat + 9 * g);
     for (int k = 0; k < 3; k++) s.size[k] = m.geom_size[3 * g + k];
     s.margin = 0; s.vert = nullptr; s.nvert = 0;
+    s.nbradr = nullptr; s.nbr = nullptr; s.start = nullptr; s.hill = 0; s.hint = -1;
     if (s.type == G_MESH) {
         const int mi = m.geom_meshid[g];
         s.vert = m.mesh_vert + 3 * m.mesh_vertadr[mi];
         s.nvert = m.mesh_vertnum[mi];
+        if (m.mesh_hill[mi]) {
+            s.hill = 1;
+            s.nbradr = m.mesh_nbradr + m.mesh_vertadr[mi];
+            s.nbr = m.mesh_nbr;
+            s.start = m.mesh_start + 32 * mi;
+        }
     }
     return s;
 }

@@ -125,7 +125,7 @@ struct Model {
     CP<int> jnt_type, jnt_bodyid, jnt_qposadr, jnt_dofadr, jnt_limited;
     CP<int> dof_bodyid, dof_jntid, dof_parentid;
     CP<int> geom_type, geom_bodyid, geom_meshid, geom_condim;
-    CP<int> mesh_vertadr, mesh_vertnum, pair_geom;
+    CP<int> mesh_vertadr, mesh_vertnum, mesh_nbradr, mesh_nbr, mesh_start, mesh_hill, pair_geom;
     CP<int> act_dofid, act_qposid, eq_body1, eq_body2, probe_body;
     // reals
     CP<T> body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia;
@@ -159,7 +159,7 @@ inline Layout make_layout(const Sizes& s) {
     L.efcX = take(EFC_EXTRA * s.maxefc);
     L.nreal = o;
     o = 0;
-    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(12);   // + 8 solver phase timers (MW_SOLVER_TIMING builds)
+    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(20);   // + 16 phase timers (MW_SOLVER_TIMING builds): 8 solver phases, 6 pipeline stages
     L.nint = o;
     return L;
 }

@@ -992,12 +992,24 @@ inline double* mw_prof() { static double t[8] = {0}; return t; }
 template <typename T>
 MW_STAGE_FN void forward(const Env<T> e_) {
     const Env<T> e = e_.uniform();
+#if defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    CLayout& L = e.lay();
+    MW_TICK(t0) kinematics(e);
+    MW_TICK(t1) crb(e);
+    MW_TICK(t2) collision(e);
+    MW_TICK(t3) make_constraints(e);
+    MW_TICK(t4) smooth_forces(e);
+    MW_TICK(t5) solve(e);
+    MW_TICK(t6)
+    MW_TOCK(e, L, 8, t0, t1) MW_TOCK(e, L, 9, t1, t2) MW_TOCK(e, L, 10, t2, t3) MW_TOCK(e, L, 11, t3, t4) MW_TOCK(e, L, 12, t4, t5) MW_TOCK(e, L, 13, t5, t6)
+#else
     MW_STAGE(0, kinematics(e))
     MW_STAGE(1, crb(e))
     MW_STAGE(2, collision(e))
     MW_STAGE(3, make_constraints(e))
     MW_STAGE(4, smooth_forces(e))
     MW_STAGE(5, solve(e))
+#endif
 }
 
 template <typename T>

@@ -8,6 +8,7 @@
 //   template <class F> static void launch(int nblocks, F lane_program);   // F(block, thread, Scratchpad) for 64 threads / block
 //   static void sync();
 #pragma once
+#include <stdlib.h>
 #include <string.h>
 #include <map>
 #include <memory>
@@ -66,6 +67,7 @@ struct DeviceModel {
             {"dof_bodyid", &Model<T>::dof_bodyid}, {"dof_jntid", &Model<T>::dof_jntid}, {"dof_parentid", &Model<T>::dof_parentid},
             {"geom_type", &Model<T>::geom_type}, {"geom_bodyid", &Model<T>::geom_bodyid}, {"geom_meshid", &Model<T>::geom_meshid},
             {"geom_condim", &Model<T>::geom_condim}, {"mesh_vertadr", &Model<T>::mesh_vertadr}, {"mesh_vertnum", &Model<T>::mesh_vertnum},
+            {"mesh_nbradr", &Model<T>::mesh_nbradr}, {"mesh_nbr", &Model<T>::mesh_nbr}, {"mesh_start", &Model<T>::mesh_start}, {"mesh_hill", &Model<T>::mesh_hill},
             {"pair_geom", &Model<T>::pair_geom}, {"act_dofid", &Model<T>::act_dofid}, {"act_qposid", &Model<T>::act_qposid},
             {"eq_body1", &Model<T>::eq_body1}, {"eq_body2", &Model<T>::eq_body2}, {"probe_body", &Model<T>::probe_body}};
         const RF rfs[] = {{"body_pos", &Model<T>::body_pos}, {"body_quat", &Model<T>::body_quat}, {"body_ipos", &Model<T>::body_ipos},
@@ -137,6 +139,7 @@ struct World {
     const long long* snap_off;  // per task: element offset of goal 0
     const int* snap_stride;   // per task: elements per snapshot (= nstate + 39)
     int max_episode_steps, terminate_on_success, one_hot, num_tasks;
+    int lpb;                  // lanes (environments) per 64-thread workgroup: 64, or fewer to spread a small batch over more CUs
     IOPtrs io;
 };
 
@@ -146,8 +149,8 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Scratchpad sp, Env<T
     int g = 0;
     while (g + 1 < w.ngroups && block >= w.groups[g + 1].block0) g++;
     const GroupDev<T>& G = w.groups[g];
-    const int lane = (block - G.block0) * BLOCK + thread;
-    if (lane >= G.nenv) return false;
+    const int lane = (block - G.block0) * w.lpb + thread;
+    if (thread >= w.lpb || lane >= G.nenv) return false;
     e->m = &G.m; e->col = G.col + lane; e->icol = G.icol + lane; e->stride = (unsigned)G.stride;
     e->cache_layout(G.L, G.m.sz.nv);
     *gid = G.gid[lane];
@@ -309,6 +312,7 @@ class Context : public ContextBase {
     long long* d_snap_off_ = nullptr;
     int* d_snap_stride_ = nullptr;
     int nblocks_ = 0, N_ = 0;
+    int lpb_ = BLOCK;   // lanes per workgroup of the step / reset launches (see choose_lpb)
     // io buffers (device) + host staging
     float* d_act_ = nullptr; size_t act_capacity_steps_ = 0;
     int* d_next_goal_ = nullptr;
@@ -325,7 +329,7 @@ class Context : public ContextBase {
         w.groups = d_groups_; w.ngroups = (int)groups_.size(); w.tasks = d_tasks_;
         w.snap = d_snap_; w.snap_off = d_snap_off_; w.snap_stride = d_snap_stride_;
         w.max_episode_steps = cfg.max_episode_steps; w.terminate_on_success = cfg.terminate_on_success;
-        w.one_hot = cfg.one_hot; w.num_tasks = cfg.num_tasks;
+        w.one_hot = cfg.one_hot; w.num_tasks = cfg.num_tasks; w.lpb = lpb_;
         if (with_io) {
             w.io.act = d_act_; w.io.next_goal = d_next_goal_; w.io.obs = d_obs_; w.io.reward = d_reward_;
             w.io.terminated = d_flags_; w.io.truncated = d_flags_ + N_; w.io.success = d_flags_ + 2 * N_; w.io.done = d_flags_ + 3 * N_;
@@ -388,12 +392,27 @@ public:
         for (int i = 0; i < N_; i++) by_model[tasks.at(env_task[i]).model].push_back(i);
         env_group_.assign(N_, 0); env_lane_.assign(N_, 0);
         groups_.resize(by_model.size());
+        // Lanes per workgroup.  The lane programs are latency-bound and a wave runs as long as its slowest lane
+        // (solver / collision iteration counts differ per environment), so a batch that does not fill the chip is
+        // spread over MORE, emptier waves: the fewest lanes per workgroup in {16, 32, 64} that still gives every
+        // workgroup its own CU.  MW_LANES_PER_BLOCK overrides.
+        {
+            const char* ov = getenv("MW_LANES_PER_BLOCK");
+            lpb_ = BLOCK;
+            for (int cand : {32, 16}) {
+                int nb = 0;
+                for (auto& kv : by_model) nb += ((int)kv.second.size() + cand - 1) / cand;
+                if (nb <= Backend::compute_units()) lpb_ = cand;
+            }
+            if (ov) lpb_ = atoi(ov);
+            if (lpb_ != 16 && lpb_ != 32 && lpb_ != 64) throw std::runtime_error("lanes per block must be 16, 32 or 64");
+        }
         int gi = 0, blk = 0;
         for (auto& kv : by_model) {
             Group& g = groups_[gi];
             make_group(g, kv.first, kv.second);
             g.block0 = blk;
-            blk += (g.nenv + BLOCK - 1) / BLOCK;
+            blk += (g.nenv + lpb_ - 1) / lpb_;
             for (int l = 0; l < g.nenv; l++) { env_group_[kv.second[l]] = gi; env_lane_[kv.second[l]] = l; }
             gi++;
         }
@@ -455,7 +474,7 @@ public:
             const int D = obs_dim();
             double* d_o = (double*)Backend::alloc(sizeof(double) * g.nenv * D);
             World<T> w = world(false);
-            w.groups = d_g; w.ngroups = 1; w.io.obs = d_o; w.io.D = D;
+            w.groups = d_g; w.ngroups = 1; w.io.obs = d_o; w.io.D = D; w.lpb = BLOCK;
             Backend::launch((g.nenv + BLOCK - 1) / BLOCK, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_full(w, b, t, sp); });
             Backend::sync();
             Backend::d2h(host.data(), g.col, host.size() * sizeof(T));
@@ -550,7 +569,7 @@ public:
     static int ioffset_of(const Layout& L, const Sizes& s, const std::string& k, int* n) {
         if (k == "icon") { *n = CON_ISTRIDE * s.maxcon; return L.icon; }
         if (k == "iefc") { *n = EFC_ISTRIDE * s.maxefc; return L.iefc; }
-        if (k == "icount") { *n = 12; return L.icount; }
+        if (k == "icount") { *n = 20; return L.icount; }
         throw std::runtime_error("unknown int column " + k);
     }
     int layout_size(int gid, const char* what) override {

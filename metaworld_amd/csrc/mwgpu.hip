@@ -58,6 +58,7 @@ struct Backend {
     // MW_LDS_BYTES overrides (experiments / tests of the column-store fallback rows).
     static int& max_lds() { static int v = 65536; return v; }
     static int& num_cu() { static int v = 256; return v; }
+    static int compute_units() { return num_cu(); }
     static int lds_bytes(int nblocks) {
         static const char* ov = getenv("MW_LDS_BYTES");
         if (ov) return atoi(ov);

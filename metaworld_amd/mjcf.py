@@ -688,6 +688,7 @@ def compile_mjcf(path) -> Model:
     A["eq_solimp"] = np.array(eq_solimp).reshape(-1, 5)
     m.names = names
     _set_const(m)
+    add_mesh_graph(m.arrays)
     return m
 
 
@@ -828,6 +829,43 @@ def save_model(m: Model, path):
     np.savez_compressed(path, __meta__=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **m.arrays)
 
 
+HILL_MIN_VERTS = 64     # meshes with more hull vertices use hill-climbing support (like MuJoCo's mesh graphs)
+HILL_NSTART = 32        # start candidates: the support vertices of 32 fixed directions
+
+
+def add_mesh_graph(A):
+    """Hull-vertex adjacency (CSR over the global vertex index) + start candidates for hill-climbing support functions.
+    Derived from the stored hull vertices, so it is identical wherever the compiled model is loaded."""
+    if "mesh_nbradr" in A:
+        return
+    from scipy.spatial import ConvexHull
+    nmesh = len(A["mesh_vertnum"])
+    adr, nbr, start, hill = [0], [], [], []
+    k = np.arange(HILL_NSTART) + 0.5
+    phi, th = np.arccos(1 - 2 * k / HILL_NSTART), np.pi * (1 + 5 ** 0.5) * k
+    dirs = np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], 1)
+    for mi in range(nmesh):
+        a, n = int(A["mesh_vertadr"][mi]), int(A["mesh_vertnum"][mi])
+        v = A["mesh_vert"][a:a + n]
+        adj = [set() for _ in range(n)]
+        if n > HILL_MIN_VERTS:
+            for t in ConvexHull(v).simplices:
+                for i in range(3):
+                    x, y = int(t[i]), int(t[(i + 1) % 3])
+                    adj[x].add(y); adj[y].add(x)
+        ok = np.array([len(s) > 0 for s in adj])
+        use = n > HILL_MIN_VERTS and ok.all()
+        hill.append(1 if use else 0)
+        for sset in adj:
+            nbr += sorted(sset) if use else []
+            adr.append(len(nbr))
+        start += [int(np.argmax(v @ d)) for d in dirs] if use else [0] * HILL_NSTART
+    A["mesh_nbradr"] = np.array(adr, dtype=np.int32)
+    A["mesh_nbr"] = np.array(nbr if nbr else [0], dtype=np.int32)
+    A["mesh_start"] = np.array(start if start else [0], dtype=np.int32)
+    A["mesh_hill"] = np.array(hill if hill else [0], dtype=np.int32)
+
+
 def load_model(path) -> Model:
     import json
     z = np.load(path)
@@ -838,4 +876,5 @@ def load_model(path) -> Model:
     for k in z.files:
         if k != "__meta__":
             m.arrays[k] = z[k]
+    add_mesh_graph(m.arrays)
     return m

@@ -19,7 +19,12 @@
 #define CCD_TOL 1e-10
 #define CCD_ITER 50
 
-typedef struct { int type; const double *pos, *mat, *size; const double* vert; int nvert; double margin; } Shape;
+typedef struct {
+    int type; const double *pos, *mat, *size; const double* vert; int nvert; double margin;
+    /* hill-climbing support for big hulls (metaworld_amd/mjcf.py add_mesh_graph): CSR adjacency of this mesh's
+       vertices (local ids), start candidates, and the vertex the previous support call on this shape ended at */
+    const int *nbradr, *nbr, *start; int hill, hint;
+} Shape;
 typedef struct { double dist, pos[3], normal[3]; } Hit;
 
 static inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -436,9 +441,34 @@ static void support(const Shape* s, const double* dir, double* out) {
     case MJL_MESH: {
         int best = 0;
         double bd = -1e30;
-        for (int i = 0; i < s->nvert; i++) {
-            double dd = dot3(s->vert + 3 * i, dl);
-            if (dd > bd + TIE) { bd = dd; best = i; }
+        if (s->hill) {
+            /* steepest-ascent walk over the hull graph, from the previous result on this shape or else from the best
+               of the fixed start candidates; strict improvement only (same rule as csrc/mw_collide.hpp) */
+            int cur;
+            if (s->hint >= 0) { cur = s->hint; bd = dot3(s->vert + 3 * cur, dl); }
+            else {
+                cur = s->start[0]; bd = dot3(s->vert + 3 * cur, dl);
+                for (int k = 1; k < 32; k++) {
+                    double dd = dot3(s->vert + 3 * s->start[k], dl);
+                    if (dd > bd) { bd = dd; cur = s->start[k]; }
+                }
+            }
+            for (int it = 0; it < s->nvert; it++) {
+                int nxt = cur;
+                for (int j = s->nbradr[cur]; j < s->nbradr[cur + 1]; j++) {
+                    double dd = dot3(s->vert + 3 * s->nbr[j], dl);
+                    if (dd > bd) { bd = dd; nxt = s->nbr[j]; }
+                }
+                if (nxt == cur) break;
+                cur = nxt;
+            }
+            ((Shape*)s)->hint = cur;
+            best = cur;
+        } else {
+            for (int i = 0; i < s->nvert; i++) {
+                double dd = dot3(s->vert + 3 * i, dl);
+                if (dd > bd + TIE) { bd = dd; best = i; }
+            }
         }
         copy3(pl, s->vert + 3 * best);
         break;
@@ -682,10 +712,17 @@ static void make_shape(const MjlModel* m, const MjlData* d, int g, Shape* s) {
     s->size = m->geom_size + 3 * g;
     s->margin = 0;
     s->vert = NULL; s->nvert = 0;
+    s->nbradr = s->nbr = s->start = NULL; s->hill = 0; s->hint = -1;
     if (s->type == MJL_MESH) {
         int mi = m->geom_meshid[g];
         s->vert = m->mesh_vert + 3 * m->mesh_vertadr[mi];
         s->nvert = m->mesh_vertnum[mi];
+        if (m->mesh_hill && m->mesh_hill[mi]) {
+            s->hill = 1;
+            s->nbradr = m->mesh_nbradr + m->mesh_vertadr[mi];
+            s->nbr = m->mesh_nbr;
+            s->start = m->mesh_start + 32 * mi;
+        }
     }
 }
 

@@ -35,6 +35,7 @@ struct Backend {
                 for (int t = 0; t < 64; t++) f(b, t, mw::Scratchpad{pad.data(), words});
         }
     }
+    static int compute_units() { return 256; }
     static void sync() {}
     static std::chrono::steady_clock::time_point& t0() { static std::chrono::steady_clock::time_point t; return t; }
     static void timed_begin() { t0() = std::chrono::steady_clock::now(); }

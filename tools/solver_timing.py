@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Shader-clock breakdown of the Newton solver's phases on the GPU (needs the -DMW_SOLVER_TIMING build of the
-library: tools/build_timing_lib.sh -> gpurun_out/libmwgpu_timing.so is NOT used; the library is built in-tree as
-metaworld_amd/libmwgpu_timing.so).  Prints per-lane-max cycles per substep-equivalent evaluation."""
+"""Shader-clock breakdown of one VectorEnv.step on the GPU while really stepping (random actions), from the
+-DMW_SOLVER_TIMING build of the library (metaworld_amd/libmwgpu_timing.so, see DESIGN.md "measuring").
+Per window of steps: max over lanes of the cycles spent in each pipeline stage and solver phase, per step."""
 import os
 import sys
 
@@ -14,18 +14,20 @@ from metaworld_amd.vector_env import MetaWorldGpuVectorEnv  # noqa: E402
 
 lib = native.load("mw_", os.path.join(ROOT, "metaworld_amd", "libmwgpu_timing.so"))
 n = int(sys.argv[1])
-names = ["warm", "Hasm", "chol", "MvJv", "lsrch", "update", "n_ls", "n_newton"]
+win = int(os.environ.get("MW_WIN", "50"))
+nwin = int(os.environ.get("MW_NWIN", "4"))
+names = ["warm", "Hasm", "chol", "MvJv", "lsrch", "update", "n_ls", "n_newt", "kin", "crb", "coll", "cons", "smooth", "solve"]
 for task in sys.argv[2:]:
     env = MetaWorldGpuVectorEnv("MT1", task, num_envs=n, seed=0, precision="fp32", lib=lib)
     env.reset()
-    rng = np.random.default_rng(0)
-    for _ in range(int(os.environ.get("MW_WARM", "25"))):
-        env.step(rng.uniform(-1, 1, (n, 4)).astype(np.float32))
-    ic0 = np.array([env.ctx.read_int(e, "icount") for e in range(n)])
-    env.ctx.debug(15, 10)          # 10 full dynamics evaluations on the current state
-    ic1 = np.array([env.ctx.read_int(e, "icount") for e in range(n)])
-    d = (ic1 - ic0)[:, 4:].astype(np.float64) / 10
-    d[:, :6] *= 16 / 1e3           # kilo-cycles
-    print(f"{task:22s} nefc max {ic1[:,1].max():3d} | max over lanes, kcycles/eval: " +
-          " ".join(f"{k}:{v:7.1f}" for k, v in zip(names, d.max(0))) + f" | max over lanes n_ls {d[:,6].max():.1f} n_newton {d[:,7].max():.1f} mean {d[:,7].mean():.2f}", flush=True)
+    env.ctx.upload_actions(np.random.default_rng(0).uniform(-1, 1, (64, n, 4)).astype(np.float32))
+    for w in range(nwin):
+        ic0 = np.array([env.ctx.read_int(e, "icount") for e in range(n)])
+        ms = env.ctx.step_resident(win) / win
+        ic1 = np.array([env.ctx.read_int(e, "icount") for e in range(n)])
+        d = (ic1 - ic0)[:, 4:18].astype(np.float64) / win
+        scale = np.array([16e-3] * 6 + [1, 1] + [16e-3] * 6)      # kilo-cycles, counts
+        d = d * scale
+        print(f"{task:18s} steps {w*win:3d}-{(w+1)*win:3d} {ms:6.2f} ms/step nefc<= {ic1[:,1].max():3d} | kcyc/step (max lane) " +
+              " ".join(f"{k}:{v:.0f}" for k, v in zip(names, d.max(0))), flush=True)
     env.close()
