@@ -58,7 +58,6 @@ inline long* mw_hist() { static long h[4 * 64] = {0}; return h; }
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MW_GLOBAL __attribute__((address_space(1)))
 #define MW_LDS __attribute__((address_space(3)))
-#define MW_LDS_STRIDE 64        /* words between consecutive scratchpad slots of one lane (= lanes per workgroup) */
 #define MW_CONST __attribute__((address_space(4)))
 __device__ inline unsigned mw_uniform(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ inline int mw_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -72,7 +71,6 @@ __device__ inline double mw_uniform(double x) { return __builtin_bit_cast(double
 #define MW_GLOBAL
 #define MW_CONST
 #define MW_LDS
-#define MW_LDS_STRIDE 1
 inline float mw_uniform(float x) { return x; }
 inline double mw_uniform(double x) { return x; }
 inline unsigned mw_uniform(unsigned x) { return x; }
@@ -164,9 +162,9 @@ inline Layout make_layout(const Sizes& s) {
     return L;
 }
 
-// workgroup scratchpad handed to every lane program: LDS on the device (slot k of a lane at base[k * 64 + thread]),
-// a private buffer per host thread in the test harness
-struct Scratchpad { MW_LDS void* base; int words_per_lane; };   // 4-byte words available to each lane
+// workgroup scratchpad handed to every lane program: LDS on the device (stride = lanes per workgroup), a private
+// buffer per host thread in the test harness (stride 1)
+struct Scratchpad { MW_LDS void* base; int words_per_lane, stride; };   // 4-byte words per lane; slot k of lane t at base[k * stride + t]
 
 template <typename T> using CModel = const MW_CONST Model<T>;
 using CLayout = const MW_CONST Layout;
@@ -181,10 +179,12 @@ struct Env {
     int* icol;     // int column store, already offset by the lane
     unsigned stride;   // 32-bit index arithmetic: nreal * stride < 2^32 (checked at group creation)
     int nv, o_efcJ, o_efcX, o_con, o_icon, o_iefc, o_icount, o_task;   // hot layout offsets (copied from Layout)
-    MW_LDS T* lds;     // this lane's slice of the workgroup scratchpad (LDS on the device), slot k at lds[k * MW_LDS_STRIDE]
+    MW_LDS T* lds;     // this lane's slice of the workgroup scratchpad (LDS on the device), slot k at lds[k * lds_stride]
+    int lds_stride;
     int lds_rows;      // constraint rows whose solver scalars fit in the scratchpad (the rest stay in the column store)
     MW_HD void set_scratchpad(Scratchpad sp, int thread) {
-        lds = (MW_LDS T*)sp.base + (MW_LDS_STRIDE == 1 ? 0 : thread);
+        lds = (MW_LDS T*)sp.base + (sp.stride == 1 ? 0 : thread);
+        lds_stride = sp.stride;
         lds_rows = (int)(sp.words_per_lane * 4 / (SR_N * sizeof(T)));
     }
     MW_HD void cache_layout(const Layout& L, int nv_) {
@@ -196,7 +196,7 @@ struct Env {
         u.stride = mw_uniform(stride);
         u.nv = mw_uniform(nv); u.o_efcJ = mw_uniform(o_efcJ); u.o_efcX = mw_uniform(o_efcX); u.o_con = mw_uniform(o_con);
         u.o_icon = mw_uniform(o_icon); u.o_iefc = mw_uniform(o_iefc); u.o_icount = mw_uniform(o_icount); u.o_task = mw_uniform(o_task);
-        u.lds_rows = mw_uniform(lds_rows);
+        u.lds_rows = mw_uniform(lds_rows); u.lds_stride = mw_uniform(lds_stride);
         return u;
     }
     MW_HD CModel<T>& model() const { return *(CModel<T>*)(unsigned long long)m; }

@@ -5,7 +5,7 @@
 // The including file must define, before inclusion, a `Backend` struct with:
 //   static void* alloc(size_t bytes);  static void free(void*);  static void zero(void*, size_t);
 //   static void h2d(void* dst, const void* src, size_t);  static void d2h(void* dst, const void* src, size_t);
-//   template <class F> static void launch(int nblocks, F lane_program);   // F(block, thread, Scratchpad) for 64 threads / block
+//   template <class F> static void launch(int nblocks, int lanes_per_block, F lane_program);   // F(block, thread, Scratchpad) for 64 threads / block
 //   static void sync();
 #pragma once
 #include <stdlib.h>
@@ -394,18 +394,18 @@ public:
         groups_.resize(by_model.size());
         // Lanes per workgroup.  The lane programs are latency-bound and a wave runs as long as its slowest lane
         // (solver / collision iteration counts differ per environment), so a batch that does not fill the chip is
-        // spread over MORE, emptier waves: the fewest lanes per workgroup in {16, 32, 64} that still gives every
-        // workgroup its own CU.  MW_LANES_PER_BLOCK overrides.
+        // spread over MORE, emptier waves: the fewest lanes per workgroup in {8, 16, 32, 64} that still gives every
+        // wave its own SIMD.  MW_LANES_PER_BLOCK overrides.
         {
             const char* ov = getenv("MW_LANES_PER_BLOCK");
             lpb_ = BLOCK;
-            for (int cand : {32, 16}) {
+            for (int cand : {32, 16, 8}) {
                 int nb = 0;
                 for (auto& kv : by_model) nb += ((int)kv.second.size() + cand - 1) / cand;
-                if (nb <= Backend::compute_units()) lpb_ = cand;
+                if (nb <= 4 * Backend::compute_units()) lpb_ = cand;   // one wave per SIMD (the lane programs use all 512 VGPRs)
             }
             if (ov) lpb_ = atoi(ov);
-            if (lpb_ != 16 && lpb_ != 32 && lpb_ != 64) throw std::runtime_error("lanes per block must be 16, 32 or 64");
+            if (lpb_ != 4 && lpb_ != 8 && lpb_ != 16 && lpb_ != 32 && lpb_ != 64) throw std::runtime_error("lanes per block must be 4, 8, 16, 32 or 64");
         }
         int gi = 0, blk = 0;
         for (auto& kv : by_model) {
@@ -475,7 +475,7 @@ public:
             double* d_o = (double*)Backend::alloc(sizeof(double) * g.nenv * D);
             World<T> w = world(false);
             w.groups = d_g; w.ngroups = 1; w.io.obs = d_o; w.io.D = D; w.lpb = BLOCK;
-            Backend::launch((g.nenv + BLOCK - 1) / BLOCK, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_full(w, b, t, sp); });
+            Backend::launch((g.nenv + BLOCK - 1) / BLOCK, BLOCK, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_full(w, b, t, sp); });
             Backend::sync();
             Backend::d2h(host.data(), g.col, host.size() * sizeof(T));
             std::vector<double> obs((size_t)g.nenv * D);
@@ -502,7 +502,7 @@ public:
         const uint8_t* dm = nullptr;
         if (mask) { Backend::h2d(d_mask_, mask, N_); dm = d_mask_; }
         World<T> w = world();
-        Backend::launch(nblocks_, [w, dm] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_snap(w, dm, b, t, sp); });
+        Backend::launch(nblocks_, lpb_, [w, dm] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_snap(w, dm, b, t, sp); });
         Backend::sync();
         if (obs_out) Backend::d2h(obs_out, d_obs_, sizeof(double) * N_ * obs_dim());
     }
@@ -512,7 +512,7 @@ public:
         Backend::h2d(d_act_, act, sizeof(float) * 4 * N_);
         if (next_goal) Backend::h2d(d_next_goal_, next_goal, sizeof(int) * N_);
         World<T> w = world();
-        Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+        Backend::launch(nblocks_, lpb_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
         Backend::sync();
         const int D = obs_dim();
         if (obs) Backend::d2h(obs, d_obs_, sizeof(double) * N_ * D);
@@ -542,7 +542,7 @@ public:
         Backend::timed_begin();
         for (int s = 0; s < nsteps; s++) {
             w.io.act = base + (size_t)(act_steps > 0 ? s % act_steps : 0) * 4 * N_;
-            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+            Backend::launch(nblocks_, lpb_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
         }
         float ms = Backend::timed_end();
         if (kernel_ms) *kernel_ms = ms;
@@ -550,7 +550,7 @@ public:
 
     void debug(int what, int n) override {
         World<T> w = world();
-        Backend::launch(nblocks_, [w, what, n] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_debug(w, what, n, b, t, sp); });
+        Backend::launch(nblocks_, lpb_, [w, what, n] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_debug(w, what, n, b, t, sp); });
         Backend::sync();
     }
 

@@ -25,14 +25,14 @@ struct Backend {
     // and the column-store fallback rows of the solver)
     static int lds_rows() { static int r = std::getenv("MW_LDS_ROWS") ? std::atoi(std::getenv("MW_LDS_ROWS")) : 24; return r; }
     template <class F>
-    static void launch(int nblocks, F f) {
+    static void launch(int nblocks, int, F f) {
         const int words = lds_rows() * 7 * 2;   // SR_N doubles per row
 #pragma omp parallel
         {
             std::vector<double> pad((size_t)lds_rows() * 7 + 1, std::nan(""));   // LDS is not zero-initialised either
 #pragma omp for schedule(dynamic)
             for (int b = 0; b < nblocks; b++)
-                for (int t = 0; t < 64; t++) f(b, t, mw::Scratchpad{pad.data(), words});
+                for (int t = 0; t < 64; t++) f(b, t, mw::Scratchpad{pad.data(), words, 1});
         }
     }
     static int compute_units() { return 256; }
