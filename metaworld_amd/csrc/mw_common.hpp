@@ -89,7 +89,8 @@ constexpr int MAX_NV = 17;       // register-resident solver arrays are sized by
 constexpr int CON_STRIDE = 26;   // reals per contact record
 constexpr int CON_ISTRIDE = 4;   // ints per contact record
 constexpr int EFC_EXTRA = 11;    // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv, fri, info, state
-constexpr int SR_N = 7;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force
+constexpr int SR_N = 8;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force, block list
+constexpr int IC_NBLK = 18;      // icount slot: number of constraint blocks (single rows / contact cones)
 constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a non-zero Jacobian entry
 
 struct Sizes {
@@ -164,7 +165,7 @@ inline Layout make_layout(const Sizes& s) {
 
 // workgroup scratchpad handed to every lane program: LDS on the device (stride = lanes per workgroup), a private
 // buffer per host thread in the test harness (stride 1)
-struct Scratchpad { MW_LDS void* base; int words_per_lane, stride; };   // 4-byte words per lane; slot k of lane t at base[k * stride + t]
+struct Scratchpad { MW_LDS void* base; int words_per_lane, stride, nsub; };   // 4-byte words per environment; slot k of env-lane t at base[k * stride + t]
 
 template <typename T> using CModel = const MW_CONST Model<T>;
 using CLayout = const MW_CONST Layout;
@@ -181,10 +182,13 @@ struct Env {
     int nv, o_efcJ, o_efcX, o_con, o_icon, o_iefc, o_icount, o_task;   // hot layout offsets (copied from Layout)
     MW_LDS T* lds;     // this lane's slice of the workgroup scratchpad (LDS on the device), slot k at lds[k * lds_stride]
     int lds_stride;
+    int sub, nsub;     // sub-lane of this thread and sub-lanes per environment (cooperative row sweeps, see below)
     int lds_rows;      // constraint rows whose solver scalars fit in the scratchpad (the rest stay in the column store)
     MW_HD void set_scratchpad(Scratchpad sp, int thread) {
-        lds = (MW_LDS T*)sp.base + (sp.stride == 1 ? 0 : thread);
+        lds = (MW_LDS T*)sp.base + (sp.stride == 1 ? 0 : thread % sp.stride);
         lds_stride = sp.stride;
+        sub = sp.stride == 1 ? 0 : thread / sp.stride;
+        nsub = sp.nsub;
         lds_rows = (int)(sp.words_per_lane * 4 / (SR_N * sizeof(T)));
     }
     MW_HD void cache_layout(const Layout& L, int nv_) {
@@ -196,7 +200,7 @@ struct Env {
         u.stride = mw_uniform(stride);
         u.nv = mw_uniform(nv); u.o_efcJ = mw_uniform(o_efcJ); u.o_efcX = mw_uniform(o_efcX); u.o_con = mw_uniform(o_con);
         u.o_icon = mw_uniform(o_icon); u.o_iefc = mw_uniform(o_iefc); u.o_icount = mw_uniform(o_icount); u.o_task = mw_uniform(o_task);
-        u.lds_rows = mw_uniform(lds_rows); u.lds_stride = mw_uniform(lds_stride);
+        u.lds_rows = mw_uniform(lds_rows); u.lds_stride = mw_uniform(lds_stride); u.nsub = mw_uniform(nsub);
         return u;
     }
     MW_HD CModel<T>& model() const { return *(CModel<T>*)(unsigned long long)m; }
@@ -204,6 +208,59 @@ struct Env {
     MW_HD GRef<T> R(int i) const { return ((MW_GLOBAL T*)col)[(unsigned)i * stride]; }
     MW_HD GRef<int> I(int i) const { return ((MW_GLOBAL int*)icol)[(unsigned)i * stride]; }
 };
+
+// Cooperative sweeps.  When a batch is too small to fill the chip the runtime puts only `lpb` < 64 environments in a
+// workgroup and the 64 / lpb threads with the same (thread % lpb) all belong to ONE environment: its "sub-lanes".
+// They execute the lane program redundantly (same values, same stores) except inside the solver's row sweeps,
+// which are split over the sub-lanes -- rows / constraint blocks k = sub, sub + nsub, ... -- and whose partial sums
+// are combined with a butterfly (xor) exchange, so every sub-lane ends up with bit-identical totals.
+//   MW_SUBS(e, sub) { ... slot MW_SLOT(sub) ... }   one parallel section; partial results go into arrays of MW_NSLOT
+//   MW_SYNC()                                        makes scratchpad / column-store writes of a section visible
+//   sub_sum(e, p) / sub_sum_n<N>(e, p)               butterfly totals
+// The host harness has no lanes: it runs the sections for sub = 0 .. nsub-1 in a loop and adds the partials in the
+// butterfly's order, which reproduces the device arithmetic exactly for any nsub.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MW_SUBS(e, sub) for (int sub = (e).sub, mw_once_ = 1; mw_once_; mw_once_ = 0)
+#define MW_SLOT(sub) 0
+constexpr int MW_NSLOT = 1;
+#define MW_SYNC() __syncthreads()
+template <typename T>
+__device__ inline T sub_sum(const Env<T>& e, const T* p) {
+    T v = p[0];
+    for (int off = e.lds_stride; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+template <int N, typename T>
+__device__ inline void sub_sum_n(const Env<T>& e, T (*p)[N]) {
+    for (int off = e.lds_stride; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < N; k++) p[0][k] += __shfl_xor(p[0][k], off);
+    }
+}
+#else
+#define MW_SUBS(e, sub) for (int sub = 0; sub < (e).nsub; sub++)
+#define MW_SLOT(sub) (sub)
+constexpr int MW_NSLOT = 8;
+#define MW_SYNC()
+template <typename T>
+inline T sub_sum(const Env<T>& e, const T* p) {
+    T q[MW_NSLOT], r[MW_NSLOT];
+    for (int s = 0; s < e.nsub; s++) q[s] = p[s];
+    for (int off = 1; off < e.nsub; off <<= 1) {
+        for (int s = 0; s < e.nsub; s++) r[s] = q[s] + q[s ^ off];
+        for (int s = 0; s < e.nsub; s++) q[s] = r[s];
+    }
+    return q[0];
+}
+template <int N, typename T>
+inline void sub_sum_n(const Env<T>& e, T (*p)[N]) {
+    for (int k = 0; k < N; k++) {
+        T col[MW_NSLOT];
+        for (int s = 0; s < e.nsub; s++) col[s] = p[s][k];
+        p[0][k] = sub_sum(e, col);
+    }
+}
+#endif
 
 // ----------------------------------------------------------------------------- small math
 template <typename T> MW_HD T mw_sqrt(T x) { return sqrt(x); }

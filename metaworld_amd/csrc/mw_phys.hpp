@@ -467,8 +467,13 @@ MW_HD int new_rows(const Env<T> e, int n, int type, int id) {
     GRef<int> nefc = e.I(e.lay().icount + 1);
     if (nefc + n > m.sz.maxefc) { e.I(e.lay().icount + 3) |= 1; return -1; }
     const int r0 = nefc;
+    {   // constraint block list (IEFC slot 2 of entry k = first row of block k): one block per contact cone, else per row
+        GRef<int> nblk = e.I(e.lay().icount + IC_NBLK);
+        if (type == C_CONTACT) { IEFC(e, nblk, 2) = r0; nblk += 1; }
+        else { for (int k = 0; k < n; k++) IEFC(e, nblk + k, 2) = r0 + k; nblk += n; }
+    }
     for (int k = 0; k < n; k++) {
-        IEFC(e, r0 + k, 0) = type; IEFC(e, r0 + k, 1) = id; IEFC(e, r0 + k, 2) = 0;
+        IEFC(e, r0 + k, 0) = type; IEFC(e, r0 + k, 1) = id;
         IEFC(e, r0 + k, 3) = m.sz.nv; IEFC(e, r0 + k, 4) = -1;
         for (int i = 0; i < m.sz.nv; i++) EJ(e, r0 + k, i) = 0;
         EX(e, r0 + k, 0) = 0; EX(e, r0 + k, 1) = 0;
@@ -486,6 +491,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
     CLayout& L = e.lay();
     const int nv = m.sz.nv;
     e.I(L.icount + 1) = 0;
+    e.I(L.icount + IC_NBLK) = 0;
     // ---- weld(mocap, hand): 3 translational + 3 rotational rows ----
     for (int q = 0; q < m.sz.neq; q++) {
         const int b1 = m.eq_body1[q], b2 = m.eq_body2[q];
@@ -584,11 +590,11 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
 // ------------------------------------------------------------------ Newton solver
 // Solver row scalars.  The solver sweeps the constraint rows many times (cost/force updates, Hessian assembly and
 // every line-search evaluation); on the GPU each sweep is a chain of dependent memory round trips per row.  The
-// seven scalars a sweep needs (D, jar, Jv, friction scale, descriptor, state, force) therefore live in the
+// scalars a sweep needs (D, jar, Jv, friction scale, descriptor, state, force, block list) therefore live in the
 // workgroup scratchpad (LDS, ~50-cycle reads instead of ~200-900) for the first `lds_rows` rows; rows beyond the
 // scratchpad capacity use slots of the row's record in the column store.  `info` = type + 16 * dim + 256 * k (k-th
 // row of a dim-row cone block); the rows of a block are visited from its first row with a wave-uniform counter.
-enum { SR_D = 0, SR_JAR, SR_JV, SR_FRI, SR_INFO, SR_STATE, SR_FORCE };
+enum { SR_D = 0, SR_JAR, SR_JV, SR_FRI, SR_INFO, SR_STATE, SR_FORCE, SR_BLK };
 MW_HD constexpr int sr_slot(int f) { return f == SR_D ? 3 : f == SR_JAR ? 6 : f == SR_JV ? 7 : f == SR_FRI ? 8 : f == SR_INFO ? 9 : f == SR_STATE ? 10 : 5; }
 template <typename T>
 MW_HD T sr_get(const Env<T> e, int i, int f) {
@@ -685,34 +691,52 @@ MW_HD void uc_row(const R& rows, const Env<T> e, int i, T* cost) {
     }
 }
 
+// first row of constraint block k (scratchpad copy of the list built by make_constraints)
+template <typename T>
+MW_HD int block_row(const Env<T> e, int k) {
+    if (k < e.lds_rows) return (int)e.lds[(k * SR_N + SR_BLK) * e.lds_stride];
+    return IEFC(e, k, 2);
+}
+
 // cost, forces, states at the current jar; qfrc_constraint = J' force; returns total cost incl. Gauss term
 template <typename T, int NV>
 MW_STAGE_FN T update_constraint(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CLayout& L = e.lay();
-    const int nv = e.nv, nefc = e.I(L.icount + 1);
-    T cost = 0;
+    const int nv = e.nv, nefc = e.I(L.icount + 1), nblk = e.I(L.icount + IC_NBLK);
     const Rows<T, true> fast{e};
     const Rows<T, false> slow{e};
-    for (int i = 0; i < nefc; i++) {
-        if (i + 4 <= e.lds_rows) uc_row<T>(fast, e, i, &cost);
-        else uc_row<T>(slow, e, i, &cost);
+    T cp[MW_NSLOT];
+    MW_SUBS(e, sub) {
+        T c = 0;
+        for (int k = sub; k < nblk; k += e.nsub) {
+            const int i = block_row(e, k);
+            if (i + 4 <= e.lds_rows) uc_row<T>(fast, e, i, &c);
+            else uc_row<T>(slow, e, i, &c);
+        }
+        cp[MW_SLOT(sub)] = c;
     }
+    MW_SYNC();
+    const T cost = sub_sum(e, cp);
     T gauss = 0;
     for (int k = 0; k < nv; k++)
         gauss += (e.R(L.Ma + k) - e.R(L.smooth + k)) * (e.R(L.qacc + k) - e.R(L.qacc_smooth + k));
-    T qf[NV];
+    T qf[MW_NSLOT][NV];
+    MW_SUBS(e, sub) {
+        T* q = qf[MW_SLOT(sub)];
 #pragma unroll
-    for (int k = 0; k < NV; k++) qf[k] = 0;
-    for (int i = 0; i < nefc; i++) {      // J' f over the active rows, accumulated in registers
-        const T f = sr_get(e, i, SR_FORCE);
-        if (f == 0) continue;
-        T j[NV];
-        jrow_load<T, NV>(e, i, nv, j);
+        for (int k = 0; k < NV; k++) q[k] = 0;
+        for (int i = sub; i < nefc; i += e.nsub) {      // J' f over the active rows, accumulated in registers
+            const T f = sr_get(e, i, SR_FORCE);
+            if (f == 0) continue;
+            T j[NV];
+            jrow_load<T, NV>(e, i, nv, j);
 #pragma unroll
-        for (int k = 0; k < NV; k++) qf[k] += j[k] * f;
+            for (int k = 0; k < NV; k++) q[k] += j[k] * f;
+        }
     }
-    vec_store<T, NV>(e, L.qfrc_c, nv, qf);
+    sub_sum_n<NV>(e, qf);
+    vec_store<T, NV>(e, L.qfrc_c, nv, qf[0]);
     return cost + T(0.5) * gauss;
 }
 
@@ -755,34 +779,43 @@ MW_HD void le_row(const R& rows, int i, T alpha, T* C, T* D1, T* D2, T* A1) {
 // constraint part of the cost (no forces written) at jar + alpha*Jv, with 1st/2nd derivatives along the line
 // *mag: sum of the magnitudes that cancel inside d1 (rounding-noise scale of the derivative, fp32 termination)
 template <typename T>
-MW_HD void line_eval(const Env<T> e, int nefc, T alpha, const T* quadGauss, T* cost, T* d1, T* d2, T* mag = nullptr) {
+MW_HD void line_eval(const Env<T> e, int nblk, T alpha, const T* quadGauss, T* cost, T* d1, T* d2, T* mag = nullptr) {
     MW_COUNT(0)
-    T C = alpha * alpha * quadGauss[2] + alpha * quadGauss[1] + quadGauss[0];
-    T D1 = 2 * alpha * quadGauss[2] + quadGauss[1], D2 = 2 * quadGauss[2];
-    T A1 = mw_abs(2 * alpha * quadGauss[2]) + mw_abs(quadGauss[1]);
     const Rows<T, true> fast{e};
     const Rows<T, false> slow{e};
-    for (int i = 0; i < nefc; i++) {
-        if (i + 4 <= e.lds_rows) le_row<T>(fast, i, alpha, &C, &D1, &D2, &A1);
-        else le_row<T>(slow, i, alpha, &C, &D1, &D2, &A1);
+    T part[MW_NSLOT][4];
+    MW_SUBS(e, sub) {
+        T C = 0, D1 = 0, D2 = 0, A1 = 0;
+        for (int k = sub; k < nblk; k += e.nsub) {
+            const int i = block_row(e, k);
+            if (i + 4 <= e.lds_rows) le_row<T>(fast, i, alpha, &C, &D1, &D2, &A1);
+            else le_row<T>(slow, i, alpha, &C, &D1, &D2, &A1);
+        }
+        T* p = part[MW_SLOT(sub)];
+        p[0] = C; p[1] = D1; p[2] = D2; p[3] = A1;
     }
-    *cost = C; *d1 = D1; *d2 = D2;
-    if (mag) *mag = A1;
+    sub_sum_n<4>(e, part);
+    *cost = part[0][0] + (alpha * alpha * quadGauss[2] + alpha * quadGauss[1] + quadGauss[0]);
+    *d1 = part[0][1] + (2 * alpha * quadGauss[2] + quadGauss[1]);
+    *d2 = part[0][2] + 2 * quadGauss[2];
+    if (mag) *mag = part[0][3] + mw_abs(2 * alpha * quadGauss[2]) + mw_abs(quadGauss[1]);
 }
 
 template <typename T, int NV>
 MW_HD void solve_impl(const Env<T> e) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    const int nv = e.nv, nefc = e.I(L.icount + 1);
+    const int nv = e.nv, nefc = e.I(L.icount + 1), nblk = e.I(L.icount + IC_NBLK);
     constexpr int NT = NV * (NV + 1) / 2;
     MW_TICK(t_a)
-    {   // stage the static row scalars into the scratchpad
-        for (int i = 0; i < nefc; i++) {
+    MW_SUBS(e, sub) {   // stage the static row scalars and the block list into the scratchpad
+        for (int i = sub; i < nefc; i += e.nsub) {
             if (i >= e.lds_rows) { EX(e, i, 7) = 0; continue; }
             const T D = EX(e, i, 3), fri = EX(e, i, 8), info = EX(e, i, 9);
+            const int blk = IEFC(e, i, 2);
             sr_set(e, i, SR_D, D); sr_set(e, i, SR_FRI, fri); sr_set(e, i, SR_INFO, info);
             sr_set(e, i, SR_JV, T(0));   // read (times alpha = 0) before the first search direction exists
+            sr_set(e, i, SR_BLK, T(blk));
         }
     }
     auto set_point = [&](int src) {   // qacc <- src ; Ma, jar
@@ -791,13 +824,16 @@ MW_HD void solve_impl(const Env<T> e) {
         mat_vec<T, NV>(e, L.qM, nv, x, y);
         vec_store<T, NV>(e, L.qacc, nv, x);
         vec_store<T, NV>(e, L.Ma, nv, y);
-        for (int i = 0; i < nefc; i++) {
-            T j[NV], s = -EX(e, i, 4);
-            jrow_load<T, NV>(e, i, nv, j);
+        MW_SUBS(e, sub) {
+            for (int i = sub; i < nefc; i += e.nsub) {
+                T j[NV], s = -EX(e, i, 4);
+                jrow_load<T, NV>(e, i, nv, j);
 #pragma unroll
-            for (int k = 0; k < NV; k++) s += j[k] * x[k];
-            sr_set(e, i, SR_JAR, s);
+                for (int k = 0; k < NV; k++) s += j[k] * x[k];
+                sr_set(e, i, SR_JAR, s);
+            }
         }
+        MW_SYNC();
     };
     // warm start: the better of qacc_warmstart and qacc_smooth (ties go to the warm start)
     set_point(L.qacc_smooth);
@@ -822,72 +858,84 @@ MW_HD void solve_impl(const Env<T> e) {
         if (scale * mw_sqrt(gn) < m.tolerance) break;
         MW_TICK(t_c)
         {
-            // H = M + J' D J over quadratic rows (+ dense cone blocks): lower triangle in registers, Cholesky, solve
-            T H[NT];
-            tri_load<T, NV>(e, L.qM, nv, H);
-            for (int i = 0; i < nefc; i++) {
-                const int st = (int)sr_get(e, i, SR_STATE);
-                if (st == S_QUADRATIC) {
-                    const T D = sr_get(e, i, SR_D);
-                    T j[NV];
-                    jrow_load<T, NV>(e, i, nv, j);
+            // H = M + J' D J over quadratic rows (+ dense cone blocks): lower triangle in registers (a partial sum per
+            // sub-lane over its blocks, M on sub-lane 0), butterfly total, then Cholesky + solve replicated
+            T H[MW_NSLOT][NT];
+            MW_SUBS(e, sub) {
+                T* h = H[MW_SLOT(sub)];
+                if (sub == 0) tri_load<T, NV>(e, L.qM, nv, h);
+                else {
 #pragma unroll
-                    for (int a = 0; a < NV; a++) j[a] = a < nv ? j[a] : T(0);
+                    for (int k = 0; k < NT; k++) h[k] = 0;
+                }
+                for (int kb = sub; kb < nblk; kb += e.nsub) {
+                    const int i = block_row(e, kb);
+                    const int st = (int)sr_get(e, i, SR_STATE);
+                    if (st == S_SATISFIED) continue;
+                    const int info = (int)sr_get(e, i, SR_INFO), dim = (info >> 4) & 15, type = info & 15;
+                    if (st == S_CONE) {
+                        ConeEval<T> z = cone_eval<T>(Rows<T, false>{e}, i, dim, T(0));
+                        const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu));
+                        T Hc[16];
+                        const T scl = z.mu * z.N / (z.Tn * z.Tn * z.Tn), dg = z.mu * z.mu - z.mu * z.N / z.Tn;
 #pragma unroll
-                    for (int a = 0; a < NV; a++) {
-                        const T Da = D * j[a];
+                        for (int r = 0; r < 4; r++)
 #pragma unroll
-                        for (int b = 0; b <= a; b++) H[tri(a, b)] += Da * j[b];
-                    }
-                } else if (st == S_CONE) {
-                    const int info = (int)sr_get(e, i, SR_INFO);
-                    if (info >= 256) continue;
-                    const int dim = (info >> 4) & 15;
-                    ConeEval<T> z = cone_eval<T>(Rows<T, false>{e}, i, dim, T(0));
-                    const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu));
-                    T Hc[16];
-                    const T scl = z.mu * z.N / (z.Tn * z.Tn * z.Tn), dg = z.mu * z.mu - z.mu * z.N / z.Tn;
+                            for (int c = 0; c < 4; c++) {
+                                T v;
+                                if (r == 0 && c == 0) v = 1;
+                                else if (r == 0) v = -z.mu * z.U[c] / z.Tn;
+                                else if (c == 0) v = -z.mu * z.U[r] / z.Tn;
+                                else v = scl * z.U[r] * z.U[c] + (r == c ? dg : T(0));
+                                Hc[4 * r + c] = (r < dim && c < dim) ? v * Dm * z.fri[r] * z.fri[c] : T(0);
+                            }
+                        T j[4][NV];
 #pragma unroll
-                    for (int r = 0; r < 4; r++)
+                        for (int r = 0; r < 4; r++) {
+                            const bool on = r < dim;
+                            jrow_load<T, NV>(e, on ? i + r : i, nv, j[r]);
 #pragma unroll
-                        for (int s = 0; s < 4; s++) {
-                            T h;
-                            if (r == 0 && s == 0) h = 1;
-                            else if (r == 0) h = -z.mu * z.U[s] / z.Tn;
-                            else if (s == 0) h = -z.mu * z.U[r] / z.Tn;
-                            else h = scl * z.U[r] * z.U[s] + (r == s ? dg : T(0));
-                            Hc[4 * r + s] = (r < dim && s < dim) ? h * Dm * z.fri[r] * z.fri[s] : T(0);
-                        }
-                    T j[4][NV];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const bool on = r < dim;
-                        jrow_load<T, NV>(e, on ? i + r : i, nv, j[r]);
-#pragma unroll
-                        for (int a = 0; a < NV; a++) j[r][a] = (on && a < nv) ? j[r][a] : T(0);
-                    }
-#pragma unroll
-                    for (int a = 0; a < NV; a++) {
-                        T t[4];
-#pragma unroll
-                        for (int s = 0; s < 4; s++) {
-                            t[s] = 0;
-#pragma unroll
-                            for (int r = 0; r < 4; r++) t[s] += j[r][a] * Hc[4 * r + s];
+                            for (int a = 0; a < NV; a++) j[r][a] = (on && a < nv) ? j[r][a] : T(0);
                         }
 #pragma unroll
-                        for (int b = 0; b <= a; b++) {
-                            T acc = 0;
+                        for (int a = 0; a < NV; a++) {
+                            T t[4];
 #pragma unroll
-                            for (int s = 0; s < 4; s++) acc += t[s] * j[s][b];
-                            H[tri(a, b)] += acc;
+                            for (int c = 0; c < 4; c++) {
+                                t[c] = 0;
+#pragma unroll
+                                for (int r = 0; r < 4; r++) t[c] += j[r][a] * Hc[4 * r + c];
+                            }
+#pragma unroll
+                            for (int b = 0; b <= a; b++) {
+                                T acc = 0;
+#pragma unroll
+                                for (int c = 0; c < 4; c++) acc += t[c] * j[c][b];
+                                h[tri(a, b)] += acc;
+                            }
+                        }
+                    } else {          // quadratic: every row of the block is an independent rank-1 term
+                        const int nr = type == C_CONTACT ? dim : 1;
+                        for (int r = 0; r < nr; r++) {
+                            const T D = sr_get(e, i + r, SR_D);
+                            T j[NV];
+                            jrow_load<T, NV>(e, i + r, nv, j);
+#pragma unroll
+                            for (int a = 0; a < NV; a++) j[a] = a < nv ? j[a] : T(0);
+#pragma unroll
+                            for (int a = 0; a < NV; a++) {
+                                const T Da = D * j[a];
+#pragma unroll
+                                for (int b = 0; b <= a; b++) h[tri(a, b)] += Da * j[b];
+                            }
                         }
                     }
                 }
             }
+            sub_sum_n<NT>(e, H);
             MW_TICK(t_d)
-            chol_reg<T, NV>(H);
-            chol_solve_reg<T, NV>(H, sr);
+            chol_reg<T, NV>(H[0]);
+            chol_solve_reg<T, NV>(H[0], sr);
             MW_TICK(t_e)
             MW_TOCK(e, L, 1, t_c, t_d)
             MW_TOCK(e, L, 2, t_d, t_e)
@@ -914,25 +962,28 @@ MW_HD void solve_impl(const Env<T> e) {
         }
         snorm = mw_sqrt(snorm);
         if (snorm < T(1e-15)) break;
-        for (int i = 0; i < nefc; i++) {
-            T j[NV], s = 0;
-            jrow_load<T, NV>(e, i, nv, j);
+        MW_SUBS(e, sub) {
+            for (int i = sub; i < nefc; i += e.nsub) {
+                T j[NV], s = 0;
+                jrow_load<T, NV>(e, i, nv, j);
 #pragma unroll
-            for (int k = 0; k < NV; k++) s += j[k] * sr[k];
-            sr_set(e, i, SR_JV, s);
+                for (int k = 0; k < NV; k++) s += j[k] * sr[k];
+                sr_set(e, i, SR_JV, s);
+            }
         }
+        MW_SYNC();
         const T gtol = m.tolerance * T(0.01) * snorm / scale;
         MW_TICK(t_g)
         MW_TOCK(e, L, 3, t_f, t_g)
         T c0, d1, d2;
-        line_eval(e, nefc, T(0), quadGauss, &c0, &d1, &d2);
+        line_eval(e, nblk, T(0), quadGauss, &c0, &d1, &d2);
         if (d1 >= 0 || d2 <= 0) break;
         T lo = 0, hi = -1, alpha = -d1 / d2;
         int nls = 0;
         for (int it = 0; it < m.sz.ls_iterations; it++) {
             T ca, da, dda, mag;
             nls++;
-            line_eval(e, nefc, alpha, quadGauss, &ca, &da, &dda, &mag);
+            line_eval(e, nblk, alpha, quadGauss, &ca, &da, &dda, &mag);
             if (mw_abs(da) < gtol) break;
             // single precision: the derivative cannot be resolved below its own rounding noise (a few ulp of the
             // magnitudes that cancel inside it); without this test ~10 % of the searches ran to ls_iterations and,
@@ -955,7 +1006,10 @@ MW_HD void solve_impl(const Env<T> e) {
 #pragma unroll
         for (int k = 0; k < NV; k++)
             if (k < nv) { e.R(L.qacc + k) += alpha * sr[k]; e.R(L.Ma + k) += alpha * e.R(L.Mv + k); }
-        for (int i = 0; i < nefc; i++) sr_set(e, i, SR_JAR, sr_get(e, i, SR_JAR) + alpha * sr_get(e, i, SR_JV));
+        MW_SUBS(e, sub) {
+            for (int i = sub; i < nefc; i += e.nsub) sr_set(e, i, SR_JAR, sr_get(e, i, SR_JAR) + alpha * sr_get(e, i, SR_JV));
+        }
+        MW_SYNC();
         const T old = cost;
         cost = update_constraint<T, NV>(e);
         MW_TICK(t_i)

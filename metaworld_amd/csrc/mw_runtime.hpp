@@ -149,8 +149,8 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Scratchpad sp, Env<T
     int g = 0;
     while (g + 1 < w.ngroups && block >= w.groups[g + 1].block0) g++;
     const GroupDev<T>& G = w.groups[g];
-    const int lane = (block - G.block0) * w.lpb + thread;
-    if (thread >= w.lpb || lane >= G.nenv) return false;
+    const int lane = (block - G.block0) * w.lpb + thread % w.lpb;   // threads t, t + lpb, ... are one environment's sub-lanes
+    if (lane >= G.nenv) return false;
     e->m = &G.m; e->col = G.col + lane; e->icol = G.icol + lane; e->stride = (unsigned)G.stride;
     e->cache_layout(G.L, G.m.sz.nv);
     *gid = G.gid[lane];

@@ -23,7 +23,7 @@ namespace {
 template <class F>
 __global__ void __launch_bounds__(64) k_lanes(F f, int words_per_lane, int lanes) {
     extern __shared__ float mw_scratchpad[];
-    f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, words_per_lane, lanes});
+    f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, words_per_lane, lanes, 64 / lanes});
 }
 
 struct Backend {
