@@ -110,6 +110,7 @@ struct Layout {
     int nreal;
     // int columns
     int icon, iefc, icount;   // icount: ncon, nefc, niter, flags
+    int iwork;                // constraint work items of make_constraints: (kind, id, first row) x maxefc
     int nint;
 };
 
@@ -158,7 +159,7 @@ inline Layout make_layout(const Sizes& s) {
     L.efcX = take(EFC_EXTRA * s.maxefc);
     L.nreal = o;
     o = 0;
-    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(20);   // + 16 phase timers (MW_SOLVER_TIMING builds): 8 solver phases, 6 pipeline stages
+    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(20); L.iwork = take(3 * s.maxefc);   // + 16 phase timers (MW_SOLVER_TIMING builds): 8 solver phases, 6 pipeline stages
     L.nint = o;
     return L;
 }

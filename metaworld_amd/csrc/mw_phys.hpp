@@ -461,76 +461,130 @@ MW_HD void add_jac_row(const Env<T> e, int row, int body, V3<T> point, V3<T> axi
     if (last >= 0) row_range(e, row, first, last);
 }
 
+// initialise rows r0 .. r0+n-1 of one constraint (type, id): empty Jacobian rows, descriptor, friction scale
 template <typename T>
-MW_HD int new_rows(const Env<T> e, int n, int type, int id) {
-    CModel<T>& m = e.model();
-    GRef<int> nefc = e.I(e.lay().icount + 1);
-    if (nefc + n > m.sz.maxefc) { e.I(e.lay().icount + 3) |= 1; return -1; }
-    const int r0 = nefc;
-    {   // constraint block list (IEFC slot 2 of entry k = first row of block k): one block per contact cone, else per row
-        GRef<int> nblk = e.I(e.lay().icount + IC_NBLK);
-        if (type == C_CONTACT) { IEFC(e, nblk, 2) = r0; nblk += 1; }
-        else { for (int k = 0; k < n; k++) IEFC(e, nblk + k, 2) = r0 + k; nblk += n; }
-    }
+MW_HD void init_rows(const Env<T> e, int r0, int n, int type, int id) {
+    const int nv = e.nv;
     for (int k = 0; k < n; k++) {
         IEFC(e, r0 + k, 0) = type; IEFC(e, r0 + k, 1) = id;
-        IEFC(e, r0 + k, 3) = m.sz.nv; IEFC(e, r0 + k, 4) = -1;
-        for (int i = 0; i < m.sz.nv; i++) EJ(e, r0 + k, i) = 0;
+        IEFC(e, r0 + k, 3) = nv; IEFC(e, r0 + k, 4) = -1;
+        for (int i = 0; i < nv; i++) EJ(e, r0 + k, i) = 0;
         EX(e, r0 + k, 0) = 0; EX(e, r0 + k, 1) = 0;
         // solver row descriptor: type + 16 * (rows in this cone block) + 256 * (index inside the block)
-        EX(e, r0 + k, 8) = 0; EX(e, r0 + k, 9) = T(type + 16 * n + 256 * k);
+        EX(e, r0 + k, 8) = 0; EX(e, r0 + k, 9) = type == C_CONTACT ? T(type + 16 * n + 256 * k) : T(type + 16);
     }
-    nefc += n;
-    return r0;
 }
 
+template <typename T>
+MW_HD void weld_rows(const Env<T> e, int q, int r0) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
+    const int b1 = m.eq_body1[q], b2 = m.eq_body2[q];
+    const T* data = m.eq_data + 11 * q;
+    V3<T> p1 = ld3(e, L.xpos + 3 * b1) + ld9(e, L.xmat + 9 * b1) * mv3(data + 3);
+    V3<T> p2 = ld3(e, L.xpos + 3 * b2) + ld9(e, L.xmat + 9 * b2) * mv3(data);
+    V3<T> cp = p1 - p2;
+    const T ts = data[10];
+    Q4<T> qa = qmul(ld4(e, L.xquat + 4 * b1), mq4(data + 6));
+    Q4<T> q2n = qconj(ld4(e, L.xquat + 4 * b2));
+    Q4<T> qr = qmul(q2n, qa);
+    init_rows(e, r0, 6, C_EQUALITY, q);
+    for (int k = 0; k < 3; k++) {
+        V3<T> ax{T(k == 0), T(k == 1), T(k == 2)};
+        add_jac_row(e, r0 + k, b1, p1, ax, false, T(1));
+        add_jac_row(e, r0 + k, b2, p2, ax, false, T(-1));
+    }
+    // rotational rows: 0.5 * imag( conj(q2) * (w1 - w2) * q1 * rel ) * torquescale
+    for (int pass = 0; pass < 2; pass++) {
+        const int b = pass ? b2 : b1;
+        const T sg = pass ? T(-1) : T(1);
+        int first = m.body_lastdof[b];
+        for (int i = m.body_lastdof[b]; i >= 0; i = m.dof_parentid[i]) {
+            V3<T> w = ld3(e, L.cdof + 6 * i);
+            Q4<T> q4 = qmul(qmul(q2n, Q4<T>{0, w.x, w.y, w.z}), qa);
+            EJ(e, r0 + 3, i) += sg * T(0.5) * q4.x * ts;
+            EJ(e, r0 + 4, i) += sg * T(0.5) * q4.y * ts;
+            EJ(e, r0 + 5, i) += sg * T(0.5) * q4.z * ts;
+            first = i;
+        }
+        if (m.body_lastdof[b] >= 0) for (int k = 3; k < 6; k++) row_range(e, r0 + k, first, m.body_lastdof[b]);
+    }
+    const T res[6] = {cp.x, cp.y, cp.z, ts * qr.x, ts * qr.y, ts * qr.z};
+    for (int k = 0; k < 6; k++) {
+        EX(e, r0 + k, 0) = res[k];
+        finish_row(e, r0 + k, m.eq_solref + 2 * q, m.eq_solimp + 5 * q, m.eq_invweight0[2 * q + (k >= 3)], (T*)nullptr, (T*)nullptr, (T*)nullptr);
+    }
+}
+
+template <typename T>
+MW_HD void limit_row(const Env<T> e, int id, int r) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
+    const int j = id >> 1, side = (id & 1) ? 1 : -1;
+    const T q = e.R(L.qpos + m.jnt_qposadr[j]), margin = m.jnt_margin[j];
+    const T dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - q);
+    init_rows(e, r, 1, C_LIMIT, id);
+    EJ(e, r, m.jnt_dofadr[j]) = T(-side);
+    row_range(e, r, m.jnt_dofadr[j], m.jnt_dofadr[j]);
+    EX(e, r, 0) = dist; EX(e, r, 1) = margin;
+    finish_row(e, r, m.jnt_solref + 2 * j, m.jnt_solimp + 5 * j, m.dof_invweight0[m.jnt_dofadr[j]], (T*)nullptr, (T*)nullptr, (T*)nullptr);
+}
+
+template <typename T>
+MW_HD void contact_rows(const Env<T> e, int c, int r0) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
+    const T dist = CON(e, c, 0), inc = CON(e, c, 13);
+    const int g1 = ICON(e, c, 0), g2 = ICON(e, c, 1), dim = ICON(e, c, 2);
+    init_rows(e, r0, dim, C_CONTACT, c);
+    const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
+    V3<T> pos{CON(e, c, 1), CON(e, c, 2), CON(e, c, 3)};
+    for (int k = 0; k < dim; k++) {
+        const int a = k < 3 ? k : k - 3;
+        V3<T> ax{CON(e, c, 4 + 3 * a), CON(e, c, 5 + 3 * a), CON(e, c, 6 + 3 * a)};
+        add_jac_row(e, r0 + k, b2, pos, ax, k >= 3, T(1));
+        add_jac_row(e, r0 + k, b1, pos, ax, k >= 3, T(-1));
+    }
+    EX(e, r0, 0) = dist; EX(e, r0, 1) = inc;
+    T solref[2] = {CON(e, c, 17), CON(e, c, 18)}, solimp[5];
+    for (int k = 0; k < 5; k++) solimp[k] = CON(e, c, 19 + k);
+    const T wt = m.geom_invweight0[2 * g1] + m.geom_invweight0[2 * g2];
+    T R0, B, imp;
+    finish_row(e, r0, solref, solimp, wt, &R0, &B, &imp);
+    // friction rows: R scaled by friction ratios (impratio 1), aref = -B * vel
+    const T f0 = CON(e, c, 14), f1 = CON(e, c, 15);
+    EX(e, r0, 8) = f0;   // mu
+    for (int k = 1; k < dim; k++) {
+        const T fk = k < 3 ? f0 : f1;
+        EX(e, r0 + k, 8) = fk;
+        const T R = R0 * f0 * f0 / (fk * fk);
+        T vel = 0;
+        for (int i = IEFC(e, r0 + k, 3); i <= IEFC(e, r0 + k, 4); i++) vel += EJ(e, r0 + k, i) * e.R(L.qvel + i);
+        EX(e, r0 + k, 2) = R; EX(e, r0 + k, 3) = 1 / R; EX(e, r0 + k, 4) = -B * vel;
+    }
+    CON(e, c, 24) = f0;  // mu = friction[0] * sqrt(R[1]/R[0]) with impratio 1
+}
+
+// Constraint rows in two passes: (A) every sub-lane redundantly walks the welds / limited joints / contacts and assigns
+// row ranges, the solver's block list and a work-item list (cheap: a few loads per constraint); (B) the work items
+// -- building the Jacobian rows, impedance, reference accelerations -- are split over the environment's sub-lanes.
 template <typename T>
 MW_STAGE_FN void make_constraints(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    const int nv = m.sz.nv;
-    e.I(L.icount + 1) = 0;
-    e.I(L.icount + IC_NBLK) = 0;
+    int nefc = 0, nblk = 0, nwork = 0, flags = 0;
+    const int maxefc = m.sz.maxefc;
+    auto work = [&](int kind, int id, int r0) {
+        e.I(L.iwork + 3 * nwork) = kind; e.I(L.iwork + 3 * nwork + 1) = id; e.I(L.iwork + 3 * nwork + 2) = r0;
+        nwork++;
+    };
     // ---- weld(mocap, hand): 3 translational + 3 rotational rows ----
     for (int q = 0; q < m.sz.neq; q++) {
-        const int b1 = m.eq_body1[q], b2 = m.eq_body2[q];
-        const T* data = m.eq_data + 11 * q;
-        V3<T> p1 = ld3(e, L.xpos + 3 * b1) + ld9(e, L.xmat + 9 * b1) * mv3(data + 3);
-        V3<T> p2 = ld3(e, L.xpos + 3 * b2) + ld9(e, L.xmat + 9 * b2) * mv3(data);
-        V3<T> cp = p1 - p2;
-        const T ts = data[10];
-        Q4<T> qa = qmul(ld4(e, L.xquat + 4 * b1), mq4(data + 6));
-        Q4<T> q2n = qconj(ld4(e, L.xquat + 4 * b2));
-        Q4<T> qr = qmul(q2n, qa);
-        const int r0 = new_rows(e, 6, C_EQUALITY, q);
-        if (r0 < 0) continue;
-        for (int k = 0; k < 6; k++) EX(e, r0 + k, 9) = T(C_EQUALITY + 16);
-        for (int k = 0; k < 3; k++) {
-            V3<T> ax{T(k == 0), T(k == 1), T(k == 2)};
-            add_jac_row(e, r0 + k, b1, p1, ax, false, T(1));
-            add_jac_row(e, r0 + k, b2, p2, ax, false, T(-1));
-        }
-        // rotational rows: 0.5 * imag( conj(q2) * (w1 - w2) * q1 * rel ) * torquescale
-        for (int pass = 0; pass < 2; pass++) {
-            const int b = pass ? b2 : b1;
-            const T sg = pass ? T(-1) : T(1);
-            int first = m.body_lastdof[b];
-            for (int i = m.body_lastdof[b]; i >= 0; i = m.dof_parentid[i]) {
-                V3<T> w = ld3(e, L.cdof + 6 * i);
-                Q4<T> q4 = qmul(qmul(q2n, Q4<T>{0, w.x, w.y, w.z}), qa);
-                EJ(e, r0 + 3, i) += sg * T(0.5) * q4.x * ts;
-                EJ(e, r0 + 4, i) += sg * T(0.5) * q4.y * ts;
-                EJ(e, r0 + 5, i) += sg * T(0.5) * q4.z * ts;
-                first = i;
-            }
-            if (m.body_lastdof[b] >= 0) for (int k = 3; k < 6; k++) row_range(e, r0 + k, first, m.body_lastdof[b]);
-        }
-        const T res[6] = {cp.x, cp.y, cp.z, ts * qr.x, ts * qr.y, ts * qr.z};
-        for (int k = 0; k < 6; k++) {
-            EX(e, r0 + k, 0) = res[k];
-            finish_row(e, r0 + k, m.eq_solref + 2 * q, m.eq_solimp + 5 * q, m.eq_invweight0[2 * q + (k >= 3)], (T*)nullptr, (T*)nullptr, (T*)nullptr);
-        }
+        if (nefc + 6 > maxefc) { flags |= 1; continue; }
+        work(C_EQUALITY, q, nefc);
+        for (int k = 0; k < 6; k++) IEFC(e, nblk + k, 2) = nefc + k;
+        nblk += 6; nefc += 6;
     }
     // ---- joint limits ----
     for (int j = 0; j < m.sz.njnt; j++) {
@@ -539,53 +593,45 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
         for (int side = -1; side <= 1; side += 2) {
             const T dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - q);
             if (dist < margin) {
-                const int r = new_rows(e, 1, C_LIMIT, j);
-                if (r < 0) continue;
-                EJ(e, r, m.jnt_dofadr[j]) = T(-side);
-                row_range(e, r, m.jnt_dofadr[j], m.jnt_dofadr[j]);
-                EX(e, r, 0) = dist; EX(e, r, 1) = margin;
-                finish_row(e, r, m.jnt_solref + 2 * j, m.jnt_solimp + 5 * j, m.dof_invweight0[m.jnt_dofadr[j]], (T*)nullptr, (T*)nullptr, (T*)nullptr);
+                if (nefc + 1 > maxefc) { flags |= 1; continue; }
+                work(C_LIMIT, 2 * j + (side > 0), nefc);
+                IEFC(e, nblk, 2) = nefc;
+                nblk++; nefc++;
             }
         }
     }
     // ---- contacts (elliptic cones, condim 3 or 4) ----
     const int ncon = e.I(L.icount);
     for (int c = 0; c < ncon; c++) {
-        ICON(e, c, 3) = -1;
         const T dist = CON(e, c, 0), inc = CON(e, c, 13);
-        if (dist >= inc) continue;
-        const int g1 = ICON(e, c, 0), g2 = ICON(e, c, 1), dim = ICON(e, c, 2);
-        const int r0 = new_rows(e, dim, C_CONTACT, c);
-        if (r0 < 0) continue;
-        ICON(e, c, 3) = r0;
-        const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
-        V3<T> pos{CON(e, c, 1), CON(e, c, 2), CON(e, c, 3)};
-        for (int k = 0; k < dim; k++) {
-            const int a = k < 3 ? k : k - 3;
-            V3<T> ax{CON(e, c, 4 + 3 * a), CON(e, c, 5 + 3 * a), CON(e, c, 6 + 3 * a)};
-            add_jac_row(e, r0 + k, b2, pos, ax, k >= 3, T(1));
-            add_jac_row(e, r0 + k, b1, pos, ax, k >= 3, T(-1));
+        const int dim = ICON(e, c, 2);
+        int adr = -1;
+        if (dist < inc) {
+            if (nefc + dim > maxefc) flags |= 1;
+            else {
+                adr = nefc;
+                work(C_CONTACT, c, nefc);
+                IEFC(e, nblk, 2) = nefc;
+                nblk++; nefc += dim;
+            }
         }
-        EX(e, r0, 0) = dist; EX(e, r0, 1) = inc;
-        T solref[2] = {CON(e, c, 17), CON(e, c, 18)}, solimp[5];
-        for (int k = 0; k < 5; k++) solimp[k] = CON(e, c, 19 + k);
-        const T wt = m.geom_invweight0[2 * g1] + m.geom_invweight0[2 * g2];
-        T R0, B, imp;
-        finish_row(e, r0, solref, solimp, wt, &R0, &B, &imp);
-        // friction rows: R scaled by friction ratios (impratio 1), aref = -B * vel
-        const T f0 = CON(e, c, 14), f1 = CON(e, c, 15);
-        EX(e, r0, 8) = f0;   // mu
-        for (int k = 1; k < dim; k++) {
-            const T fk = k < 3 ? f0 : f1;
-            EX(e, r0 + k, 8) = fk;
-            const T R = R0 * f0 * f0 / (fk * fk);
-            T vel = 0;
-            for (int i = IEFC(e, r0 + k, 3); i <= IEFC(e, r0 + k, 4); i++) vel += EJ(e, r0 + k, i) * e.R(L.qvel + i);
-            EX(e, r0 + k, 2) = R; EX(e, r0 + k, 3) = 1 / R; EX(e, r0 + k, 4) = -B * vel;
-        }
-        CON(e, c, 24) = f0;  // mu = friction[0] * sqrt(R[1]/R[0]) with impratio 1
+        ICON(e, c, 3) = adr;
     }
+    e.I(L.icount + 1) = nefc;
+    e.I(L.icount + IC_NBLK) = nblk;
+    if (flags) e.I(L.icount + 3) |= flags;
+    MW_SYNC();
+    MW_SUBS(e, sub) {
+        for (int w = sub; w < nwork; w += e.nsub) {
+            const int kind = e.I(L.iwork + 3 * w), id = e.I(L.iwork + 3 * w + 1), r0 = e.I(L.iwork + 3 * w + 2);
+            if (kind == C_EQUALITY) weld_rows(e, id, r0);
+            else if (kind == C_LIMIT) limit_row(e, id, r0);
+            else contact_rows(e, id, r0);
+        }
+    }
+    MW_SYNC();
 }
+
 
 // ------------------------------------------------------------------ Newton solver
 // Solver row scalars.  The solver sweeps the constraint rows many times (cost/force updates, Hessian assembly and
