@@ -585,10 +585,12 @@ MW_HD Shape<T> make_shape(const Env<T> e, int g) {
     return s;
 }
 
-template <typename T>
+// UNIFORM: every active lane of the wave tests the same geom pair (no sub-lanes), so the shapes' model constants can
+// live in scalar registers; with sub-lanes each sub-lane group has its own pair and nothing is wave-uniform.
+template <typename T, bool UNIFORM>
 MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h) {
-    const Shape<T> ua = a_.uniform(), ub = b_.uniform();
-    margin = mw_uniform(margin);
+    const Shape<T> ua = UNIFORM ? a_.uniform() : a_, ub = UNIFORM ? b_.uniform() : b_;
+    if (UNIFORM) margin = mw_uniform(margin);
     const int t1 = ua.type, t2 = ub.type;
     int n = -1;
     if (t1 == G_PLANE) n = plane_x(ua, ub, margin, h);
@@ -634,65 +636,95 @@ MW_HD bool obb_overlap(const Env<T> e, int g1, int g2, T margin) {
     return true;
 }
 
+// Narrow phase over the model's static pair list.  The pairs are tested in rounds of nsub (one pair per sub-lane of the
+// environment); the hits of a round are appended in pair order (exclusive prefix of the hit counts over the sub-lanes),
+// so the contact list is identical to a serial sweep whatever nsub is.
 template <typename T>
 MW_STAGE_FN void collision(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    int ncon = 0;
-    for (int p = 0; p < m.sz.npair; p++) {
-        const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
-        const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
-        const V3<T> p1 = ld3(e, L.geom_xpos + 3 * g1), p2 = ld3(e, L.geom_xpos + 3 * g2);
-        if (m.geom_type[g1] != G_PLANE) {
-            const T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
-            const V3<T> t = p1 - p2;
-            if (dot(t, t) > bound * bound) continue;
-            if (!obb_overlap(e, g1, g2, margin)) continue;   // mid-phase: oriented bounding boxes (conservative)
-        } else {
-            const V3<T> n{e.R(L.geom_xmat + 9 * g1 + 2), e.R(L.geom_xmat + 9 * g1 + 5), e.R(L.geom_xmat + 9 * g1 + 8)};
-            if (dot(p2 - p1, n) > m.geom_rbound[g2] + margin) continue;
+    const int npair = m.sz.npair, maxcon = m.sz.maxcon;
+    int ncon = 0, flags = 0;
+    for (int p0 = 0; p0 < npair; p0 += e.nsub) {
+        Hit<T> h[MW_NSLOT][16];
+        int n[MW_NSLOT], off[MW_NSLOT];
+        MW_SUBS(e, sub) {
+            const int p = p0 + sub;
+            int cnt = 0;
+            if (p < npair) {
+                const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+                const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
+                const V3<T> p1 = ld3(e, L.geom_xpos + 3 * g1), p2 = ld3(e, L.geom_xpos + 3 * g2);
+                bool near;
+                if (m.geom_type[g1] != G_PLANE) {
+                    const T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
+                    const V3<T> t = p1 - p2;
+                    near = dot(t, t) <= bound * bound && obb_overlap(e, g1, g2, margin);   // mid-phase: oriented boxes (conservative)
+                } else {
+                    const V3<T> nn{e.R(L.geom_xmat + 9 * g1 + 2), e.R(L.geom_xmat + 9 * g1 + 5), e.R(L.geom_xmat + 9 * g1 + 8)};
+                    near = dot(p2 - p1, nn) <= m.geom_rbound[g2] + margin;
+                }
+                if (near) {
+                    if (e.nsub == 1) cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)]);
+                    else cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)]);
+                    if (cnt < 0) cnt = 0;
+                }
+            }
+            n[MW_SLOT(sub)] = cnt;
         }
-        if (ncon >= m.sz.maxcon) { e.I(L.icount + 3) |= 2; break; }
-        Hit<T> h[16];
-        int n = collide_pair(make_shape(e, g1), make_shape(e, g2), margin, h);
-        if (n > m.sz.maxcon - ncon) { n = m.sz.maxcon - ncon; e.I(L.icount + 3) |= 2; }
-        if (n <= 0) continue;
-        // mixed contact parameters (equal priorities)
-        const T gap = mw_max(m.geom_gap[g1], m.geom_gap[g2]);
-        const int dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
-        const T s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
-        T mix;
-        if (s1 >= T(1e-15) && s2 >= T(1e-15)) mix = s1 / (s1 + s2);
-        else if (s1 < T(1e-15) && s2 < T(1e-15)) mix = T(0.5);
-        else mix = s1 < T(1e-15) ? T(0) : T(1);
-        T solref[2], solimp[5], fr[3];
-        const T *r1 = m.geom_solref + 2 * g1, *r2 = m.geom_solref + 2 * g2;
-        for (int k = 0; k < 2; k++) solref[k] = (r1[0] > 0 && r2[0] > 0) ? mix * r1[k] + (1 - mix) * r2[k] : mw_min(r1[k], r2[k]);
-        for (int k = 0; k < 5; k++) solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
-        for (int k = 0; k < 3; k++) fr[k] = mw_max(m.geom_friction[3 * g1 + k], m.geom_friction[3 * g2 + k]);
-        for (int i = 0; i < n; i++) {
-            const int c = ncon + i;
-            // frame: normal, then the MuJoCo tangent construction
-            V3<T> nx = normalized(h[i].normal);
-            V3<T> ny = (nx.y < T(0.5) && nx.y > T(-0.5)) ? v3<T>(0, 1, 0) : v3<T>(0, 0, 1);
-            ny = normalized(ny - nx * dot(nx, ny));
-            const V3<T> nz = cross(nx, ny);
-            CON(e, c, 0) = h[i].dist;
-            CON(e, c, 1) = h[i].pos.x; CON(e, c, 2) = h[i].pos.y; CON(e, c, 3) = h[i].pos.z;
-            CON(e, c, 4) = nx.x; CON(e, c, 5) = nx.y; CON(e, c, 6) = nx.z;
-            CON(e, c, 7) = ny.x; CON(e, c, 8) = ny.y; CON(e, c, 9) = ny.z;
-            CON(e, c, 10) = nz.x; CON(e, c, 11) = nz.y; CON(e, c, 12) = nz.z;
-            CON(e, c, 13) = margin - gap;
-            CON(e, c, 14) = fr[0]; CON(e, c, 15) = fr[1]; CON(e, c, 16) = fr[2];
-            CON(e, c, 17) = solref[0]; CON(e, c, 18) = solref[1];
-            for (int k = 0; k < 5; k++) CON(e, c, 19 + k) = solimp[k];
-            CON(e, c, 24) = fr[0];
-            ICON(e, c, 0) = g1; ICON(e, c, 1) = g2; ICON(e, c, 2) = dim; ICON(e, c, 3) = -1;
+        const int total = sub_scan(e, n, off);
+        MW_SUBS(e, sub) {
+            const int cnt = n[MW_SLOT(sub)], c0 = ncon + off[MW_SLOT(sub)];
+            if (cnt > 0) {
+                const int p = p0 + sub;
+                const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+                const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
+                // mixed contact parameters (equal priorities)
+                const T gap = mw_max(m.geom_gap[g1], m.geom_gap[g2]);
+                const int dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
+                const T s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
+                T mix;
+                if (s1 >= T(1e-15) && s2 >= T(1e-15)) mix = s1 / (s1 + s2);
+                else if (s1 < T(1e-15) && s2 < T(1e-15)) mix = T(0.5);
+                else mix = s1 < T(1e-15) ? T(0) : T(1);
+                T solref[2], solimp[5], fr[3];
+                const T r10 = m.geom_solref[2 * g1], r20 = m.geom_solref[2 * g2];
+                for (int k = 0; k < 2; k++) {
+                    const T a = m.geom_solref[2 * g1 + k], b = m.geom_solref[2 * g2 + k];
+                    solref[k] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : mw_min(a, b);
+                }
+                for (int k = 0; k < 5; k++) solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
+                for (int k = 0; k < 3; k++) fr[k] = mw_max(m.geom_friction[3 * g1 + k], m.geom_friction[3 * g2 + k]);
+                const Hit<T>* hh = h[MW_SLOT(sub)];
+                for (int i = 0; i < cnt; i++) {
+                    const int c = c0 + i;
+                    if (c >= maxcon) break;            // contact buffer full: the rest of the list is dropped (flagged below)
+                    // frame: normal, then the MuJoCo tangent construction
+                    V3<T> nx = normalized(hh[i].normal);
+                    V3<T> ny = (nx.y < T(0.5) && nx.y > T(-0.5)) ? v3<T>(0, 1, 0) : v3<T>(0, 0, 1);
+                    ny = normalized(ny - nx * dot(nx, ny));
+                    const V3<T> nz = cross(nx, ny);
+                    CON(e, c, 0) = hh[i].dist;
+                    CON(e, c, 1) = hh[i].pos.x; CON(e, c, 2) = hh[i].pos.y; CON(e, c, 3) = hh[i].pos.z;
+                    CON(e, c, 4) = nx.x; CON(e, c, 5) = nx.y; CON(e, c, 6) = nx.z;
+                    CON(e, c, 7) = ny.x; CON(e, c, 8) = ny.y; CON(e, c, 9) = ny.z;
+                    CON(e, c, 10) = nz.x; CON(e, c, 11) = nz.y; CON(e, c, 12) = nz.z;
+                    CON(e, c, 13) = margin - gap;
+                    CON(e, c, 14) = fr[0]; CON(e, c, 15) = fr[1]; CON(e, c, 16) = fr[2];
+                    CON(e, c, 17) = solref[0]; CON(e, c, 18) = solref[1];
+                    for (int k = 0; k < 5; k++) CON(e, c, 19 + k) = solimp[k];
+                    CON(e, c, 24) = fr[0];
+                    ICON(e, c, 0) = g1; ICON(e, c, 1) = g2; ICON(e, c, 2) = dim; ICON(e, c, 3) = -1;
+                }
+            }
         }
-        ncon += n;
+        ncon += total;
+        if (ncon > maxcon) { ncon = maxcon; flags |= 2; }
     }
     e.I(L.icount) = ncon;
+    if (flags) e.I(L.icount + 3) |= flags;
+    MW_SYNC();
 }
 
 }  // namespace mw

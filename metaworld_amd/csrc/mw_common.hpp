@@ -184,11 +184,13 @@ struct Env {
     MW_LDS T* lds;     // this lane's slice of the workgroup scratchpad (LDS on the device), slot k at lds[k * lds_stride]
     int lds_stride;
     int sub, nsub;     // sub-lane of this thread and sub-lanes per environment (cooperative row sweeps, see below)
+    int thr;           // thread index inside the workgroup
     int lds_rows;      // constraint rows whose solver scalars fit in the scratchpad (the rest stay in the column store)
     MW_HD void set_scratchpad(Scratchpad sp, int thread) {
         lds = (MW_LDS T*)sp.base + (sp.stride == 1 ? 0 : thread % sp.stride);
         lds_stride = sp.stride;
         sub = sp.stride == 1 ? 0 : thread / sp.stride;
+        thr = thread;
         nsub = sp.nsub;
         lds_rows = (int)(sp.words_per_lane * 4 / (SR_N * sizeof(T)));
     }
@@ -238,6 +240,19 @@ __device__ inline void sub_sum_n(const Env<T>& e, T (*p)[N]) {
         for (int k = 0; k < N; k++) p[0][k] += __shfl_xor(p[0][k], off);
     }
 }
+// exclusive prefix of one int per sub-lane (in sub-lane order) and the total
+template <typename T>
+__device__ inline int sub_scan(const Env<T>& e, const int* n, int* off) {
+    const int mine = n[0], base = e.thr % e.lds_stride;
+    int pre = 0, tot = 0;
+    for (int s = 0; s < e.nsub; s++) {
+        const int v = __shfl(mine, base + s * e.lds_stride);
+        if (s < e.sub) pre += v;
+        tot += v;
+    }
+    off[0] = pre;
+    return tot;
+}
 #else
 #define MW_SUBS(e, sub) for (int sub = 0; sub < (e).nsub; sub++)
 #define MW_SLOT(sub) (sub)
@@ -252,6 +267,12 @@ inline T sub_sum(const Env<T>& e, const T* p) {
         for (int s = 0; s < e.nsub; s++) q[s] = r[s];
     }
     return q[0];
+}
+template <typename T>
+inline int sub_scan(const Env<T>& e, const int* n, int* off) {
+    int tot = 0;
+    for (int s = 0; s < e.nsub; s++) { off[s] = tot; tot += n[s]; }
+    return tot;
 }
 template <int N, typename T>
 inline void sub_sum_n(const Env<T>& e, T (*p)[N]) {
