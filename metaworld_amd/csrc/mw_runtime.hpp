@@ -112,7 +112,7 @@ struct GroupDev {
     Layout L;
     T* col;
     int* icol;
-    size_t stride;
+    int lpb;          // environments per workgroup; the column store is chunked per workgroup: [chunk][element][lpb]
     int nenv, block0;
     const int* gid;   // lane -> global env index
 };
@@ -151,7 +151,12 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Scratchpad sp, Env<T
     const GroupDev<T>& G = w.groups[g];
     const int lane = (block - G.block0) * w.lpb + thread % w.lpb;   // threads t, t + lpb, ... are one environment's sub-lanes
     if (lane >= G.nenv) return false;
-    e->m = &G.m; e->col = G.col + lane; e->icol = G.icol + lane; e->stride = (unsigned)G.stride;
+    // element i of this environment: chunk base + i * lpb + (lane in chunk) -- consecutive elements of a workgroup's
+    // environments are adjacent in memory (a Jacobian row of 8 environments is a few cache lines, not one line per entry)
+    const size_t chunk = (size_t)(block - G.block0);
+    e->col = G.col + chunk * G.L.nreal * w.lpb + thread % w.lpb;
+    e->icol = G.icol + chunk * G.L.nint * w.lpb + thread % w.lpb;
+    e->m = &G.m; e->stride = (unsigned)w.lpb;
     e->cache_layout(G.L, G.m.sz.nv);
     *gid = G.gid[lane];
     return true;
@@ -300,7 +305,12 @@ class Context : public ContextBase {
         T* col = nullptr;
         int* icol = nullptr;
         int* gid_dev = nullptr;
-        size_t stride = 0;
+        int lpb = BLOCK;
+        size_t nchunk = 0;
+        size_t at(int i, int lane) const { return ((size_t)(lane / lpb) * L.nreal + i) * lpb + lane % lpb; }     // real column element
+        size_t iat(int i, int lane) const { return ((size_t)(lane / lpb) * L.nint + i) * lpb + lane % lpb; }     // int column element
+        size_t nreal_total() const { return nchunk * lpb * (size_t)L.nreal; }
+        size_t nint_total() const { return nchunk * lpb * (size_t)L.nint; }
         int nenv = 0, block0 = 0, model = 0;
         std::vector<int> gid;
     };
@@ -350,30 +360,30 @@ class Context : public ContextBase {
         for (int k = 0; k < 16; k++) d.c[k] = (T)s.c[k];
         return d;
     }
-    void make_group(Group& g, int model, const std::vector<int>& gids) {
+    void make_group(Group& g, int model, const std::vector<int>& gids, int lpb) {
         g.model = model;
         g.dm.reset(new DeviceModel<T, Backend>(*models[model]));
         g.L = make_layout(models[model]->sz);
         g.nenv = (int)gids.size();
         g.gid = gids;
-        g.stride = (size_t)((g.nenv + BLOCK - 1) / BLOCK) * BLOCK;
-        if ((double)g.stride * g.L.nreal >= 4294967295.0) throw std::runtime_error("group too large for 32-bit column indexing");
-        g.col = (T*)Backend::alloc(sizeof(T) * g.stride * g.L.nreal);
-        g.icol = (int*)Backend::alloc(sizeof(int) * g.stride * g.L.nint);
-        Backend::zero(g.col, sizeof(T) * g.stride * g.L.nreal);
-        Backend::zero(g.icol, sizeof(int) * g.stride * g.L.nint);
+        g.lpb = lpb;
+        g.nchunk = (size_t)((g.nenv + lpb - 1) / lpb);
+        g.col = (T*)Backend::alloc(sizeof(T) * g.nreal_total());
+        g.icol = (int*)Backend::alloc(sizeof(int) * g.nint_total());
+        Backend::zero(g.col, sizeof(T) * g.nreal_total());
+        Backend::zero(g.icol, sizeof(int) * g.nint_total());
         g.gid_dev = (int*)Backend::alloc(sizeof(int) * g.nenv);
         Backend::h2d(g.gid_dev, gids.data(), sizeof(int) * g.nenv);
     }
     void free_group(Group& g) { Backend::free(g.col); Backend::free(g.icol); Backend::free(g.gid_dev); g.col = nullptr; }
     GroupDev<T> dev_of(const Group& g) const {
         GroupDev<T> d{};
-        d.m = g.dm->m; d.L = g.L; d.col = g.col; d.icol = g.icol; d.stride = g.stride; d.nenv = g.nenv; d.block0 = g.block0; d.gid = g.gid_dev;
+        d.m = g.dm->m; d.L = g.L; d.col = g.col; d.icol = g.icol; d.lpb = g.lpb; d.nenv = g.nenv; d.block0 = g.block0; d.gid = g.gid_dev;
         return d;
     }
     void set_task_field(Group& g, int lane, int k, double v) {
         T x = (T)v;
-        Backend::h2d(g.col + (size_t)(g.L.task + k) * g.stride + lane, &x, sizeof(T));
+        Backend::h2d(g.col + g.at(g.L.task + k, lane), &x, sizeof(T));
     }
 
 public:
@@ -410,7 +420,7 @@ public:
         int gi = 0, blk = 0;
         for (auto& kv : by_model) {
             Group& g = groups_[gi];
-            make_group(g, kv.first, kv.second);
+            make_group(g, kv.first, kv.second, lpb_);
             g.block0 = blk;
             blk += (g.nenv + lpb_ - 1) / lpb_;
             for (int l = 0; l < g.nenv; l++) { env_group_[kv.second[l]] = gi; env_lane_[kv.second[l]] = l; }
@@ -458,14 +468,14 @@ public:
             Group g;
             std::vector<int> gids(kv.second.size());
             for (size_t i = 0; i < gids.size(); i++) gids[i] = (int)i;
-            make_group(g, kv.first, gids);
+            make_group(g, kv.first, gids, BLOCK);
             // seed the task block of each lane: task id, goal idx, rand_vec
-            std::vector<T> host((size_t)g.L.nstate * g.stride, (T)0);
+            std::vector<T> host(g.nreal_total(), (T)0);
             for (size_t l = 0; l < kv.second.size(); l++) {
                 const int t = kv.second[l].first, go = kv.second[l].second;
-                host[(size_t)(g.L.task + TK_TASK) * g.stride + l] = (T)t;
-                host[(size_t)(g.L.task + TK_GOAL) * g.stride + l] = (T)go;
-                for (int k = 0; k < 6; k++) host[(size_t)(g.L.task + TK_RANDVEC + k) * g.stride + l] = (T)tasks[t].goals[6 * go + k];
+                host[g.at(g.L.task + TK_TASK, (int)l)] = (T)t;
+                host[g.at(g.L.task + TK_GOAL, (int)l)] = (T)go;
+                for (int k = 0; k < 6; k++) host[g.at(g.L.task + TK_RANDVEC + k, (int)l)] = (T)tasks[t].goals[6 * go + k];
             }
             Backend::h2d(g.col, host.data(), host.size() * sizeof(T));
             GroupDev<T> gd = dev_of(g);
@@ -483,7 +493,7 @@ public:
             for (size_t l = 0; l < kv.second.size(); l++) {
                 const int t = kv.second[l].first, go = kv.second[l].second;
                 T* dst = snap.data() + snap_off_[t] + (long long)go * snap_stride_[t];
-                for (int k = 0; k < g.L.nstate; k++) dst[k] = host[(size_t)k * g.stride + l];
+                for (int k = 0; k < g.L.nstate; k++) dst[k] = host[g.at(k, (int)l)];
                 for (int k = 0; k < 39; k++) dst[g.L.nstate + k] = (T)obs[l * D + k];
             }
             Backend::free(d_o); Backend::free(d_g);
@@ -581,19 +591,19 @@ public:
         const Group& g = groups_.at(env_group_.at(gid));
         int cnt; const int off = offset_of(g.L, models[g.model]->sz, what, &cnt);
         if (n > cnt) n = cnt;
-        for (int k = 0; k < n; k++) { T x; Backend::d2h(&x, g.col + (size_t)(off + k) * g.stride + env_lane_[gid], sizeof(T)); out[k] = (double)x; }
+        for (int k = 0; k < n; k++) { T x; Backend::d2h(&x, g.col + g.at(off + k, env_lane_[gid]), sizeof(T)); out[k] = (double)x; }
     }
     void write_col(int gid, const char* what, int n, const double* in) override {
         Group& g = groups_.at(env_group_.at(gid));
         int cnt; const int off = offset_of(g.L, models[g.model]->sz, what, &cnt);
         if (n > cnt) n = cnt;
-        for (int k = 0; k < n; k++) { T x = (T)in[k]; Backend::h2d(g.col + (size_t)(off + k) * g.stride + env_lane_[gid], &x, sizeof(T)); }
+        for (int k = 0; k < n; k++) { T x = (T)in[k]; Backend::h2d(g.col + g.at(off + k, env_lane_[gid]), &x, sizeof(T)); }
     }
     void read_icol(int gid, const char* what, int n, int* out) override {
         const Group& g = groups_.at(env_group_.at(gid));
         int cnt; const int off = ioffset_of(g.L, models[g.model]->sz, what, &cnt);
         if (n > cnt) n = cnt;
-        for (int k = 0; k < n; k++) Backend::d2h(out + k, g.icol + (size_t)(off + k) * g.stride + env_lane_[gid], sizeof(int));
+        for (int k = 0; k < n; k++) Backend::d2h(out + k, g.icol + g.iat(off + k, env_lane_[gid]), sizeof(int));
     }
 };
 
