@@ -117,6 +117,13 @@ def main():
         per_launch_s = kernel_ms / 1e3 / args.steps
         bytes_launch = ALGO_BYTES_PER_ENV_STEP[args.precision] * N
         ach = bytes_launch / per_launch_s / 1e9
+        traffic = None                 # HBM bytes per launch from the committed PMC profile of this exact workload
+        prof = os.path.join(ROOT, "profiles", "r01_mt50_pmc.json")
+        if os.path.exists(prof):
+            with open(prof) as f:
+                pj = json.load(f)
+            if pj.get("workload") == workload and world == 1:
+                traffic = pj["fetch_bytes_per_launch"] + pj["write_bytes_per_launch"]
         out = {"metric": "env-steps/sec (whole node) MT50 @4096 envs/GPU; achieved HBM GB/s vs peak", "value": value,
                "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -124,9 +131,10 @@ def main():
                "config": {"workload": workload, "envs_per_gpu": N, "tasks_with_device_code": len(T.supported_tasks()),
                           "parallelism": f"dp{world} (independent env shards, no data-path collective)"},
                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                            "traffic": None, "kernel_ms_per_launch": kernel_ms / args.steps,
-                            "note": "algorithmic bytes/env-step x envs / HIP-event kernel time; the step kernel is "
-                                    "latency/issue bound, not HBM bound (DESIGN.md)"}}
+                            "traffic": traffic, "kernel_ms_per_launch": kernel_ms / args.steps,
+                            "note": "achieved = algorithmic bytes/env-step x envs / HIP-event kernel time; traffic = FETCH_SIZE + "
+                                    "WRITE_SIZE bytes per launch of the committed rocprofv3 profile (profiles/r01_mt50_pmc.json); the "
+                                    "step kernel is bound by the latency of its per-environment dependency chain, not by HBM (DESIGN.md 5)"}}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl_task)
         print(json.dumps(out))
