@@ -636,27 +636,27 @@ MW_HD bool obb_overlap(const Env<T> e, int g1, int g2, T margin) {
     return true;
 }
 
-// Narrow phase over the model's static pair list.  The pairs are tested in rounds of nsub (one pair per sub-lane of the
-// environment); the hits of a round are appended in pair order (exclusive prefix of the hit counts over the sub-lanes),
-// so the contact list is identical to a serial sweep whatever nsub is.
+// Collision over the model's static pair list, in two passes that both split the work over the environment's sub-lanes:
+// (1) broad + mid phase for every pair -> compacted, ordered candidate list; (2) narrow phase over the candidates in
+// rounds of nsub (so a round is nsub real narrow-phase calls, not nsub pairs of which most were culled).  Hits are
+// appended in pair order (exclusive prefix of the hit counts over the sub-lanes): the contact list is identical to a
+// serial sweep whatever nsub is.
 template <typename T>
 MW_STAGE_FN void collision(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int npair = m.sz.npair, maxcon = m.sz.maxcon;
-    int ncon = 0, flags = 0;
+    int ncand = 0;
     for (int p0 = 0; p0 < npair; p0 += e.nsub) {
-        Hit<T> h[MW_NSLOT][16];
-        int n[MW_NSLOT], off[MW_NSLOT];
+        int f[MW_NSLOT], foff[MW_NSLOT];
         MW_SUBS(e, sub) {
             const int p = p0 + sub;
-            int cnt = 0;
+            bool near = false;
             if (p < npair) {
                 const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
                 const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
                 const V3<T> p1 = ld3(e, L.geom_xpos + 3 * g1), p2 = ld3(e, L.geom_xpos + 3 * g2);
-                bool near;
                 if (m.geom_type[g1] != G_PLANE) {
                     const T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
                     const V3<T> t = p1 - p2;
@@ -665,19 +665,37 @@ MW_STAGE_FN void collision(const Env<T> e_) {
                     const V3<T> nn{e.R(L.geom_xmat + 9 * g1 + 2), e.R(L.geom_xmat + 9 * g1 + 5), e.R(L.geom_xmat + 9 * g1 + 8)};
                     near = dot(p2 - p1, nn) <= m.geom_rbound[g2] + margin;
                 }
-                if (near) {
-                    if (e.nsub == 1) cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)]);
-                    else cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)]);
-                    if (cnt < 0) cnt = 0;
-                }
             }
-            n[MW_SLOT(sub)] = cnt;
+            f[MW_SLOT(sub)] = near ? 1 : 0;
+        }
+        const int tot = sub_scan(e, f, foff);
+        MW_SUBS(e, sub) {
+            if (f[MW_SLOT(sub)]) e.I(L.ipair + ncand + foff[MW_SLOT(sub)]) = p0 + sub;
+        }
+        ncand += tot;
+    }
+    MW_SYNC();
+    int ncon = 0, flags = 0;
+    for (int c0 = 0; c0 < ncand; c0 += e.nsub) {
+        Hit<T> h[MW_NSLOT][16];
+        int n[MW_NSLOT], off[MW_NSLOT], pp[MW_NSLOT];
+        MW_SUBS(e, sub) {
+            int cnt = 0, p = -1;
+            if (c0 + sub < ncand) {
+                p = e.I(L.ipair + c0 + sub);
+                const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+                const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
+                if (e.nsub == 1) cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)]);
+                else cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)]);
+                if (cnt < 0) cnt = 0;
+            }
+            n[MW_SLOT(sub)] = cnt; pp[MW_SLOT(sub)] = p;
         }
         const int total = sub_scan(e, n, off);
         MW_SUBS(e, sub) {
             const int cnt = n[MW_SLOT(sub)], c0 = ncon + off[MW_SLOT(sub)];
             if (cnt > 0) {
-                const int p = p0 + sub;
+                const int p = pp[MW_SLOT(sub)];
                 const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
                 const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
                 // mixed contact parameters (equal priorities)

@@ -111,6 +111,7 @@ struct Layout {
     // int columns
     int icon, iefc, icount;   // icount: ncon, nefc, niter, flags
     int iwork;                // constraint work items of make_constraints: (kind, id, first row) x maxefc
+    int ipair;                // collision candidates (pair indices that passed the broad / mid phase), npair
     int nint;
 };
 
@@ -159,7 +160,7 @@ inline Layout make_layout(const Sizes& s) {
     L.efcX = take(EFC_EXTRA * s.maxefc);
     L.nreal = o;
     o = 0;
-    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(20); L.iwork = take(3 * s.maxefc);   // + 16 phase timers (MW_SOLVER_TIMING builds): 8 solver phases, 6 pipeline stages
+    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(20); L.iwork = take(3 * s.maxefc); L.ipair = take(s.npair > 0 ? s.npair : 1);   // + 16 phase timers (MW_SOLVER_TIMING builds): 8 solver phases, 6 pipeline stages
     L.nint = o;
     return L;
 }
