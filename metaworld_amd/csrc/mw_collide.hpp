@@ -636,109 +636,130 @@ MW_HD bool obb_overlap(const Env<T> e, int g1, int g2, T margin) {
     return true;
 }
 
-// Collision over the model's static pair list, in two passes that both split the work over the environment's sub-lanes:
-// (1) broad + mid phase for every pair -> compacted, ordered candidate list; (2) narrow phase over the candidates in
-// rounds of nsub (so a round is nsub real narrow-phase calls, not nsub pairs of which most were culled).  Hits are
-// appended in pair order (exclusive prefix of the hit counts over the sub-lanes): the contact list is identical to a
-// serial sweep whatever nsub is.
+// broad phase (bounding spheres / plane distance) + mid phase (oriented boxes, conservative) of pair p
+template <typename T>
+MW_HD bool pair_near(const Env<T> e, int p) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
+    const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+    const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
+    const V3<T> p1 = ld3(e, L.geom_xpos + 3 * g1), p2 = ld3(e, L.geom_xpos + 3 * g2);
+    if (m.geom_type[g1] != G_PLANE) {
+        const T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
+        const V3<T> t = p1 - p2;
+        return dot(t, t) <= bound * bound && obb_overlap(e, g1, g2, margin);
+    }
+    const V3<T> nn{e.R(L.geom_xmat + 9 * g1 + 2), e.R(L.geom_xmat + 9 * g1 + 5), e.R(L.geom_xmat + 9 * g1 + 8)};
+    return dot(p2 - p1, nn) <= m.geom_rbound[g2] + margin;
+}
+
+// contact records c0 .. c0+cnt-1 (dropped beyond maxcon) for the hits of pair p
+template <typename T>
+MW_HD void append_contacts(const Env<T> e, int p, int cnt, const Hit<T>* hh, int c0, int maxcon) {
+    CModel<T>& m = e.model();
+    const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+    const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
+    // mixed contact parameters (equal priorities)
+    const T gap = mw_max(m.geom_gap[g1], m.geom_gap[g2]);
+    const int dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
+    const T s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
+    T mix;
+    if (s1 >= T(1e-15) && s2 >= T(1e-15)) mix = s1 / (s1 + s2);
+    else if (s1 < T(1e-15) && s2 < T(1e-15)) mix = T(0.5);
+    else mix = s1 < T(1e-15) ? T(0) : T(1);
+    T solref[2], solimp[5], fr[3];
+    const T r10 = m.geom_solref[2 * g1], r20 = m.geom_solref[2 * g2];
+    for (int k = 0; k < 2; k++) {
+        const T a = m.geom_solref[2 * g1 + k], b = m.geom_solref[2 * g2 + k];
+        solref[k] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : mw_min(a, b);
+    }
+    for (int k = 0; k < 5; k++) solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
+    for (int k = 0; k < 3; k++) fr[k] = mw_max(m.geom_friction[3 * g1 + k], m.geom_friction[3 * g2 + k]);
+    for (int i = 0; i < cnt; i++) {
+        const int c = c0 + i;
+        if (c >= maxcon) break;            // contact buffer full: the rest of the list is dropped (flagged by the caller)
+        // frame: normal, then the MuJoCo tangent construction
+        V3<T> nx = normalized(hh[i].normal);
+        V3<T> ny = (nx.y < T(0.5) && nx.y > T(-0.5)) ? v3<T>(0, 1, 0) : v3<T>(0, 0, 1);
+        ny = normalized(ny - nx * dot(nx, ny));
+        const V3<T> nz = cross(nx, ny);
+        CON(e, c, 0) = hh[i].dist;
+        CON(e, c, 1) = hh[i].pos.x; CON(e, c, 2) = hh[i].pos.y; CON(e, c, 3) = hh[i].pos.z;
+        CON(e, c, 4) = nx.x; CON(e, c, 5) = nx.y; CON(e, c, 6) = nx.z;
+        CON(e, c, 7) = ny.x; CON(e, c, 8) = ny.y; CON(e, c, 9) = ny.z;
+        CON(e, c, 10) = nz.x; CON(e, c, 11) = nz.y; CON(e, c, 12) = nz.z;
+        CON(e, c, 13) = margin - gap;
+        CON(e, c, 14) = fr[0]; CON(e, c, 15) = fr[1]; CON(e, c, 16) = fr[2];
+        CON(e, c, 17) = solref[0]; CON(e, c, 18) = solref[1];
+        for (int k = 0; k < 5; k++) CON(e, c, 19 + k) = solimp[k];
+        CON(e, c, 24) = fr[0];
+        ICON(e, c, 0) = g1; ICON(e, c, 1) = g2; ICON(e, c, 2) = dim; ICON(e, c, 3) = -1;
+    }
+}
+
+// Collision over the model's static pair list.
+//  * no sub-lanes (nsub = 1): one sweep; every lane of the wave is at the SAME pair, so the shapes' model constants are
+//    wave-uniform (collide_pair<T, true>: scalar registers, scalar branches on the geom types);
+//  * sub-lanes: (1) broad + mid phase for every pair, split over the sub-lanes -> compacted, ordered candidate list;
+//    (2) narrow phase over the candidates in rounds of nsub (a round is nsub real narrow-phase calls, not nsub pairs of
+//    which most were culled); each sub-lane has its own pair, nothing is wave-uniform (collide_pair<T, false>).
+// Hits are appended in pair order (exclusive prefix of the hit counts over the sub-lanes): the contact list is identical
+// to a serial sweep whatever nsub is.
 template <typename T>
 MW_STAGE_FN void collision(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int npair = m.sz.npair, maxcon = m.sz.maxcon;
-    int ncand = 0;
-    for (int p0 = 0; p0 < npair; p0 += e.nsub) {
-        int f[MW_NSLOT], foff[MW_NSLOT];
-        MW_SUBS(e, sub) {
-            const int p = p0 + sub;
-            bool near = false;
-            if (p < npair) {
-                const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
-                const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
-                const V3<T> p1 = ld3(e, L.geom_xpos + 3 * g1), p2 = ld3(e, L.geom_xpos + 3 * g2);
-                if (m.geom_type[g1] != G_PLANE) {
-                    const T bound = m.geom_rbound[g1] + m.geom_rbound[g2] + margin;
-                    const V3<T> t = p1 - p2;
-                    near = dot(t, t) <= bound * bound && obb_overlap(e, g1, g2, margin);   // mid-phase: oriented boxes (conservative)
-                } else {
-                    const V3<T> nn{e.R(L.geom_xmat + 9 * g1 + 2), e.R(L.geom_xmat + 9 * g1 + 5), e.R(L.geom_xmat + 9 * g1 + 8)};
-                    near = dot(p2 - p1, nn) <= m.geom_rbound[g2] + margin;
-                }
-            }
-            f[MW_SLOT(sub)] = near ? 1 : 0;
-        }
-        const int tot = sub_scan(e, f, foff);
-        MW_SUBS(e, sub) {
-            if (f[MW_SLOT(sub)]) e.I(L.ipair + ncand + foff[MW_SLOT(sub)]) = p0 + sub;
-        }
-        ncand += tot;
-    }
-    MW_SYNC();
     int ncon = 0, flags = 0;
-    for (int c0 = 0; c0 < ncand; c0 += e.nsub) {
-        Hit<T> h[MW_NSLOT][16];
-        int n[MW_NSLOT], off[MW_NSLOT], pp[MW_NSLOT];
-        MW_SUBS(e, sub) {
-            int cnt = 0, p = -1;
-            if (c0 + sub < ncand) {
-                p = e.I(L.ipair + c0 + sub);
-                const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
-                const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
-                if (e.nsub == 1) cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)]);
-                else cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)]);
-                if (cnt < 0) cnt = 0;
-            }
-            n[MW_SLOT(sub)] = cnt; pp[MW_SLOT(sub)] = p;
+    if (e.nsub == 1) {
+        for (int p = 0; p < npair; p++) {
+            if (!pair_near(e, p)) continue;
+            const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+            const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
+            Hit<T> h[16];
+            int cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h);
+            if (cnt <= 0) continue;
+            append_contacts(e, p, cnt, h, ncon, maxcon);
+            ncon += cnt;
+            if (ncon > maxcon) { ncon = maxcon; flags |= 2; }
         }
-        const int total = sub_scan(e, n, off);
-        MW_SUBS(e, sub) {
-            const int cnt = n[MW_SLOT(sub)], c0 = ncon + off[MW_SLOT(sub)];
-            if (cnt > 0) {
-                const int p = pp[MW_SLOT(sub)];
-                const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
-                const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
-                // mixed contact parameters (equal priorities)
-                const T gap = mw_max(m.geom_gap[g1], m.geom_gap[g2]);
-                const int dim = m.geom_condim[g1] > m.geom_condim[g2] ? m.geom_condim[g1] : m.geom_condim[g2];
-                const T s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
-                T mix;
-                if (s1 >= T(1e-15) && s2 >= T(1e-15)) mix = s1 / (s1 + s2);
-                else if (s1 < T(1e-15) && s2 < T(1e-15)) mix = T(0.5);
-                else mix = s1 < T(1e-15) ? T(0) : T(1);
-                T solref[2], solimp[5], fr[3];
-                const T r10 = m.geom_solref[2 * g1], r20 = m.geom_solref[2 * g2];
-                for (int k = 0; k < 2; k++) {
-                    const T a = m.geom_solref[2 * g1 + k], b = m.geom_solref[2 * g2 + k];
-                    solref[k] = (r10 > 0 && r20 > 0) ? mix * a + (1 - mix) * b : mw_min(a, b);
-                }
-                for (int k = 0; k < 5; k++) solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
-                for (int k = 0; k < 3; k++) fr[k] = mw_max(m.geom_friction[3 * g1 + k], m.geom_friction[3 * g2 + k]);
-                const Hit<T>* hh = h[MW_SLOT(sub)];
-                for (int i = 0; i < cnt; i++) {
-                    const int c = c0 + i;
-                    if (c >= maxcon) break;            // contact buffer full: the rest of the list is dropped (flagged below)
-                    // frame: normal, then the MuJoCo tangent construction
-                    V3<T> nx = normalized(hh[i].normal);
-                    V3<T> ny = (nx.y < T(0.5) && nx.y > T(-0.5)) ? v3<T>(0, 1, 0) : v3<T>(0, 0, 1);
-                    ny = normalized(ny - nx * dot(nx, ny));
-                    const V3<T> nz = cross(nx, ny);
-                    CON(e, c, 0) = hh[i].dist;
-                    CON(e, c, 1) = hh[i].pos.x; CON(e, c, 2) = hh[i].pos.y; CON(e, c, 3) = hh[i].pos.z;
-                    CON(e, c, 4) = nx.x; CON(e, c, 5) = nx.y; CON(e, c, 6) = nx.z;
-                    CON(e, c, 7) = ny.x; CON(e, c, 8) = ny.y; CON(e, c, 9) = ny.z;
-                    CON(e, c, 10) = nz.x; CON(e, c, 11) = nz.y; CON(e, c, 12) = nz.z;
-                    CON(e, c, 13) = margin - gap;
-                    CON(e, c, 14) = fr[0]; CON(e, c, 15) = fr[1]; CON(e, c, 16) = fr[2];
-                    CON(e, c, 17) = solref[0]; CON(e, c, 18) = solref[1];
-                    for (int k = 0; k < 5; k++) CON(e, c, 19 + k) = solimp[k];
-                    CON(e, c, 24) = fr[0];
-                    ICON(e, c, 0) = g1; ICON(e, c, 1) = g2; ICON(e, c, 2) = dim; ICON(e, c, 3) = -1;
-                }
+    } else {
+        int ncand = 0;
+        for (int p0 = 0; p0 < npair; p0 += e.nsub) {
+            int f[MW_NSLOT], foff[MW_NSLOT];
+            MW_SUBS(e, sub) {
+                const int p = p0 + sub;
+                f[MW_SLOT(sub)] = (p < npair && pair_near(e, p)) ? 1 : 0;
             }
+            const int tot = sub_scan(e, f, foff);
+            MW_SUBS(e, sub) {
+                if (f[MW_SLOT(sub)]) e.I(L.ipair + ncand + foff[MW_SLOT(sub)]) = p0 + sub;
+            }
+            ncand += tot;
         }
-        ncon += total;
-        if (ncon > maxcon) { ncon = maxcon; flags |= 2; }
+        MW_SYNC();
+        for (int c0 = 0; c0 < ncand; c0 += e.nsub) {
+            Hit<T> h[MW_NSLOT][16];
+            int n[MW_NSLOT], off[MW_NSLOT], pp[MW_NSLOT];
+            MW_SUBS(e, sub) {
+                int cnt = 0, p = -1;
+                if (c0 + sub < ncand) {
+                    p = e.I(L.ipair + c0 + sub);
+                    const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+                    const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
+                    cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)]);
+                    if (cnt < 0) cnt = 0;
+                }
+                n[MW_SLOT(sub)] = cnt; pp[MW_SLOT(sub)] = p;
+            }
+            const int total = sub_scan(e, n, off);
+            MW_SUBS(e, sub) {
+                if (n[MW_SLOT(sub)] > 0) append_contacts(e, pp[MW_SLOT(sub)], n[MW_SLOT(sub)], h[MW_SLOT(sub)], ncon + off[MW_SLOT(sub)], maxcon);
+            }
+            ncon += total;
+            if (ncon > maxcon) { ncon = maxcon; flags |= 2; }
+        }
     }
     e.I(L.icount) = ncon;
     if (flags) e.I(L.icount + 3) |= flags;

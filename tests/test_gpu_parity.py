@@ -1,5 +1,7 @@
 """GPU parity tests: the HIP library (through the C ABI) against the oracle engine and the golden traces."""
 import numpy as np
+
+from metaworld_amd import tasks as T
 import pytest
 
 from tests.helpers import golden, make_env, oracle_for, replay_trace
@@ -64,15 +66,47 @@ def test_smoke_entry(gpulib):
     g.smoke()
 
 
-@pytest.mark.parametrize("task", ["push-v3", "pick-place-v3", "door-open-v3", "drawer-close-v3", "button-press-v3", "window-open-v3",
-                                  "peg-insert-side-v3", "stick-push-v3", "assembly-v3", "coffee-push-v3"])
+@pytest.mark.parametrize("task", T.ALL_V3)
 def test_gpu_task_matches_reference_trace(gpulib, task):
-    """MT10 tasks + a few contact-rich ones, fp64 on the GPU, one step from a synchronised state."""
+    """All 50 tasks, fp64 on the GPU: reset observation, then one step from a synchronised state, against the traces of
+    the unmodified reference Python (same tolerances as the host-harness test)."""
+    from tests.test_tasks_parity import TOL
     G = dict(golden(f"trace_{task}_seed42.npz"))
+    if task == "basketball-v3":     # only the first episode of a fresh env is history-free
+        G = {k: (v[:1] if getattr(v, "ndim", 0) >= 1 and len(v) == len(G["goal_idx"]) and k != "rand_vecs" else v) for k, v in G.items()}
     env = make_env(gpulib, task, n=len(G["goal_idx"]), precision="fp64")
     r = replay_trace(env, G, sync=True, steps=30)
     env.close()
-    assert r["reset"] < 1e-6 and r["obs"] < 1e-5 and r["reward"] < 1e-5 and r["success_mismatch"] == 0, r
+    tol_obs, tol_rew = TOL.get(task, (1e-5, 1e-5))
+    assert r["reset"] < 1e-4 and r["obs"] < tol_obs and r["reward"] < tol_rew and r["success_mismatch"] == 0, r
+
+
+@pytest.mark.parametrize("task", ["box-close-v3", "door-unlock-v3", "peg-unplug-side-v3", "sweep-into-v3"])
+def test_gpu_lanes_per_block_invariance(gpulib, task, monkeypatch):
+    """The mapping of environments to lanes (64 per wave, no sub-lanes ... 8 per wave, 8 cooperating sub-lanes each) must
+    not change the physics: contact lists identical, states equal up to summation order.  Guards the wave-uniformity
+    assumptions and the cross-sub-lane synchronisation, which the host harness cannot exercise."""
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    acts = np.random.default_rng(0).uniform(-1, 1, (40, 6, 4)).astype(np.float32)
+    runs = {}
+    for lpb in ("64", "16", "8"):
+        monkeypatch.setenv("MW_LANES_PER_BLOCK", lpb)
+        env = MetaWorldGpuVectorEnv("MT1", task, num_envs=6, seed=3, precision="fp64", lib=gpulib)
+        env.reset()
+        qp, nc = [], []
+        for t in range(40):
+            env.step(acts[t])
+            qp.append([env.ctx.read(e, "qpos") for e in range(6)])
+            nc.append([env.ctx.read_int(e, "icount")[:2] for e in range(6)])
+        runs[lpb] = (np.array(qp), np.array(nc))
+        env.close()
+    for lpb in ("16", "8"):
+        # identical while the trajectories are numerically the same; a contact that sits exactly at its margin may then flip
+        # between configurations (summation order differs), after which a chaotic scene drifts apart
+        assert (runs[lpb][1][:12] == runs["64"][1][:12]).all(), "contact / row counts differ"
+        assert np.abs(runs[lpb][0][:12] - runs["64"][0][:12]).max() < 1e-8
+        assert (runs[lpb][1] != runs["64"][1]).mean() < 0.1
+        assert np.abs(runs[lpb][0] - runs["64"][0]).max() < 1e-2
 
 
 def test_gpu_mt50_smoke(gpulib):
