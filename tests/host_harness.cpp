@@ -23,18 +23,19 @@ struct Backend {
     static void d2h(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
     // scratchpad rows per lane: MW_LDS_ROWS (default 24, so that typical scenes exercise both the scratchpad rows
     // and the column-store fallback rows of the solver)
-    static int lds_rows() { static int r = std::getenv("MW_LDS_ROWS") ? std::atoi(std::getenv("MW_LDS_ROWS")) : 24; return r; }
+    static int lds_rows() { const char* v = std::getenv("MW_LDS_ROWS"); return v ? std::atoi(v) : 24; }
     // emulated sub-lanes per environment (MW_NSUB = 1, 2, 4 or 8; default 8 = the small-batch device configuration)
-    static int nsub() { static int r = std::getenv("MW_NSUB") ? std::atoi(std::getenv("MW_NSUB")) : 8; return r; }
+    static int nsub() { const char* v = std::getenv("MW_NSUB"); return v ? std::atoi(v) : 8; }
     template <class F>
     static void launch(int nblocks, int lanes, F f) {   // one call per environment: the sub-lanes are emulated inside (MW_SUBS)
-        const int words = lds_rows() * mw::SR_N * 2;   // SR_N doubles per row
+        const int rows = lds_rows(), ns = nsub();
+        const int words = rows * mw::SR_N * 2;   // SR_N doubles per row
 #pragma omp parallel
         {
-            std::vector<double> pad((size_t)lds_rows() * mw::SR_N + 1, std::nan(""));   // LDS is not zero-initialised either
+            std::vector<double> pad((size_t)rows * mw::SR_N + 1, std::nan(""));   // LDS is not zero-initialised either
 #pragma omp for schedule(dynamic)
             for (int b = 0; b < nblocks; b++)
-                for (int t = 0; t < lanes; t++) f(b, t, mw::Scratchpad{pad.data(), words, 1, nsub()});
+                for (int t = 0; t < lanes; t++) f(b, t, mw::Scratchpad{pad.data(), words, 1, ns});
         }
     }
     static int compute_units() { return 256; }

@@ -73,3 +73,29 @@ def test_one_hot_and_obs_layout(hostsim):
     assert (np.abs(o[:, 36:39]) > 0).any()
     assert set(info) >= {"success", "near_object", "grasp_success", "grasp_reward", "in_place_reward", "obj_to_target", "unscaled_reward"}
     env.close()
+
+
+@pytest.mark.parametrize("task", ["box-close-v3", "door-unlock-v3", "pick-place-v3"])
+def test_sub_lane_and_scratchpad_invariance(hostsim, task, monkeypatch):
+    """The emulated sub-lane count (partial sums added in butterfly order) and the number of solver rows that fit the
+    scratchpad (LDS on the device, else column-store slots) must not change the physics beyond summation order."""
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    acts = np.random.default_rng(0).uniform(-1, 1, (25, 4, 4)).astype(np.float32)
+    runs = {}
+    for nsub, rows in (("1", "0"), ("1", "300"), ("4", "24"), ("8", "24"), ("8", "300")):
+        monkeypatch.setenv("MW_NSUB", nsub); monkeypatch.setenv("MW_LDS_ROWS", rows)
+        env = MetaWorldGpuVectorEnv("MT1", task, num_envs=4, seed=3, precision="fp64", lib=hostsim)
+        env.reset()
+        qp, nc = [], []
+        for t in range(25):
+            env.step(acts[t])
+            qp.append([env.ctx.read(e, "qpos") for e in range(4)])
+            nc.append([env.ctx.read_int(e, "icount")[:2] for e in range(4)])
+        runs[(nsub, rows)] = (np.array(qp), np.array(nc))
+        env.close()
+    ref = runs[("1", "0")]
+    assert np.abs(runs[("1", "300")][0] - ref[0]).max() == 0          # the scratchpad is storage only
+    assert np.abs(runs[("8", "300")][0] - runs[("8", "24")][0]).max() == 0
+    for k in (("4", "24"), ("8", "24")):
+        assert (runs[k][1] == ref[1]).all()
+        assert np.abs(runs[k][0] - ref[0]).max() < 1e-6     # resting multi-contact bodies amplify the summation-order noise
