@@ -167,7 +167,7 @@ inline Layout make_layout(const Sizes& s) {
 
 // workgroup scratchpad handed to every lane program: LDS on the device (stride = lanes per workgroup), a private
 // buffer per host thread in the test harness (stride 1)
-struct Scratchpad { MW_LDS void* base; int words_per_lane, stride, nsub; };   // 4-byte words per environment; slot k of env-lane t at base[k * stride + t]
+struct Scratchpad { MW_LDS void* base; int block_words, host_nsub; };   // 4-byte words of the whole workgroup; host_nsub > 0: host harness (one call per env, that many emulated sub-lanes)
 
 template <typename T> using CModel = const MW_CONST Model<T>;
 using CLayout = const MW_CONST Layout;
@@ -187,13 +187,15 @@ struct Env {
     int sub, nsub;     // sub-lane of this thread and sub-lanes per environment (cooperative row sweeps, see below)
     int thr;           // thread index inside the workgroup
     int lds_rows;      // constraint rows whose solver scalars fit in the scratchpad (the rest stay in the column store)
-    MW_HD void set_scratchpad(Scratchpad sp, int thread) {
-        lds = (MW_LDS T*)sp.base + (sp.stride == 1 ? 0 : thread % sp.stride);
-        lds_stride = sp.stride;
-        sub = sp.stride == 1 ? 0 : thread / sp.stride;
+    // lpb = environments per workgroup of this environment's group; threads t, t + lpb, ... are its sub-lanes
+    MW_HD void set_scratchpad(Scratchpad sp, int thread, int lpb) {
+        const bool host = sp.host_nsub > 0;
+        lds = (MW_LDS T*)sp.base + (host ? 0 : thread % lpb);
+        lds_stride = host ? 1 : lpb;
+        sub = host ? 0 : thread / lpb;
         thr = thread;
-        nsub = sp.nsub;
-        lds_rows = (int)(sp.words_per_lane * 4 / (SR_N * sizeof(T)));
+        nsub = host ? sp.host_nsub : 64 / lpb;
+        lds_rows = (int)((host ? sp.block_words : sp.block_words / lpb) * 4 / (SR_N * sizeof(T)));
     }
     MW_HD void cache_layout(const Layout& L, int nv_) {
         nv = nv_; o_efcJ = L.efcJ; o_efcX = L.efcX; o_con = L.con; o_icon = L.icon; o_iefc = L.iefc; o_icount = L.icount; o_task = L.task;
@@ -257,7 +259,7 @@ __device__ inline int sub_scan(const Env<T>& e, const int* n, int* off) {
 #else
 #define MW_SUBS(e, sub) for (int sub = 0; sub < (e).nsub; sub++)
 #define MW_SLOT(sub) (sub)
-constexpr int MW_NSLOT = 8;
+constexpr int MW_NSLOT = 16;
 #define MW_SYNC()
 template <typename T>
 inline T sub_sum(const Env<T>& e, const T* p) {

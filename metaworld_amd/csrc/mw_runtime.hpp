@@ -5,7 +5,7 @@
 // The including file must define, before inclusion, a `Backend` struct with:
 //   static void* alloc(size_t bytes);  static void free(void*);  static void zero(void*, size_t);
 //   static void h2d(void* dst, const void* src, size_t);  static void d2h(void* dst, const void* src, size_t);
-//   template <class F> static void launch(int nblocks, int lanes_per_block, F lane_program);   // F(block, thread, Scratchpad) for 64 threads / block
+//   template <class F> static void launch(int nblocks, F lane_program);   // F(block, thread, Scratchpad) for 64 threads / block
 //   static void sync();
 #pragma once
 #include <stdlib.h>
@@ -139,24 +139,27 @@ struct World {
     const long long* snap_off;  // per task: element offset of goal 0
     const int* snap_stride;   // per task: elements per snapshot (= nstate + 39)
     int max_episode_steps, terminate_on_success, one_hot, num_tasks;
-    int lpb;                  // lanes (environments) per 64-thread workgroup: 64, or fewer to spread a small batch over more CUs
     IOPtrs io;
 };
 
 template <typename T>
 MW_HD bool locate(const World<T>& w, int block, int thread, Scratchpad sp, Env<T>* e, int* gid) {
-    e->set_scratchpad(sp, thread);
     int g = 0;
     while (g + 1 < w.ngroups && block >= w.groups[g + 1].block0) g++;
     const GroupDev<T>& G = w.groups[g];
-    const int lane = (block - G.block0) * w.lpb + thread % w.lpb;   // threads t, t + lpb, ... are one environment's sub-lanes
+    const int lpb = G.lpb;                    // environments per workgroup of this group (64, or fewer + sub-lanes)
+    const bool host = sp.host_nsub > 0;       // host harness: one call per environment
+    if (host && thread >= lpb) return false;
+    const int lin = host ? thread : thread % lpb;
+    const int lane = (block - G.block0) * lpb + lin;
     if (lane >= G.nenv) return false;
+    e->set_scratchpad(sp, thread, lpb);
     // element i of this environment: chunk base + i * lpb + (lane in chunk) -- consecutive elements of a workgroup's
     // environments are adjacent in memory (a Jacobian row of 8 environments is a few cache lines, not one line per entry)
     const size_t chunk = (size_t)(block - G.block0);
-    e->col = G.col + chunk * G.L.nreal * w.lpb + thread % w.lpb;
-    e->icol = G.icol + chunk * G.L.nint * w.lpb + thread % w.lpb;
-    e->m = &G.m; e->stride = (unsigned)w.lpb;
+    e->col = G.col + chunk * G.L.nreal * lpb + lin;
+    e->icol = G.icol + chunk * G.L.nint * lpb + lin;
+    e->m = &G.m; e->stride = (unsigned)lpb;
     e->cache_layout(G.L, G.m.sz.nv);
     *gid = G.gid[lane];
     return true;
@@ -322,7 +325,6 @@ class Context : public ContextBase {
     long long* d_snap_off_ = nullptr;
     int* d_snap_stride_ = nullptr;
     int nblocks_ = 0, N_ = 0;
-    int lpb_ = BLOCK;   // lanes per workgroup of the step / reset launches (see choose_lpb)
     // io buffers (device) + host staging
     float* d_act_ = nullptr; size_t act_capacity_steps_ = 0;
     int* d_next_goal_ = nullptr;
@@ -339,7 +341,7 @@ class Context : public ContextBase {
         w.groups = d_groups_; w.ngroups = (int)groups_.size(); w.tasks = d_tasks_;
         w.snap = d_snap_; w.snap_off = d_snap_off_; w.snap_stride = d_snap_stride_;
         w.max_episode_steps = cfg.max_episode_steps; w.terminate_on_success = cfg.terminate_on_success;
-        w.one_hot = cfg.one_hot; w.num_tasks = cfg.num_tasks; w.lpb = lpb_;
+        w.one_hot = cfg.one_hot; w.num_tasks = cfg.num_tasks;
         if (with_io) {
             w.io.act = d_act_; w.io.next_goal = d_next_goal_; w.io.obs = d_obs_; w.io.reward = d_reward_;
             w.io.terminated = d_flags_; w.io.truncated = d_flags_ + N_; w.io.success = d_flags_ + 2 * N_; w.io.done = d_flags_ + 3 * N_;
@@ -402,27 +404,41 @@ public:
         for (int i = 0; i < N_; i++) by_model[tasks.at(env_task[i]).model].push_back(i);
         env_group_.assign(N_, 0); env_lane_.assign(N_, 0);
         groups_.resize(by_model.size());
-        // Lanes per workgroup.  The lane programs are latency-bound and a wave runs as long as its slowest lane
-        // (solver / collision iteration counts differ per environment), so a batch that does not fill the chip is
-        // spread over MORE, emptier waves: the fewest lanes per workgroup in {8, 16, 32, 64} that still gives every
-        // wave its own SIMD.  MW_LANES_PER_BLOCK overrides.
+        // Lanes per workgroup, per group.  The lane programs are latency-bound and a wave runs as long as its slowest lane,
+        // so while the batch does not fill the chip (one wave per SIMD: the lane programs use all 512 VGPRs) the groups
+        // are spread over MORE, emptier waves whose idle threads become sub-lanes.  Greedy: halve the lanes-per-workgroup
+        // of the group with the largest (row capacity x lanes per workgroup) -- the heaviest wave -- while the grid still
+        // fits.  MW_LANES_PER_BLOCK forces one value for every group.
+        std::map<int, int> lpb_of;
         {
             const char* ov = getenv("MW_LANES_PER_BLOCK");
-            lpb_ = BLOCK;
-            for (int cand : {32, 16, 8}) {
-                int nb = 0;
-                for (auto& kv : by_model) nb += ((int)kv.second.size() + cand - 1) / cand;
-                if (nb <= 4 * Backend::compute_units()) lpb_ = cand;   // one wave per SIMD (the lane programs use all 512 VGPRs)
+            const int budget = 4 * Backend::compute_units();
+            auto blocks = [&]() { int nb = 0; for (auto& kv : by_model) nb += ((int)kv.second.size() + lpb_of[kv.first] - 1) / lpb_of[kv.first]; return nb; };
+            for (auto& kv : by_model) lpb_of[kv.first] = BLOCK;
+            for (;;) {
+                int best = -1; double bw = -1;
+                for (auto& kv : by_model) {
+                    const int l = lpb_of[kv.first];
+                    if (l <= 4) continue;
+                    const double wgt = (double)models[kv.first]->sz.maxefc * l;
+                    if (wgt > bw) { bw = wgt; best = kv.first; }
+                }
+                if (best < 0) break;
+                lpb_of[best] /= 2;
+                if (blocks() > budget) { lpb_of[best] *= 2; break; }
             }
-            if (ov) lpb_ = atoi(ov);
-            if (lpb_ != 4 && lpb_ != 8 && lpb_ != 16 && lpb_ != 32 && lpb_ != 64) throw std::runtime_error("lanes per block must be 4, 8, 16, 32 or 64");
+            if (ov) {
+                const int l = atoi(ov);
+                if (l != 4 && l != 8 && l != 16 && l != 32 && l != 64) throw std::runtime_error("lanes per block must be 4, 8, 16, 32 or 64");
+                for (auto& kv : by_model) lpb_of[kv.first] = l;
+            }
         }
         int gi = 0, blk = 0;
         for (auto& kv : by_model) {
             Group& g = groups_[gi];
-            make_group(g, kv.first, kv.second, lpb_);
+            make_group(g, kv.first, kv.second, lpb_of[kv.first]);
             g.block0 = blk;
-            blk += (g.nenv + lpb_ - 1) / lpb_;
+            blk += (g.nenv + g.lpb - 1) / g.lpb;
             for (int l = 0; l < g.nenv; l++) { env_group_[kv.second[l]] = gi; env_lane_[kv.second[l]] = l; }
             gi++;
         }
@@ -484,8 +500,8 @@ public:
             const int D = obs_dim();
             double* d_o = (double*)Backend::alloc(sizeof(double) * g.nenv * D);
             World<T> w = world(false);
-            w.groups = d_g; w.ngroups = 1; w.io.obs = d_o; w.io.D = D; w.lpb = BLOCK;
-            Backend::launch((g.nenv + BLOCK - 1) / BLOCK, BLOCK, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_full(w, b, t, sp); });
+            w.groups = d_g; w.ngroups = 1; w.io.obs = d_o; w.io.D = D;
+            Backend::launch((g.nenv + BLOCK - 1) / BLOCK, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_full(w, b, t, sp); });
             Backend::sync();
             Backend::d2h(host.data(), g.col, host.size() * sizeof(T));
             std::vector<double> obs((size_t)g.nenv * D);
@@ -512,7 +528,7 @@ public:
         const uint8_t* dm = nullptr;
         if (mask) { Backend::h2d(d_mask_, mask, N_); dm = d_mask_; }
         World<T> w = world();
-        Backend::launch(nblocks_, lpb_, [w, dm] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_snap(w, dm, b, t, sp); });
+        Backend::launch(nblocks_, [w, dm] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_snap(w, dm, b, t, sp); });
         Backend::sync();
         if (obs_out) Backend::d2h(obs_out, d_obs_, sizeof(double) * N_ * obs_dim());
     }
@@ -522,7 +538,7 @@ public:
         Backend::h2d(d_act_, act, sizeof(float) * 4 * N_);
         if (next_goal) Backend::h2d(d_next_goal_, next_goal, sizeof(int) * N_);
         World<T> w = world();
-        Backend::launch(nblocks_, lpb_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+        Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
         Backend::sync();
         const int D = obs_dim();
         if (obs) Backend::d2h(obs, d_obs_, sizeof(double) * N_ * D);
@@ -552,7 +568,7 @@ public:
         Backend::timed_begin();
         for (int s = 0; s < nsteps; s++) {
             w.io.act = base + (size_t)(act_steps > 0 ? s % act_steps : 0) * 4 * N_;
-            Backend::launch(nblocks_, lpb_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
         }
         float ms = Backend::timed_end();
         if (kernel_ms) *kernel_ms = ms;
@@ -560,7 +576,7 @@ public:
 
     void debug(int what, int n) override {
         World<T> w = world();
-        Backend::launch(nblocks_, lpb_, [w, what, n] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_debug(w, what, n, b, t, sp); });
+        Backend::launch(nblocks_, [w, what, n] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_debug(w, what, n, b, t, sp); });
         Backend::sync();
     }
 

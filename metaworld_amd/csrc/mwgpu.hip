@@ -21,9 +21,9 @@ inline void hip_check(hipError_t e, const char* what) {
 namespace {
 // one wavefront per workgroup; the dynamic LDS allocation is the lanes' scratchpad (solver row scalars, mw_phys.hpp)
 template <class F>
-__global__ void __launch_bounds__(64) k_lanes(F f, int words_per_lane, int lanes) {
+__global__ void __launch_bounds__(64) k_lanes(F f, int block_words) {
     extern __shared__ float mw_scratchpad[];
-    f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, words_per_lane, lanes, 64 / lanes});
+    f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, block_words, 0});
 }
 
 struct Backend {
@@ -67,14 +67,14 @@ struct Backend {
         return (max_lds() / per_cu) & ~1023;
     }
     template <class F>
-    static void launch(int nblocks, int lanes, F f) {   // `lanes` of the 64 threads of each workgroup carry an environment
+    static void launch(int nblocks, F f) {
         static int configured = 0;
         const int bytes = lds_bytes(nblocks);
         if (bytes > configured) {
             hip_check(hipFuncSetAttribute((const void*)k_lanes<F>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute(LDS)");
             configured = bytes;
         }
-        hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), bytes, stream(), f, bytes / 4 / lanes, lanes);
+        hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), bytes, stream(), f, bytes / 4);
         hip_check(hipGetLastError(), "kernel launch");
     }
     static void sync() { hip_check(hipStreamSynchronize(stream()), "hipStreamSynchronize"); }

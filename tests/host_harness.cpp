@@ -27,7 +27,7 @@ struct Backend {
     // emulated sub-lanes per environment (MW_NSUB = 1, 2, 4 or 8; default 8 = the small-batch device configuration)
     static int nsub() { const char* v = std::getenv("MW_NSUB"); return v ? std::atoi(v) : 8; }
     template <class F>
-    static void launch(int nblocks, int lanes, F f) {   // one call per environment: the sub-lanes are emulated inside (MW_SUBS)
+    static void launch(int nblocks, F f) {   // one call per environment (locate() rejects threads >= lanes per workgroup): the sub-lanes are emulated inside (MW_SUBS)
         const int rows = lds_rows(), ns = nsub();
         const int words = rows * mw::SR_N * 2;   // SR_N doubles per row
 #pragma omp parallel
@@ -35,7 +35,7 @@ struct Backend {
             std::vector<double> pad((size_t)rows * mw::SR_N + 1, std::nan(""));   // LDS is not zero-initialised either
 #pragma omp for schedule(dynamic)
             for (int b = 0; b < nblocks; b++)
-                for (int t = 0; t < lanes; t++) f(b, t, mw::Scratchpad{pad.data(), words, 1, ns});
+                for (int t = 0; t < 64; t++) f(b, t, mw::Scratchpad{pad.data(), words, ns});
         }
     }
     static int compute_units() { return 256; }
