@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--benchmark", default="auto")
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp64 (parity precision) measurement at N=1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +136,22 @@ def main():
                             "note": "achieved = algorithmic bytes/env-step x envs / HIP-event kernel time; traffic = FETCH_SIZE + "
                                     "WRITE_SIZE bytes per launch of the committed rocprofv3 profile (profiles/r01_mt50_pmc.json); the "
                                     "step kernel is bound by the latency of its per-environment dependency chain, not by HBM (DESIGN.md 5)"}}
+        if world == 1 and args.precision == "fp32" and not args.no_parity_mode:
+            # the same workload in the parity precision (fp64 state/arithmetic: obs/reward <= 1e-5 vs the reference traces)
+            env.close()
+            env64 = MetaWorldGpuVectorEnv(bench, "reach-v3" if bench == "MT1" else None, num_envs=args.envs, seed=42 + rank,
+                                          use_one_hot=bench != "MT1", precision="fp64", device_id=local_rank)
+            env64.reset()
+            env64.ctx.upload_actions(acts)
+            env64.ctx.step_resident(args.warmup)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            k64 = env64.ctx.step_resident(args.steps)
+            torch.cuda.synchronize()
+            w64 = time.perf_counter() - t1
+            out["parity_mode"] = {"dtype": "f64", "value": N * args.steps / w64, "unit": "env-steps/s", "ms_per_step": w64 / args.steps * 1e3,
+                                  "kernel_ms_per_launch": k64 / args.steps}
+            env64.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl_task)
         print(json.dumps(out))

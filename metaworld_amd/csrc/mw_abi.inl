@@ -26,6 +26,7 @@ int MW_API(model_set_real)(mw_model* m, const char* f, const double* v, int n) {
 int MW_API(model_set_option)(mw_model* m, const char* name, double v) {
     std::string k = name;
     if (k == "timestep") m->d.timestep = v; else if (k == "tolerance") m->d.tolerance = v;
+    else if (k == "reset_tolerance") m->d.reset_tolerance = v;
     else if (k == "meaninertia") m->d.meaninertia = v; else if (k == "gravity_z") m->d.gravity[2] = v;
     else if (k == "iterations") m->d.sz.iterations = (int)v; else if (k == "ls_iterations") m->d.sz.ls_iterations = (int)v;
     else if (k == "maxcon") m->d.sz.maxcon = (int)v; else if (k == "maxefc") m->d.sz.maxefc = (int)v;

@@ -548,7 +548,7 @@ MW_HD int face_upgrade(const Shape<T>& c, const Shape<T>& box, Hit<T>* h, T marg
         const V3<T> d_ = t[i].pos - box.pos;
         bool inside = true;
         for (int j = 0; j < 3; j++)
-            if (j != k && mw_abs(dot(d_, col(box.mat, j))) > box.size[j] + T(1e-9)) inside = false;
+            if (j != k && mw_abs(dot(d_, col(box.mat, j))) > box.size[j] + (sizeof(T) == 8 ? T(1e-9) : T(1e-6))) inside = false;
         if (!inside) continue;
         t[mcount] = t[i];
         t[mcount].normal = -nf;
@@ -556,7 +556,8 @@ MW_HD int face_upgrade(const Shape<T>& c, const Shape<T>& box, Hit<T>* h, T marg
         mcount++;
     }
     // order-independent acceptance: some point lies on the face and none of the depth found by MPR is lost
-    if (mcount == 0 || deepest > h[0].dist + T(1e-6)) return 0;
+    // (single precision: MPR resolves the depth to ~2e-6 + rounding of the poses, so the comparison gets that much slack)
+    if (mcount == 0 || deepest > h[0].dist + (sizeof(T) == 8 ? T(1e-6) : T(2e-5))) return 0;
     for (int i = 0; i < mcount; i++) h[i] = t[i];
     return mcount;
 }

@@ -31,6 +31,7 @@ struct ModelData {
     std::map<std::string, std::vector<double>> reals;
     Sizes sz{};
     double timestep = 0.0025, tolerance = 1e-10, meaninertia = 1, gravity[3] = {0, 0, -9.81};
+    double reset_tolerance = 0;   // solver tolerance of the (double precision) reset-snapshot build; 0 = same as tolerance
     const std::vector<int>& I(const std::string& k) const {
         auto it = ints.find(k);
         if (it == ints.end()) throw std::runtime_error("model is missing int field " + k);
@@ -302,6 +303,7 @@ public:
 
 template <typename T, typename Backend>
 class Context : public ContextBase {
+    template <typename, typename> friend class Context;
     struct Group {
         std::unique_ptr<DeviceModel<T, Backend>> dm;
         Layout L;
@@ -447,10 +449,7 @@ public:
         for (auto& g : groups_) gd.push_back(dev_of(g));
         d_groups_ = (GroupDev<T>*)Backend::alloc(sizeof(GroupDev<T>) * gd.size());
         Backend::h2d(d_groups_, gd.data(), sizeof(GroupDev<T>) * gd.size());
-        std::vector<TaskDesc<T>> td;
-        for (auto& s : tasks) td.push_back(to_desc(s));
-        d_tasks_ = (TaskDesc<T>*)Backend::alloc(sizeof(TaskDesc<T>) * td.size());
-        Backend::h2d(d_tasks_, td.data(), sizeof(TaskDesc<T>) * td.size());
+        upload_tasks();
         const int D = obs_dim();
         d_next_goal_ = (int*)Backend::alloc(sizeof(int) * N_); Backend::zero(d_next_goal_, sizeof(int) * N_);
         d_mask_ = (uint8_t*)Backend::alloc(N_);
@@ -465,9 +464,46 @@ public:
         build_snapshots();
     }
 
+    void upload_tasks() {
+        std::vector<TaskDesc<T>> td;
+        for (auto& s : tasks) td.push_back(to_desc(s));
+        Backend::free(d_tasks_);
+        d_tasks_ = (TaskDesc<T>*)Backend::alloc(sizeof(TaskDesc<T>) * td.size());
+        Backend::h2d(d_tasks_, td.data(), sizeof(TaskDesc<T>) * td.size());
+    }
+
     // run the faithful reset once per (task, goal) and keep the resulting persistent state + reset observation
+    // The snapshots are always computed in double precision with the model's own solver tolerance, also for an fp32
+    // context: every episode then starts from the reference's reset state (to ~1e-7 after the cast) instead of from a
+    // single-precision replay of the 500 settling substeps.
     void build_snapshots() override {
         Backend::free(d_snap_); Backend::free(d_snap_off_); Backend::free(d_snap_stride_);
+        std::vector<T> snap;
+        if (sizeof(T) == 8) compute_snapshots(snap);
+        else {
+            Context<double, Backend> c64;
+            c64.cfg = cfg;
+            c64.tasks = tasks;
+            for (auto& m : models) {
+                auto md = std::make_shared<ModelData>(*m);
+                if (md->reset_tolerance > 0) md->tolerance = md->reset_tolerance;
+                c64.models.push_back(md);
+            }
+            c64.upload_tasks();
+            std::vector<double> s64;
+            c64.compute_snapshots(s64);
+            snap.assign(s64.begin(), s64.end());
+            snap_off_ = c64.snap_off_; snap_stride_ = c64.snap_stride_;
+        }
+        const long long total = (long long)snap.size();
+        d_snap_ = (T*)Backend::alloc(sizeof(T) * (size_t)(total > 0 ? total : 1));
+        Backend::h2d(d_snap_, snap.data(), sizeof(T) * (size_t)total);
+        d_snap_off_ = (long long*)Backend::alloc(sizeof(long long) * tasks.size());
+        Backend::h2d(d_snap_off_, snap_off_.data(), sizeof(long long) * tasks.size());
+        d_snap_stride_ = (int*)Backend::alloc(sizeof(int) * tasks.size());
+        Backend::h2d(d_snap_stride_, snap_stride_.data(), sizeof(int) * tasks.size());
+    }
+    void compute_snapshots(std::vector<T>& snap) {
         snap_off_.assign(tasks.size(), 0); snap_stride_.assign(tasks.size(), 0);
         long long total = 0;
         for (size_t t = 0; t < tasks.size(); t++) {
@@ -475,7 +511,7 @@ public:
             snap_off_[t] = total; snap_stride_[t] = ns;
             total += (long long)ns * (tasks[t].goals.size() / 6);
         }
-        std::vector<T> snap((size_t)total);
+        snap.assign((size_t)total, (T)0);
         // temporary groups: one per model, one lane per (task, goal)
         std::map<int, std::vector<std::pair<int, int>>> by_model;
         for (size_t t = 0; t < tasks.size(); t++)
@@ -515,12 +551,6 @@ public:
             Backend::free(d_o); Backend::free(d_g);
             free_group(g);
         }
-        d_snap_ = (T*)Backend::alloc(sizeof(T) * (size_t)(total > 0 ? total : 1));
-        Backend::h2d(d_snap_, snap.data(), sizeof(T) * (size_t)total);
-        d_snap_off_ = (long long*)Backend::alloc(sizeof(long long) * tasks.size());
-        Backend::h2d(d_snap_off_, snap_off_.data(), sizeof(long long) * tasks.size());
-        d_snap_stride_ = (int*)Backend::alloc(sizeof(int) * tasks.size());
-        Backend::h2d(d_snap_stride_, snap_stride_.data(), sizeof(int) * tasks.size());
     }
 
     void reset(const uint8_t* mask, const int* goal_idx, double* obs_out) override {

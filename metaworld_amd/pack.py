@@ -202,6 +202,7 @@ def pack_model(m: Model, probes, reloc_bodies=(), maxcon=64, maxefc=256, toleran
     reals["probe_pos"] = np.array(pp, dtype=np.float64).ravel()
     reals["probe_quat"] = np.array(pq, dtype=np.float64).ravel()
     options = dict(timestep=m.opt_timestep, tolerance=m.opt_tolerance if tolerance is None else tolerance,
+                   reset_tolerance=m.opt_tolerance,
                    meaninertia=float(A["stat_meaninertia"][0]), gravity_z=float(m.gravity[2]),
                    iterations=m.opt_iterations if iterations is None else iterations, ls_iterations=ls_iterations,
                    maxcon=maxcon, maxefc=maxefc, nreloc=len(reloc_bodies))
@@ -231,6 +232,7 @@ def _pack_lowered(m, probes, reloc_bodies, maxcon, maxefc, tolerance, iterations
     reals["eq_data"] = np.array(data)
     ints["probe_body"], reals["probe_pos"], reals["probe_quat"] = pb, pp.ravel(), pq.ravel()
     options = dict(timestep=m.opt_timestep, tolerance=m.opt_tolerance if tolerance is None else tolerance,
+                   reset_tolerance=m.opt_tolerance,
                    meaninertia=float(A["stat_meaninertia"][0]), gravity_z=float(m.gravity[2]),
                    iterations=m.opt_iterations if iterations is None else iterations, ls_iterations=ls_iterations,
                    maxcon=maxcon, maxefc=maxefc, nreloc=len(reloc_bodies))

@@ -83,6 +83,18 @@ def test_gpu_task_matches_reference_trace(gpulib, task):
 
 # (peg-unplug-side-v3 is excluded: the peg wedged in its hole is ill-conditioned -- the solver's converged point moves by
 # 1e-5 with the summation order, on the host harness with MW_NSUB=1 vs 8 just the same; it is a TOL exception already)
+@pytest.mark.parametrize("task", T.ALL_V3)
+def test_gpu_task_fp32_close_to_reference_trace(gpulib, task):
+    """The precision bench.py runs in: success flags exact, obs / reward within the fp32 contact-geometry floor."""
+    G = dict(golden(f"trace_{task}_seed42.npz"))
+    if task == "basketball-v3":
+        G = {k: (v[:1] if getattr(v, "ndim", 0) >= 1 and len(v) == len(G["goal_idx"]) and k != "rand_vecs" else v) for k, v in G.items()}
+    env = make_env(gpulib, task, n=len(G["goal_idx"]), precision="fp32")
+    r = replay_trace(env, G, sync=True, steps=30)
+    env.close()
+    assert r["reset"] < 1e-2 and r["obs"] < 1e-2 and r["reward"] < 5e-2 and r["success_mismatch"] == 0, r
+
+
 @pytest.mark.parametrize("task", ["box-close-v3", "door-unlock-v3", "shelf-place-v3", "sweep-into-v3"])
 def test_gpu_lanes_per_block_invariance(gpulib, task, monkeypatch):
     """The mapping of environments to lanes (64 per wave, no sub-lanes ... 8 per wave, 8 cooperating sub-lanes each) must
