@@ -421,7 +421,7 @@ public:
                 int best = -1; double bw = -1;
                 for (auto& kv : by_model) {
                     const int l = lpb_of[kv.first];
-                    if (l <= 4) continue;
+                    if (l <= 4) continue;      // (2 and 1 lanes help the heaviest scene alone but cost the others more: measured)
                     const double wgt = (double)models[kv.first]->sz.maxefc * l;
                     if (wgt > bw) { bw = wgt; best = kv.first; }
                 }
@@ -431,7 +431,7 @@ public:
             }
             if (ov) {
                 const int l = atoi(ov);
-                if (l != 4 && l != 8 && l != 16 && l != 32 && l != 64) throw std::runtime_error("lanes per block must be 4, 8, 16, 32 or 64");
+                if (l != 1 && l != 2 && l != 4 && l != 8 && l != 16 && l != 32 && l != 64) throw std::runtime_error("lanes per block must be a power of two <= 64");
                 for (auto& kv : by_model) lpb_of[kv.first] = l;
             }
         }
