@@ -49,7 +49,12 @@ typedef struct mw_task {
     double c[15];
 } mw_task;
 
-/* ---- model tables (replaces mujoco.MjModel.from_xml_path; reference call: gymnasium MujocoEnv.__init__) ---- */
+/* ---- model tables (replaces mujoco.MjModel.from_xml_path; reference call: gymnasium MujocoEnv.__init__) ----
+ * Fields: the int / real arrays listed in metaworld_amd/pack.py (INT_FIELDS, REAL_FIELDS; names follow mjModel) incl. the
+ * hull vertex graph of big meshes (mesh_nbradr, mesh_nbr, mesh_start, mesh_hill) for the hill-climbing support function.
+ * Options: timestep, tolerance (solver tolerance of the context's precision), reset_tolerance (tolerance of the
+ * double-precision reset-snapshot build; default = tolerance), meaninertia, gravity_z, iterations, ls_iterations,
+ * maxcon, maxefc (contact / constraint-row capacities per environment), nreloc. */
 mw_model* mw_model_new(void);
 int mw_model_set_int(mw_model* m, const char* field, const int32_t* v, int n);
 int mw_model_set_real(mw_model* m, const char* field, const double* v, int n);
