@@ -81,6 +81,14 @@ MW_STAGE_FN void kinematics(const Env<T> e_) {
         st3(e, L.xpos + 3 * b, pos);
         st4(e, L.xquat + 4 * b, quat);
         st9(e, L.xmat + 9 * b, R);
+    }
+    // The tree walk above is a serial chain (replicated on the sub-lanes: each reads back what it wrote itself); the
+    // per-body inertial quantities and the geom frames only depend on the finished body frames -> split over sub-lanes.
+    MW_SUBS(e, sub) {
+    for (int b = 1 + sub; b < nb; b += e.nsub) {
+        const V3<T> pos = ld3(e, L.xpos + 3 * b);
+        const Q4<T> quat = ld4(e, L.xquat + 4 * b);
+        const M3<T> R = ld9(e, L.xmat + 9 * b);
         // inertial frame and spatial inertia about the world origin: {m, m*c, J(xx,yy,zz,xy,xz,yz)}
         V3<T> c = pos + R * mv3(m.body_ipos + 3 * b);
         st3(e, L.xipos + 3 * b, c);
@@ -103,11 +111,13 @@ MW_STAGE_FN void kinematics(const Env<T> e_) {
         e.R(o + 8) = Ic[4] - mass * c.x * c.z;
         e.R(o + 9) = Ic[5] - mass * c.y * c.z;
     }
-    for (int g = 0; g < m.sz.ngeom; g++) {
+    for (int g = sub; g < m.sz.ngeom; g += e.nsub) {
         const int b = m.geom_bodyid[g];
         st3(e, L.geom_xpos + 3 * g, ld3(e, L.xpos + 3 * b) + ld9(e, L.xmat + 9 * b) * mv3(m.geom_pos + 3 * g));
         st9(e, L.geom_xmat + 9 * g, q2mat(qmul(ld4(e, L.xquat + 4 * b), mq4(m.geom_quat + 4 * g))));
     }
+    }
+    MW_SYNC();
 }
 
 // world pose of probe `p` (named body / geom / site frames the task layer reads)
@@ -243,11 +253,11 @@ MW_HD void mat_vec(const Env<T> e, int A, int n, const T* x, T* y) {
 }
 // factor the n x n matrix at A in place / solve with the factor at A, through registers
 template <typename T, int NV>
-MW_HD void chol_factor_via_reg(const Env<T> e, int A, int n) {
+MW_HD void chol_factor_via_reg(const Env<T> e, int A, int Lout, int n) {
     T h[NV * (NV + 1) / 2];
     tri_load<T, NV>(e, A, n, h);
     chol_reg<T, NV>(h);
-    tri_store<T, NV>(e, A, n, h);
+    tri_store<T, NV>(e, Lout, n, h);
 }
 template <typename T, int NV>
 MW_HD void chol_solve_via_reg(const Env<T> e, int A, int x, int n) {
@@ -275,30 +285,39 @@ MW_STAGE_FN void crb(const Env<T> e_) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nb = m.sz.nbody, nv = m.sz.nv;
-    for (int i = 0; i < 10 * nb; i++) e.R(L.crb + i) = e.R(L.cinert + i);
-    for (int b = nb - 1; b > 0; b--) {
-        const int p = m.body_parentid[b];
-        if (p > 0)
-            for (int k = 0; k < 10; k++) e.R(L.crb + 10 * p + k) += e.R(L.crb + 10 * b + k);
+    MW_SUBS(e, sub) {
+        // composite inertias: the leaf-to-root accumulation is a serial chain per component, the 10 components are
+        // independent -> one (or two) per sub-lane; same order of additions as a serial sweep
+        for (int k = sub; k < 10; k += e.nsub) {
+            for (int b = 0; b < nb; b++) e.R(L.crb + 10 * b + k) = e.R(L.cinert + 10 * b + k);
+            for (int b = nb - 1; b > 0; b--) {
+                const int p = m.body_parentid[b];
+                if (p > 0) e.R(L.crb + 10 * p + k) += e.R(L.crb + 10 * b + k);
+            }
+        }
+        for (int i = sub; i < nv * nv; i += e.nsub) e.R(L.qM + i) = 0;
     }
-    for (int i = 0; i < nv * nv; i++) e.R(L.qM + i) = 0;
-    for (int i = 0; i < nv; i++) {
-        T I[10], s[6], f[6];
-        const int b = m.dof_bodyid[i];
-        for (int k = 0; k < 10; k++) I[k] = e.R(L.crb + 10 * b + k);
-        for (int k = 0; k < 6; k++) s[k] = e.R(L.cdof + 6 * i + k);
-        inertia_mul(f, I, s);
-        for (int j = i; j >= 0; j = m.dof_parentid[j]) {
-            T v = 0;
-            for (int k = 0; k < 6; k++) v += e.R(L.cdof + 6 * j + k) * f[k];
-            if (j == i) v += m.dof_armature[i];
-            e.R(L.qM + i * nv + j) = v;
-            e.R(L.qM + j * nv + i) = v;
+    MW_SYNC();
+    MW_SUBS(e, sub) {
+        for (int i = sub; i < nv; i += e.nsub) {          // row / column i of M: one dof per sub-lane
+            T I[10], s[6], f[6];
+            const int b = m.dof_bodyid[i];
+            for (int k = 0; k < 10; k++) I[k] = e.R(L.crb + 10 * b + k);
+            for (int k = 0; k < 6; k++) s[k] = e.R(L.cdof + 6 * i + k);
+            inertia_mul(f, I, s);
+            for (int j = i; j >= 0; j = m.dof_parentid[j]) {
+                T v = 0;
+                for (int k = 0; k < 6; k++) v += e.R(L.cdof + 6 * j + k) * f[k];
+                if (j == i) v += m.dof_armature[i];
+                e.R(L.qM + i * nv + j) = v;
+                e.R(L.qM + j * nv + i) = v;
+            }
         }
     }
-    for (int i = 0; i < nv * nv; i++) e.R(L.qL + i) = e.R(L.qM + i);
-    if (nv <= NV_SMALL) chol_factor_via_reg<T, NV_SMALL>(e, L.qL, nv);
-    else chol_factor_via_reg<T, NV_LARGE>(e, L.qL, nv);
+    MW_SYNC();
+    // Cholesky factor of M (lower triangle) into qL, through registers (replicated on the sub-lanes)
+    if (nv <= NV_SMALL) chol_factor_via_reg<T, NV_SMALL>(e, L.qM, L.qL, nv);
+    else chol_factor_via_reg<T, NV_LARGE>(e, L.qM, L.qL, nv);
 }
 
 // ------------------------------------------------------------------ bias forces (RNE), passive, actuation
@@ -357,13 +376,18 @@ MW_STAGE_FN void smooth_forces(const Env<T> e_) {
         e.R(L.cfrc + 6 * b) = Ia[0] + tn.x; e.R(L.cfrc + 6 * b + 1) = Ia[1] + tn.y; e.R(L.cfrc + 6 * b + 2) = Ia[2] + tn.z;
         e.R(L.cfrc + 6 * b + 3) = Ia[3] + tf.x; e.R(L.cfrc + 6 * b + 4) = Ia[4] + tf.y; e.R(L.cfrc + 6 * b + 5) = Ia[5] + tf.z;
     }
-    for (int b = nb - 1; b > 0; b--) {
-        const int p = m.body_parentid[b];
-        if (p > 0)
-            for (int k = 0; k < 6; k++) e.R(L.cfrc + 6 * p + k) += e.R(L.cfrc + 6 * b + k);
+    MW_SYNC();
+    MW_SUBS(e, sub) {
+        for (int k = sub; k < 6; k += e.nsub)          // leaf-to-root force accumulation: one component per sub-lane
+            for (int b = nb - 1; b > 0; b--) {
+                const int p = m.body_parentid[b];
+                if (p > 0) e.R(L.cfrc + 6 * p + k) += e.R(L.cfrc + 6 * b + k);
+            }
     }
+    MW_SYNC();
     // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
-    for (int i = 0; i < nv; i++) {
+    MW_SUBS(e, sub)
+    for (int i = sub; i < nv; i += e.nsub) {
         T bias = 0;
         const int b = m.dof_bodyid[i];
         for (int k = 0; k < 6; k++) bias += e.R(L.cdof + 6 * i + k) * e.R(L.cfrc + 6 * b + k);
@@ -374,6 +398,7 @@ MW_STAGE_FN void smooth_forces(const Env<T> e_) {
             f -= m.jnt_stiffness[j] * (e.R(L.qpos + m.jnt_qposadr[j]) - m.jnt_springref[j]);
         e.R(L.smooth + i) = f;
     }
+    MW_SYNC();
     for (int u = 0; u < m.sz.nu; u++) {
         const T c = mw_clamp(e.R(L.ctrl + u), m.act_ctrlrange[2 * u], m.act_ctrlrange[2 * u + 1]);
         e.R(L.smooth + m.act_dofid[u]) += m.act_kp[u] * (c - e.R(L.qpos + m.act_qposid[u]));
