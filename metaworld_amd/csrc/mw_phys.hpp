@@ -276,7 +276,17 @@ MW_HD void chol_factor_solve_via_reg(const Env<T> e, int A, int x, int n) {   //
     chol_solve_reg<T, NV>(h, v);
     vec_store<T, NV>(e, x, n, v);
 }
-constexpr int NV_SMALL = 11, NV_LARGE = 17;   // nv of the 36 models is 10, 11, 15, 16 or 17
+// nv of the 36 scenes is 10, 11, 15, 16 or 17: the register-resident routines are instantiated for exactly those sizes
+// (H for nv = 15 is 120 registers instead of 153: together with four Jacobian rows it still fits the 256 architectural
+// VGPRs, which a 17-padded H does not -- accumulating in AccVGPRs costs two extra moves per FMA)
+#define MW_NV_DISPATCH(nv, CALL)                                                              \
+    switch (nv) {                                                                             \
+    case 10: { constexpr int NVC = 10; CALL; break; }                                         \
+    case 11: { constexpr int NVC = 11; CALL; break; }                                         \
+    case 15: { constexpr int NVC = 15; CALL; break; }                                         \
+    case 16: { constexpr int NVC = 16; CALL; break; }                                         \
+    default: { constexpr int NVC = 17; CALL; break; }                                         \
+    }
 
 // ------------------------------------------------------------------ mass matrix
 template <typename T>
@@ -316,8 +326,7 @@ MW_STAGE_FN void crb(const Env<T> e_) {
     }
     MW_SYNC();
     // Cholesky factor of M (lower triangle) into qL, through registers (replicated on the sub-lanes)
-    if (nv <= NV_SMALL) chol_factor_via_reg<T, NV_SMALL>(e, L.qM, L.qL, nv);
-    else chol_factor_via_reg<T, NV_LARGE>(e, L.qM, L.qL, nv);
+    MW_NV_DISPATCH(nv, (chol_factor_via_reg<T, NVC>(e, L.qM, L.qL, nv)))
 }
 
 // ------------------------------------------------------------------ bias forces (RNE), passive, actuation
@@ -404,8 +413,7 @@ MW_STAGE_FN void smooth_forces(const Env<T> e_) {
         e.R(L.smooth + m.act_dofid[u]) += m.act_kp[u] * (c - e.R(L.qpos + m.act_qposid[u]));
     }
     for (int i = 0; i < nv; i++) e.R(L.qacc_smooth + i) = e.R(L.smooth + i);
-    if (nv <= NV_SMALL) chol_solve_via_reg<T, NV_SMALL>(e, L.qL, L.qacc_smooth, nv);
-    else chol_solve_via_reg<T, NV_LARGE>(e, L.qL, L.qacc_smooth, nv);
+    MW_NV_DISPATCH(nv, (chol_solve_via_reg<T, NVC>(e, L.qL, L.qacc_smooth, nv)))
 }
 
 // ------------------------------------------------------------------ constraint rows
@@ -1102,8 +1110,7 @@ MW_STAGE_FN void solve(const Env<T> e_) {
         for (int k = 0; k < nv; k++) { e.R(L.qacc + k) = e.R(L.qacc_smooth + k); e.R(L.qfrc_c + k) = 0; }
         return;
     }
-    if (nv <= NV_SMALL) solve_impl<T, NV_SMALL>(e);
-    else solve_impl<T, NV_LARGE>(e);
+    MW_NV_DISPATCH(nv, (solve_impl<T, NVC>(e)))
 }
 
 // ------------------------------------------------------------------ pipeline
@@ -1152,8 +1159,7 @@ MW_STAGE_FN void substep(const Env<T> e_) {
         e.R(L.qH + a * nv + a) += h * m.dof_damping[a];
         e.R(L.search + a) = e.R(L.smooth + a) + e.R(L.qfrc_c + a);
     }
-    if (nv <= NV_SMALL) chol_factor_solve_via_reg<T, NV_SMALL>(e, L.qH, L.search, nv);
-    else chol_factor_solve_via_reg<T, NV_LARGE>(e, L.qH, L.search, nv);
+    MW_NV_DISPATCH(nv, (chol_factor_solve_via_reg<T, NVC>(e, L.qH, L.search, nv)))
     for (int k = 0; k < nv; k++) e.R(L.qvel + k) += h * e.R(L.search + k);
     for (int j = 0; j < m.sz.njnt; j++) {
         const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
