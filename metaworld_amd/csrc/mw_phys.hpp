@@ -209,8 +209,10 @@ MW_HD void tri_store(const Env<T> e, int A, int n, const T* h) {
         for (int j = 0; j <= i; j++)
             if (i < n) e.R(A + i * n + j) = h[tri(i, j)];
 }
+// (the reciprocals of the diagonal are kept so that the 136 + 34 divisions of a factor + solve become multiplications:
+//  a division is ~10 instructions in fp32 and more in fp64, the Cholesky runs 4-5 times per dynamics evaluation)
 template <typename T, int NV>
-MW_HD void chol_reg(T* h) {
+MW_HD void chol_reg(T* h, T* inv) {
 #pragma unroll
     for (int i = 0; i < NV; i++) {
 #pragma unroll
@@ -218,26 +220,26 @@ MW_HD void chol_reg(T* h) {
             T s = h[tri(i, j)];
 #pragma unroll
             for (int k = 0; k < j; k++) s -= h[tri(i, k)] * h[tri(j, k)];
-            if (i == j) h[tri(i, i)] = mw_sqrt(s < T(1e-15) ? T(1e-15) : s);
-            else h[tri(i, j)] = s / h[tri(j, j)];
+            if (i == j) { h[tri(i, i)] = mw_sqrt(s < T(1e-15) ? T(1e-15) : s); inv[i] = T(1) / h[tri(i, i)]; }
+            else h[tri(i, j)] = s * inv[j];
         }
     }
 }
 template <typename T, int NV>
-MW_HD void chol_solve_reg(const T* h, T* x) {
+MW_HD void chol_solve_reg(const T* h, const T* inv, T* x) {
 #pragma unroll
     for (int i = 0; i < NV; i++) {
         T s = x[i];
 #pragma unroll
         for (int k = 0; k < i; k++) s -= h[tri(i, k)] * x[k];
-        x[i] = s / h[tri(i, i)];
+        x[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = NV - 1; i >= 0; i--) {
         T s = x[i];
 #pragma unroll
         for (int k = i + 1; k < NV; k++) s -= h[tri(k, i)] * x[k];
-        x[i] = s / h[tri(i, i)];
+        x[i] = s * inv[i];
     }
 }
 // y = M x with M the full row-major n x n matrix at A (loads only)
@@ -254,9 +256,9 @@ MW_HD void mat_vec(const Env<T> e, int A, int n, const T* x, T* y) {
 // factor the n x n matrix at A in place / solve with the factor at A, through registers
 template <typename T, int NV>
 MW_HD void chol_factor_via_reg(const Env<T> e, int A, int Lout, int n) {
-    T h[NV * (NV + 1) / 2];
+    T h[NV * (NV + 1) / 2], inv[NV];
     tri_load<T, NV>(e, A, n, h);
-    chol_reg<T, NV>(h);
+    chol_reg<T, NV>(h, inv);
     tri_store<T, NV>(e, Lout, n, h);
 }
 template <typename T, int NV>
@@ -264,7 +266,10 @@ MW_HD void chol_solve_via_reg(const Env<T> e, int A, int x, int n) {
     T h[NV * (NV + 1) / 2], v[NV];
     tri_load<T, NV>(e, A, n, h);
     vec_load<T, NV>(e, x, n, v);
-    chol_solve_reg<T, NV>(h, v);
+    T inv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) inv[i] = T(1) / h[tri(i, i)];
+    chol_solve_reg<T, NV>(h, inv, v);
     vec_store<T, NV>(e, x, n, v);
 }
 template <typename T, int NV>
@@ -272,8 +277,9 @@ MW_HD void chol_factor_solve_via_reg(const Env<T> e, int A, int x, int n) {   //
     T h[NV * (NV + 1) / 2], v[NV];
     tri_load<T, NV>(e, A, n, h);
     vec_load<T, NV>(e, x, n, v);
-    chol_reg<T, NV>(h);
-    chol_solve_reg<T, NV>(h, v);
+    T inv[NV];
+    chol_reg<T, NV>(h, inv);
+    chol_solve_reg<T, NV>(h, inv, v);
     vec_store<T, NV>(e, x, n, v);
 }
 // nv of the 36 scenes is 10, 11, 15, 16 or 17: the register-resident routines are instantiated for exactly those sizes
@@ -1013,8 +1019,9 @@ MW_HD void solve_impl(const Env<T> e) {
             }
             sub_sum_n<NT>(e, H);
             MW_TICK(t_d)
-            chol_reg<T, NV>(H[0]);
-            chol_solve_reg<T, NV>(H[0], sr);
+            T inv[NV];
+            chol_reg<T, NV>(H[0], inv);
+            chol_solve_reg<T, NV>(H[0], inv, sr);
             MW_TICK(t_e)
             MW_TOCK(e, L, 1, t_c, t_d)
             MW_TOCK(e, L, 2, t_d, t_e)
