@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
 env = MetaWorldGpuVectorEnv("MT50", num_envs=200, seed=1, use_one_hot=True, precision="fp32", max_episode_steps=10)

@@ -2,7 +2,7 @@
 """How the MT50 step time scales with the number of concurrent task groups (82 envs per task)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
 

@@ -2,7 +2,7 @@
 """Per-step kernel time over an episode (random actions): MT50 @4096 and the heaviest tasks alone @82."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
 

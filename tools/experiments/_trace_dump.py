@@ -3,7 +3,7 @@
 harness build of the same lane code (tools/_trace_dump.py <gpu|host> task steps out.npz)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from metaworld_amd import native
 from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
