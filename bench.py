@@ -53,8 +53,8 @@ def cpu_baseline(workload_task, seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000, help="timed steps (default covers two full 500-step episodes incl. the auto-reset waves)")
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--benchmark", default="auto")
     ap.add_argument("--precision", default="fp32")
