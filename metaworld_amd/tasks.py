@@ -105,16 +105,39 @@ def supported_tasks():
     return [t for t in ALL_V3 if t in TASK_DEFS]
 
 
+_goal_cache = {}
+
+
+def benchmark_task_names(benchmark: str, env_name=None):
+    """Task names of a reference benchmark split in construction order: MT1 / ML1-train / ML1-test (one task), MT10, MT25,
+    MT50, ML10-train, ML10-test, ML25-*, ML45-* (metaworld/env_dict.py; dumped to data/benchmarks.json)."""
+    if benchmark in ("MT1", "ML1-train", "ML1-test"):
+        assert env_name is not None
+        return [env_name]
+    with open(os.path.join(_HERE, "data", "benchmarks.json")) as f:
+        B = json.load(f)
+    if benchmark not in B:
+        raise ValueError(f"unsupported benchmark {benchmark}")
+    return list(B[benchmark])
+
+
 def goal_table(benchmark: str, task: str, seed: int = 42) -> np.ndarray:
-    """[50][6] rand_vecs the reference's `benchmark`(seed) assigns to `task`."""
-    path = os.path.join(_HERE, "data", f"goals_seed{seed}.npz")
-    if not os.path.exists(path):
-        raise FileNotFoundError(f"no goal table for seed {seed}; generate it with tools/gen_goal_tables.py {seed}")
-    z = np.load(path)
-    key = f"{benchmark}/{task}"
-    if key not in z.files:
-        raise KeyError(key)
-    return z[key]
+    """[50][6] rand_vecs the reference's `benchmark`(seed) assigns to `task`, for any seed: the physics-free restatement
+    of `_make_tasks` in metaworld_amd/goals.py (pinned against tables dumped from the reference itself,
+    metaworld_amd/data/goals_seed*.npz, by tests/test_goal_tables.py).  ML1's test split uses seed + 1, every other
+    split of every benchmark its own stream started at `seed` (metaworld/__init__.py:185-400)."""
+    from . import goals
+    single = benchmark in ("MT1", "ML1-train", "ML1-test")
+    s = seed + 1 if benchmark == "ML1-test" else seed
+    key = (benchmark, s, task) if single else (benchmark, s)
+    if key not in _goal_cache:
+        with open(os.path.join(_HERE, "data", "task_constants.json")) as f:
+            C = json.load(f)
+        _goal_cache[key] = goals.make_tables(benchmark_task_names(benchmark, task), s, C["tasks"])
+    tab = _goal_cache[key]
+    if task not in tab:
+        raise KeyError(f"{benchmark}/{task}")
+    return tab[task]
 
 
 _model_cache = {}

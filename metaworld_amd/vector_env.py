@@ -48,14 +48,9 @@ def _box(low, high, dtype):
 
 
 def benchmark_tasks(benchmark, env_name=None):
-    if benchmark == "MT1":
-        assert env_name is not None
-        return [env_name], f"MT1/{env_name}"
-    if benchmark == "MT10":
-        return list(T.MT10), "MT10"
-    if benchmark == "MT50":
-        return list(T.ALL_V3), "MT50"
-    raise ValueError(f"unsupported benchmark {benchmark}")
+    """(task names, goal-table key) of a benchmark split: MT1, MT10, MT25, MT50, ML1-train/-test, ML10-train/-test,
+    ML25-*, ML45-* (the reference's `metaworld.MT50(seed).train_tasks` etc.)."""
+    return T.benchmark_task_names(benchmark, env_name), benchmark
 
 
 class MetaWorldGpuVectorEnv:
@@ -63,7 +58,8 @@ class MetaWorldGpuVectorEnv:
 
     def __init__(self, benchmark="MT1", env_name=None, num_envs=None, seed=None, use_one_hot=False,
                  max_episode_steps=None, terminate_on_success=False, precision="fp32", device_id=0,
-                 rank=0, world_size=1, goal_seed=42, task_names=None, lib=None, maxcon=None, maxefc=None):
+                 rank=0, world_size=1, goal_seed=42, task_names=None, lib=None, maxcon=None, maxefc=None,
+                 partially_observable=None):
         names, goal_key = benchmark_tasks(benchmark, env_name)
         if task_names is not None:          # restrict a benchmark to the tasks that have device code (tests)
             names = [n for n in names if n in task_names]
@@ -77,6 +73,9 @@ class MetaWorldGpuVectorEnv:
             raise ValueError("num_envs must be >= number of tasks")
         self.rank, self.world_size = rank, world_size
         self.use_one_hot = bool(use_one_hot)
+        # ML benchmarks hide the goal (metaworld/__init__.py `_ML_OVERRIDE`), MT ones show it; the reference's own policy test
+        # makes it visible for ML too (tests/metaworld/test_evaluation.py:70-82) -> overridable
+        self.partially_observable = benchmark.startswith("ML") if partially_observable is None else bool(partially_observable)
         self.seed_value = seed
         self._lib = lib or native.load()
         self.ctx = native.Context(self._lib, precision=1 if precision in ("fp64", 1) else 0, device_id=device_id,
@@ -93,9 +92,10 @@ class MetaWorldGpuVectorEnv:
                                                   tolerance=None if precision in ("fp64", 1) else 1e-6)
                 model_index[mname] = self.ctx.add_model(pk)
                 roles_of[mname], reloc_of[mname] = roles, reloc
-            goals = T.goal_table(goal_key.split("/")[0] if benchmark != "MT1" else "MT1", name, goal_seed)
+            goals = T.goal_table(goal_key, name, goal_seed)
             self.goal_tables[name] = goals
-            ts = T.task_struct(name, model_index[mname], roles_of[mname], reloc_of[mname], onehot_id=oh)
+            ts = T.task_struct(name, model_index[mname], roles_of[mname], reloc_of[mname], onehot_id=oh,
+                               partially_observable=self.partially_observable)
             self._task_index[name] = self.ctx.add_task(ts, goals)
         # env -> task (task-major contiguous blocks, like the reference's enumerate order)
         per, rem = divmod(self.num_envs, ntask)
@@ -185,7 +185,7 @@ class MetaWorldGpuVectorEnv:
         if name == "terminate_on_success":
             return (self.terminate_on_success,) * self.num_envs
         if name == "_partially_observable":
-            return (False,) * self.num_envs
+            return (self.partially_observable,) * self.num_envs
         if name == "_last_rand_vec":
             return tuple(self.goal_tables[n][g] for n, g in zip(self.env_task_names, self._current_goals()))
         if name == "tasks":

@@ -99,3 +99,23 @@ def test_sub_lane_and_scratchpad_invariance(hostsim, task, monkeypatch):
     for k in (("4", "24"), ("8", "24")):
         assert (runs[k][1] == ref[1]).all()
         assert np.abs(runs[k][0] - ref[0]).max() < 1e-6     # resting multi-contact bodies amplify the summation-order noise
+
+
+def test_ml_benchmark_splits_hide_the_goal(hostsim):
+    """ML10 train / test splits (metaworld/__init__.py ML10, `_ML_OVERRIDE`): task lists, own goal tables, goal zeroed in
+    the observation unless made visible (as tests/metaworld/test_evaluation.py:70-82 does for the scripted policies)."""
+    from metaworld_amd import tasks as T
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    tr, te = T.benchmark_task_names("ML10-train"), T.benchmark_task_names("ML10-test")
+    assert len(tr) == 10 and len(te) == 5 and not set(tr) & set(te)
+    env = MetaWorldGpuVectorEnv("ML10-test", num_envs=10, seed=1, precision="fp64", lib=hostsim)
+    obs, _ = env.reset()
+    assert env.get_attr("_partially_observable") == (True,) * 10
+    assert np.abs(obs[:, 36:39]).max() == 0
+    obs, *_ = env.step(np.zeros((10, 4), dtype=np.float32))
+    assert np.abs(obs[:, 36:39]).max() == 0
+    env.close()
+    env = MetaWorldGpuVectorEnv("ML10-test", num_envs=5, seed=1, precision="fp64", lib=hostsim, partially_observable=False)
+    obs, _ = env.reset()
+    assert (np.abs(obs[:, 36:39]).max(1) > 0).all()
+    env.close()

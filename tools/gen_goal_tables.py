@@ -4,7 +4,7 @@
 (hand_init_pos, mocap box, goal_space, ...) by running the reference's own code on the oracle engine.
 
 Outputs (committed, generated data):
-  metaworld_amd/data/goals_seed<seed>.npz   MT1/<task>, MT10, MT50 tables: [ntask][50][6]
+  metaworld_amd/data/goals_seed<seed>.npz   MT1/<task>, MT10, MT25, MT50, ML10/ML45 train+test, ML1 (pick-place) tables: [50][6] per task
   metaworld_amd/data/task_constants.json     per task: model, hand_init_pos, hand_low/high, goal_low/high, ...
 """
 import json
@@ -60,10 +60,25 @@ def main():
             class_constants={k: float(getattr(env, k)) for k in ("TARGET_RADIUS", "OBJ_RADIUS", "liftThresh", "max_dist", "PAD_SUCCESS_MARGIN", "LIFT_THRESH", "LEVER_RADIUS")
                              if isinstance(getattr(env, k, None), (int, float))})
         print(name, "ok", flush=True)
-    for bname, cls in (() if consts_only else (("MT10", metaworld.MT10), ("MT50", metaworld.MT50))):
+    for bname, cls in (() if consts_only else (("MT10", metaworld.MT10), ("MT25", metaworld.MT25), ("MT50", metaworld.MT50))):
         tb = table(cls(seed=seed))
         for k, v in tb.items():
             data[f"{bname}/{k}"] = v
+        print(bname, "ok", flush=True)
+
+    def table_of(tasks):
+        out = {}
+        for t in tasks:
+            d = pickle.loads(t.data)
+            rv = np.asarray(d["rand_vec"], dtype=np.float64)
+            out.setdefault(t.env_name, []).append(np.concatenate([rv, np.zeros(3)]) if rv.size == 3 else rv)
+        return {k: np.array(v) for k, v in out.items()}
+    for bname, mk in (() if consts_only else (("ML10", lambda: metaworld.ML10(seed=seed)), ("ML45", lambda: metaworld.ML45(seed=seed)),
+                                              ("ML1", lambda: metaworld.ML1("pick-place-v3", seed=seed)))):
+        b = mk()
+        for split, tasks in (("train", b.train_tasks), ("test", b.test_tasks)):
+            for k, v in table_of(tasks).items():
+                data[f"{bname}-{split}/{k}"] = v
         print(bname, "ok", flush=True)
     os.makedirs(os.path.join(ROOT, "metaworld_amd", "data"), exist_ok=True)
     if not consts_only:
