@@ -123,6 +123,15 @@ def test_gpu_lanes_per_block_invariance(gpulib, task, monkeypatch):
         assert np.abs(runs[lpb][0] - runs["64"][0]).max() < 1e-2
 
 
+@pytest.mark.parametrize("task", T.ALL_V3)
+def test_gpu_policy_episode_follows_oracle(gpulib, task):
+    """Whole scripted-policy episodes (grasp / lift / insert regimes) replayed open loop on the GPU: fp64 follows the
+    oracle trajectory with identical success flags, fp32 reaches success at the same step."""
+    from tests.test_policy_traces import check_fp32, check_fp64
+    check_fp64(gpulib, task)
+    check_fp32(gpulib, task)
+
+
 def test_gpu_mt50_smoke(gpulib):
     """MT50 x 200 envs in fp32: finite outputs, one-hot ids cover all 50 tasks, truncation + auto-reset fire together."""
     from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
