@@ -1,11 +1,13 @@
 // mw_common.hpp -- shared definitions for the MI355X batched Meta-World runtime.
 //
-// Execution model: ONE ENVIRONMENT PER LANE.  All per-environment data (persistent
-// state and scratch) lives in a struct-of-arrays "column store": element `i` of
-// environment `e` of a group is at  col[i * stride + e]  so that the 64 lanes of a
-// wavefront touch 64 consecutive words (fully coalesced 256 B / 512 B requests).
-// Every wavefront is model-uniform (groups are per compiled model), so the
-// model tables below are read at wave-uniform addresses (scalar/broadcast loads).
+// Execution model: ONE ENVIRONMENT PER LANE, PLUS SUB-LANES.  A workgroup is one 64-thread wave carrying `lpb`
+// environments; thread t works for environment t % lpb as its sub-lane t / lpb (lpb = 64: no sub-lanes).  All
+// per-environment data (persistent state and scratch) lives in a struct-of-arrays "column store" chunked per workgroup:
+// element `i` of the environment in lane `l` of chunk `c` is at  col[(c * nreal + i) * lpb + l]  (Env::R), so a wave's
+// access to one element is one contiguous request and consecutive elements are adjacent.  Every wavefront is
+// model-uniform (groups are per compiled model), so the model tables are read at wave-uniform addresses (scalar loads).
+// The solver's per-row scalars live in an LDS scratchpad, its dense algebra in registers (mw_phys.hpp); the row /
+// pair / dof sweeps of one environment are split over its sub-lanes (MW_SUBS below).
 //
 // The same headers compile for the device (hipcc, gfx950) and -- for tests only --
 // for the host (g++), where a plain loop over lanes replaces the wavefront.  The

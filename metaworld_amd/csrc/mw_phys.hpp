@@ -8,7 +8,8 @@
 // contacts) -> RNE bias / passive / position actuators -> Newton solver with
 // exact line search -> semi-implicit Euler with implicit joint damping.
 //
-// All arrays are addressed through Env<T>::R(i) (column store, one lane = one env).
+// All arrays are addressed through Env<T>::R(i) (column store, one lane = one env); the sweeps over constraint rows,
+// dofs and bodies' independent components are split over the environment's sub-lanes (mw_common.hpp, MW_SUBS).
 #pragma once
 #include "mw_common.hpp"
 
@@ -145,38 +146,11 @@ MW_HD void inertia_mul(T* f, const T* I, const T* s) {
     f[3] = p.x; f[4] = p.y; f[5] = p.z;
 }
 
-// in-place Cholesky of the lower triangle of the n x n matrix at offset A (row-major, stride n)
-template <typename T>
-MW_HD void chol_factor(const Env<T> e, int A, int n) {
-    for (int i = 0; i < n; i++) {
-        for (int j = 0; j <= i; j++) {
-            T s = e.R(A + i * n + j);
-            for (int k = 0; k < j; k++) s -= e.R(A + i * n + k) * e.R(A + j * n + k);
-            if (i == j) e.R(A + i * n + i) = mw_sqrt(s < T(1e-15) ? T(1e-15) : s);
-            else e.R(A + i * n + j) = s / e.R(A + j * n + j);
-        }
-    }
-}
-template <typename T>
-MW_HD void chol_solve(const Env<T> e, int A, int x, int n) {
-    for (int i = 0; i < n; i++) {
-        T s = e.R(x + i);
-        for (int k = 0; k < i; k++) s -= e.R(A + i * n + k) * e.R(x + k);
-        e.R(x + i) = s / e.R(A + i * n + i);
-    }
-    for (int i = n - 1; i >= 0; i--) {
-        T s = e.R(x + i);
-        for (int k = i + 1; k < n; k++) s -= e.R(A + k * n + i) * e.R(x + k);
-        e.R(x + i) = s / e.R(A + i * n + i);
-    }
-}
-
 // ---- register-resident dense helpers -------------------------------------------------------------------------
 // On the GPU a read-modify-write loop over a lane's global column serialises on memory latency (every iteration is
 // a dependent round trip).  The solver's dense pieces (H assembly, Cholesky, triangular solves, J'f, M x) therefore
-// run on compile-time-sized register arrays: NV is an upper bound on nv (instantiated for 11 and 17), every loop
-// is fully unrolled, rows/columns >= nv are identity/zero padding, and the arithmetic order matches the in-memory
-// routines above so the results are bit-identical.
+// run on compile-time-sized register arrays with every loop fully unrolled; the routines are instantiated for the
+// exact nv of the scenes (MW_NV_DISPATCH; a size bound NV > nv also works: rows/columns >= nv are identity/zero padding).
 constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
 template <typename T, int NV>
@@ -438,11 +412,6 @@ MW_HD void jrow_load(const Env<T> e, int row, int nv, T* j) {
 #pragma unroll
     for (int k = 0; k < NV; k++) j[k] = EJ(e, row, k < nv ? k : 0);
 }
-// true for the first row of a contact's cone block (rows are visited with a wave-uniform counter; the other rows
-// of a block are skipped instead of advancing the counter by a per-lane amount)
-template <typename T>
-MW_HD bool cone_leader(const Env<T> e, int row, int c) { return ICON(e, c, 3) == row; }
-
 template <typename T, typename P>
 MW_HD T impedance(P solimp, T x) {
     T d0 = mw_clamp(solimp[0], T(0.0001), T(0.9999)), dw = mw_clamp(solimp[1], T(0.0001), T(0.9999));
