@@ -1,8 +1,9 @@
 // mwgpu.hip -- libmwgpu.so: HIP (gfx950) backend of the batched Meta-World runtime + its C ABI (include/mwgpu.h).
 //
-// Kernel shape: one wavefront (64 lanes = 64 environments) per workgroup, grid = sum over model groups of
-// ceil(n_env / 64); every wavefront is model-uniform.  All per-env data is in the column store described in
-// mw_common.hpp, so each per-env load/store of a wave is one coalesced request.
+// Kernel shape: one wavefront (64 threads) per workgroup carrying lpb <= 64 environments of one model group (the other
+// threads are sub-lanes of those environments, mw_common.hpp), grid = sum over groups of ceil(n_env / lpb); dynamic LDS =
+// the lanes' scratchpad (solver row scalars).  All per-env data is in the chunked column store described in
+// mw_common.hpp, so each per-env load/store of a wave is one contiguous request.
 #include <hip/hip_runtime.h>
 
 #include <stdlib.h>
