@@ -152,7 +152,7 @@ def main():
             out["parity_mode"] = {"dtype": "f64", "value": N * args.steps / w64, "unit": "env-steps/s", "ms_per_step": w64 / args.steps * 1e3,
                                   "kernel_ms_per_launch": k64 / args.steps}
             env64.close()
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl_task)
         print(json.dumps(out))
     env.close()
