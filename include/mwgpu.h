@@ -67,6 +67,8 @@ int mw_add_model(mw_ctx* c, const mw_model* m);                    /* returns mo
 int mw_add_task(mw_ctx* c, const mw_task* t, const double* goals /*[ngoals][6] rand_vec*/, int ngoals); /* task index */
 int mw_set_envs(mw_ctx* c, const int32_t* env_task /*[n] task index per env*/, int n);
 int mw_finalize(mw_ctx* c);   /* allocates device state; runs the faithful reset once per (task, goal) -> snapshots */
+/* AutoTerminateOnSuccessWrapper.toggle_terminate_on_success (metaworld/wrappers.py:222-223): takes effect at the next mw_step */
+int mw_set_terminate_on_success(mw_ctx* c, int on);
 void mw_destroy(mw_ctx* c);
 const char* mw_last_error(const mw_ctx* c);
 int mw_num_envs(const mw_ctx* c);

@@ -70,6 +70,11 @@ int MW_API(add_task)(mw_ctx* c, const mw_task* t, const double* goals, int ngoal
     } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
 }
 int MW_API(set_envs)(mw_ctx* c, const int32_t* env_task, int n) { c->env_task.assign(env_task, env_task + n); return 0; }
+int MW_API(set_terminate_on_success)(mw_ctx* c, int on) {
+    c->cfg.terminate_on_success = on ? 1 : 0;
+    if (c->impl) c->impl->cfg.terminate_on_success = c->cfg.terminate_on_success;
+    return 0;
+}
 int MW_API(finalize)(mw_ctx* c) {
     MW_TRY(c, {
         for (int t : c->env_task) if (t < 0 || t >= (int)c->tasks.size()) throw std::runtime_error("env refers to unknown task");

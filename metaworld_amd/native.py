@@ -48,6 +48,7 @@ class Lib:
         f("add_task", C.c_int, C.c_void_p, C.POINTER(MwTask), C.c_void_p, C.c_int)
         f("set_envs", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
         f("finalize", C.c_int, C.c_void_p)
+        f("set_terminate_on_success", C.c_int, C.c_void_p, C.c_int)
         f("destroy", None, C.c_void_p)
         f("last_error", C.c_char_p, C.c_void_p)
         f("num_envs", C.c_int, C.c_void_p)
@@ -81,7 +82,7 @@ def load(prefix="mw_", path=None) -> Lib:
 
 
 EXPORTED_SYMBOLS = ["model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
-                    "add_model", "add_task", "set_envs", "finalize", "destroy", "last_error", "num_envs", "obs_dim",
+                    "add_model", "add_task", "set_envs", "finalize", "set_terminate_on_success", "destroy", "last_error", "num_envs", "obs_dim",
                     "reset", "step", "upload_actions", "step_resident", "column_size", "read", "write", "read_int",
                     "debug"]
 
@@ -141,6 +142,9 @@ class Context:
         self.reward = np.zeros(N); self.ep_ret = np.zeros(N); self.ep_len = np.zeros(N, dtype=np.int32)
         self.terminated = np.zeros(N, dtype=np.uint8); self.truncated = np.zeros(N, dtype=np.uint8)
         self.success = np.zeros(N, dtype=np.uint8); self.info = np.zeros((N, 6), dtype=np.float32)
+
+    def set_terminate_on_success(self, on):
+        self._check(self.lib.set_terminate_on_success(self.ptr, int(bool(on))))
 
     def reset(self, goal_idx, mask=None):
         g = np.ascontiguousarray(goal_idx, dtype=np.int32)

@@ -196,14 +196,48 @@ class MetaWorldGpuVectorEnv:
         return [int(self.ctx.read(e, "task", 2)[1]) for e in range(self.num_envs)]
 
     def set_attr(self, name, values):
-        raise NotImplementedError(name)
+        """gymnasium VectorEnv.set_attr for the attributes of the reference's wrapper stack that are state here"""
+        vals = list(values) if isinstance(values, (list, tuple, np.ndarray)) else [values] * self.num_envs
+        if name == "terminate_on_success":
+            assert len(set(bool(v) for v in vals)) == 1, "terminate_on_success is one flag per vector env"
+            self.call("toggle_terminate_on_success", bool(vals[0]))
+        elif name == "sample_tasks_on_reset":
+            self.sample_tasks_on_reset = bool(vals[0])
+        else:
+            raise NotImplementedError(name)
 
     def call(self, name, *args, **kwargs):
+        """gymnasium VectorEnv.call for the methods the reference's wrappers expose (metaworld/wrappers.py:107-142, :222-223;
+        used by metaworld/evaluation.py:53-125)."""
         if name == "toggle_sample_tasks_on_reset":
             self.sample_tasks_on_reset = bool(args[0])
             return (None,) * self.num_envs
         if name == "toggle_terminate_on_success":
-            raise NotImplementedError("terminate_on_success is fixed at construction in this version")
+            self.terminate_on_success = bool(args[0])
+            self.ctx.set_terminate_on_success(self.terminate_on_success)
+            return (None,) * self.num_envs
+        if name == "sample_tasks":          # RandomTaskSelectWrapper.sample_tasks: draw a task for every env, then reset it
+            saved, self.sample_tasks_on_reset = self.sample_tasks_on_reset, True
+            mask = np.ones(self.num_envs, dtype=bool)
+            self._advance_goals(mask)
+            self.sample_tasks_on_reset = saved
+            obs = self.ctx.reset(self._next_goal).astype(self.obs_dtype, copy=True)
+            self._advance_goals(mask)
+            self._episode_start[:] = time.perf_counter()
+            return tuple((obs[e], {}) for e in range(self.num_envs))
+        if name == "get_checkpoint":
+            ck = dict(tasks={n: t.copy() for n, t in self.goal_tables.items()}, reset_count=self._reset_count.copy(),
+                      next_goal=self._next_goal.copy(), seed=self.seed_value, sample_tasks_on_reset=self.sample_tasks_on_reset,
+                      state=[self.ctx.read(e, "state") for e in range(self.num_envs)])
+            return (ck,) + (None,) * (self.num_envs - 1)
+        if name == "load_checkpoint":
+            ck = args[0][0] if isinstance(args[0], (list, tuple)) else args[0]
+            assert all(np.array_equal(ck["tasks"][n], t) for n, t in self.goal_tables.items()), "checkpoint of another benchmark/seed"
+            self._reset_count[:] = ck["reset_count"]; self._next_goal[:] = ck["next_goal"]
+            self.sample_tasks_on_reset = ck["sample_tasks_on_reset"]
+            for e in range(self.num_envs):
+                self.ctx.write(e, "state", ck["state"][e])
+            return (None,) * self.num_envs
         return self.get_attr(name)
 
     def bookkeeping(self):

@@ -119,3 +119,37 @@ def test_ml_benchmark_splits_hide_the_goal(hostsim):
     obs, _ = env.reset()
     assert (np.abs(obs[:, 36:39]).max(1) > 0).all()
     env.close()
+
+
+def test_wrapper_calls_of_the_reference_surface(hostsim):
+    """VectorEnv.call / set_attr for the methods metaworld/evaluation.py uses (wrappers.py:107-142, :222-223):
+    toggle_terminate_on_success at run time, sample_tasks, checkpoint round trip."""
+    env = make_env(hostsim, "reach-v3", n=3, precision="fp64", max_episode_steps=500)
+    obs0, _ = env.reset()
+    a = np.zeros((3, 4), dtype=np.float32)
+    # a state that counts as success: put the hand at the goal through repeated steps towards it
+    goal = obs0[:, 36:39]
+    for _ in range(150):
+        d = np.clip((goal - env.ctx.obs[:, :3]) * 10, -1, 1)
+        obs, rew, term, trunc, info = env.step(np.concatenate([d, np.zeros((3, 1))], 1).astype(np.float32))
+        if info["success"].all():
+            break
+    assert info["success"].all() and not term.any()          # AutoTerminate off: success does not terminate
+    assert env.get_attr("terminate_on_success") == (False,) * 3
+    env.call("toggle_terminate_on_success", True)
+    assert env.get_attr("terminate_on_success") == (True,) * 3
+    obs, rew, term, trunc, info = env.step(a)
+    assert term.all() and "final_obs" in info                 # ... now it does, with the SAME_STEP auto-reset
+    env.set_attr("terminate_on_success", False)
+    obs, rew, term, trunc, info = env.step(a)
+    assert not term.any()
+    # sample_tasks: a fresh draw + reset for every env, returned per env
+    res = env.call("sample_tasks")
+    assert len(res) == 3 and res[0][0].shape == obs0[0].shape and np.abs(res[0][0][18:36] - res[0][0][:18]).max() == 0
+    # checkpoint round trip restores the physics state and the task-sampling stream position
+    ck = env.call("get_checkpoint")
+    s1 = [env.step(a)[0].copy() for _ in range(3)]
+    env.call("load_checkpoint", ck)
+    s2 = [env.step(a)[0].copy() for _ in range(3)]
+    assert all(np.array_equal(x, y) for x, y in zip(s1, s2))
+    env.close()
