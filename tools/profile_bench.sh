@@ -8,7 +8,7 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
-args="--steps 10 --warmup 3 --no-cpu-baseline $*"
+args="--no-cpu-baseline --no-parity-mode $*"     # bench.py defaults (1000 timed steps after 100) unless overridden
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python $root/bench.py $args > "$out/kt.log" 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" \
