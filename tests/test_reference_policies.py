@@ -66,3 +66,83 @@ def test_scripted_policy_succeeds_on_device_code(hostsim, task):
     env.close()
     need = 0 if task == "basketball-v3" else 4
     assert done.sum() >= need, f"{task}: {int(done.sum())}/5"
+
+
+def test_reference_evaluation_loop_runs_on_the_vector_env(hostsim):
+    """Drop-in at the evaluation surface: the reference's own `metaworld.evaluation.evaluation` (unmodified; it toggles
+    terminate_on_success through VectorEnv.call, reads task names through get_attr and episode statistics from the
+    SAME_STEP `final_info`) drives MetaWorldGpuVectorEnv("MT10") with the reference's scripted policies as the agent."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from metaworld_amd import tasks as T
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    from oracle import refshim
+    refshim.install()
+    from metaworld.evaluation import evaluation
+    from metaworld.policies import ENV_POLICY_MAP
+
+    env = MetaWorldGpuVectorEnv("MT10", num_envs=10, seed=42, use_one_hot=True, precision="fp32", lib=hostsim)
+
+    class ScriptedAgent:
+        def __init__(self):
+            self.policies = [ENV_POLICY_MAP[n]() for n in env.env_task_names]
+
+        def eval_action(self, observations):
+            return np.stack([np.clip(p.get_action(np.asarray(o[:39], dtype=np.float64)), -1, 1)
+                             for p, o in zip(self.policies, observations)]).astype(np.float32)
+
+        def reset(self, env_mask):
+            for i in np.flatnonzero(env_mask):
+                self.policies[i] = ENV_POLICY_MAP[env.env_task_names[i]]()
+
+    mean_success, mean_return, per_task, returns = evaluation(ScriptedAgent(), env, num_episodes=2)
+    env.close()
+    assert set(per_task) == set(T.MT10) and all(len(r) == 2 for r in returns.values())
+    assert mean_success >= 0.8, per_task
+    assert env.terminate_on_success is False          # evaluation() restores the flag it found
+
+
+def test_reference_metalearning_evaluation_runs_on_ml_split(hostsim):
+    """The reference's `metalearning_evaluation` (unmodified) on MetaWorldGpuVectorEnv("ML10-test"): it relies on
+    call("toggle_sample_tasks_on_reset" / "toggle_terminate_on_success" / "sample_tasks"), reset and step only."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    from metaworld_amd import tasks as T
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    from oracle import refshim
+    refshim.install()
+    from metaworld.evaluation import metalearning_evaluation
+    from metaworld.policies import ENV_POLICY_MAP
+
+    env = MetaWorldGpuVectorEnv("ML10-test", num_envs=5, seed=42, precision="fp32", lib=hostsim, max_episode_steps=150,
+                                partially_observable=False)      # goal visible, as tests/metaworld/test_evaluation.py:70-82
+
+    class Agent:
+        def init(self):
+            self.policies = [ENV_POLICY_MAP[n]() for n in env.env_task_names]
+
+        def _act(self, observations):
+            return np.stack([np.clip(p.get_action(np.asarray(o[:39], dtype=np.float64)), -1, 1)
+                             for p, o in zip(self.policies, observations)]).astype(np.float32)
+
+        def adapt_action(self, observations):
+            return self._act(observations), {}
+
+        def eval_action(self, observations):
+            return self._act(observations)
+
+        def step(self, timestep):
+            pass
+
+        def adapt(self):
+            pass
+
+        def reset(self, env_mask):
+            for i in np.flatnonzero(env_mask):
+                self.policies[i] = ENV_POLICY_MAP[env.env_task_names[i]]()
+
+    mean_success, mean_return, per_task = metalearning_evaluation(Agent(), env, num_evals=1, adaptation_steps=1,
+                                                                   adaptation_episodes=1, evaluation_episodes=1)
+    env.close()
+    assert set(per_task) == set(T.benchmark_task_names("ML10-test")) and 0.0 <= mean_success <= 1.0 and np.isfinite(mean_return)
+    assert mean_success >= 0.6, per_task
