@@ -153,3 +153,30 @@ def test_wrapper_calls_of_the_reference_surface(hostsim):
     s2 = [env.step(a)[0].copy() for _ in range(3)]
     assert all(np.array_equal(x, y) for x, y in zip(s1, s2))
     env.close()
+
+
+@pytest.mark.parametrize("benchmark,ntask", [("MT10", 10), ("MT50", 50)])
+def test_mt_benchmark_surface_like_the_reference_test(hostsim, benchmark, ntask):
+    """Mirror of the reference's own tests/metaworld/test_gym_make.py:37-93 (`test_mt_benchmarks`) on MetaWorldGpuVectorEnv:
+    one env per task, 50 goals each, one-hot ids in the observation, truncation at max_episode_steps, a new task
+    (rand_vec) sampled by the auto-reset, goal observable."""
+    from metaworld_amd import tasks as T
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    max_episode_steps = 10
+    envs = MetaWorldGpuVectorEnv(benchmark, seed=42, use_one_hot=True, max_episode_steps=max_episode_steps, precision="fp32", lib=hostsim)
+    cls_to_name = {T.TASK_CONST[n]["cls"]: n for n in T.ALL_V3}
+    task_names = [cls_to_name[c] for c in envs.get_attr("task_name")]
+    assert envs.num_envs == ntask and set(task_names) == set(T.benchmark_task_names(benchmark))
+    assert all(len(t) == 50 for t in envs.get_attr("tasks"))
+    obs, _ = envs.reset()
+    original_vecs = envs.get_attr("_last_rand_vec")
+    has_truncated = False
+    for _ in range(max_episode_steps + 1):
+        obs, _, _, truncated, _ = envs.step(envs.action_space.sample())
+        assert set(np.argmax(obs[:, -envs.num_envs:], axis=1)) == set(range(envs.num_envs))
+        has_truncated |= bool(truncated.any())
+    assert has_truncated
+    new_vecs = envs.get_attr("_last_rand_vec")
+    assert any(np.any(a != b) for a, b in zip(original_vecs, new_vecs))
+    assert not all(envs.get_attr("_partially_observable"))
+    envs.close()
