@@ -1,0 +1,88 @@
+"""The reference's construction surface for the hot path, returning the GPU VectorEnv.
+
+`make_mt_envs` / `make_ml_envs` / `make_ml_envs_train` / `make_ml_envs_test` mirror metaworld/__init__.py:460-618 (same names,
+argument meaning and errors); `register_mw_envs` registers the same "Meta-World/..." vector ids (`:621-823`) under the
+namespace "Meta-World-GPU/" when gymnasium is importable, so `gym.make_vec("Meta-World-GPU/MT50", num_envs=4096, seed=42)` is
+the one-line switch.  As in the reference one `seed` feeds both the benchmark's goal tables and every sub-env's task-selection
+stream.  `vector_strategy` is accepted and ignored (there is one kernel launch per step, not a worker pool); only
+SAME_STEP auto-reset exists, the mode the reference's entry points use.
+"""
+from __future__ import annotations
+
+from functools import partial
+
+from . import tasks as T
+from .vector_env import MetaWorldGpuVectorEnv
+
+_MT = ("MT10", "MT25", "MT50")
+_ML = ("ML10", "ML25", "ML45")
+
+
+def _check_autoreset(mode):
+    name = getattr(mode, "value", mode)
+    if str(name).replace("_", "").lower() not in ("samestep",):
+        raise NotImplementedError(f"autoreset_mode {mode!r}: the step kernel fuses the SAME_STEP auto-reset")
+
+
+def make_mt_envs(name, seed=None, num_tasks=None, vector_strategy="sync", autoreset_mode="SameStep", num_envs=None, **kwargs):
+    """metaworld/__init__.py:460-513.  `name` is a task name (the MT1 case; the reference returns one wrapped env, here a
+    VectorEnv of `num_envs` copies) or "MT10" / "MT25" / "MT50"."""
+    _check_autoreset(autoreset_mode)
+    gs = 42 if seed is None else seed          # the reference draws unseeded goals for seed=None; a fixed table is reproducible
+    if name in T.ALL_V3:
+        return MetaWorldGpuVectorEnv("MT1", name, num_envs=num_envs or 1, seed=seed, goal_seed=gs, **kwargs)
+    if name in _MT:
+        if num_tasks is not None and num_tasks != len(T.benchmark_task_names(name)):
+            raise NotImplementedError("num_tasks other than the benchmark's own size (a wider one-hot) is not supported")
+        return MetaWorldGpuVectorEnv(name, num_envs=num_envs, seed=seed, goal_seed=gs, **kwargs)
+    raise ValueError("Invalid MT env name. Must either be a valid Metaworld task name (e.g. 'reach-v3'), 'MT10' or 'MT50'.")
+
+
+def make_ml_envs(name, seed=None, meta_batch_size=20, total_tasks_per_cls=None, split="train", vector_strategy="sync",
+                 autoreset_mode="SameStep", num_envs=None, **kwargs):
+    """metaworld/__init__.py:565-593 (+ `_make_ml_envs_inner` :516-562): `meta_batch_size` sub-envs, each class's goals dealt
+    round-robin over its sub-envs."""
+    _check_autoreset(autoreset_mode)
+    if split not in ("train", "test"):
+        raise ValueError(split)
+    gs = 42 if seed is None else seed
+    if name in T.ALL_V3:
+        return MetaWorldGpuVectorEnv(f"ML1-{split}", name, seed=seed, goal_seed=gs, meta_batch_size=meta_batch_size,
+                                     total_tasks_per_cls=total_tasks_per_cls, **kwargs)
+    if name in _ML:
+        return MetaWorldGpuVectorEnv(f"{name}-{split}", seed=seed, goal_seed=gs, meta_batch_size=meta_batch_size,
+                                     total_tasks_per_cls=total_tasks_per_cls, **kwargs)
+    raise ValueError("Invalid ML env name. Must either be a valid Metaworld task name (e.g. 'reach-v3'), 'ML10', 'ML25', or 'ML45'.")
+
+
+# metaworld/__init__.py:596-604
+make_ml_envs_train = partial(make_ml_envs, terminate_on_success=False, task_select="pseudorandom", split="train")
+make_ml_envs_test = partial(make_ml_envs, terminate_on_success=True, task_select="pseudorandom", split="test")
+
+
+def register_mw_envs(namespace="Meta-World-GPU"):
+    """Register the vector ids of metaworld/__init__.py:655-823 that sit on the hot path.  No-op (returns False) when
+    gymnasium is not installed.  Unlike the reference's lambdas (`:711-718`), `num_envs` is honoured."""
+    try:
+        from gymnasium.envs.registration import register
+    except Exception:
+        return False
+
+    def mt(bench, env_name=None, vector_strategy="sync", autoreset_mode="SameStep", seed=None, use_one_hot=False, num_envs=None, **kw):
+        return make_mt_envs(env_name or bench, seed=seed, use_one_hot=use_one_hot, vector_strategy=vector_strategy,
+                            autoreset_mode=autoreset_mode, num_envs=num_envs, **kw)
+
+    def ml(bench, split, env_name=None, vector_strategy="sync", autoreset_mode="SameStep", total_tasks_per_cls=None, seed=None,
+           meta_batch_size=20, num_envs=None, **kw):
+        gen = make_ml_envs_train if split == "train" else make_ml_envs_test
+        return gen(env_name or bench, seed=seed, meta_batch_size=meta_batch_size, total_tasks_per_cls=total_tasks_per_cls,
+                   vector_strategy=vector_strategy, autoreset_mode=autoreset_mode, **kw)
+
+    register(id=f"{namespace}/MT1", vector_entry_point=partial(mt, "MT1"), kwargs={})
+    for b in _MT:
+        register(id=f"{namespace}/{b}", vector_entry_point=partial(mt, b), kwargs={})
+    for split in ("train", "test"):
+        register(id=f"{namespace}/ML1-{split}", vector_entry_point=partial(ml, "ML1", split), kwargs={})
+        for b in _ML:
+            register(id=f"{namespace}/{b}-{split}", vector_entry_point=partial(ml, b, split), kwargs={})
+    return True

@@ -53,13 +53,45 @@ def benchmark_tasks(benchmark, env_name=None):
     return T.benchmark_task_names(benchmark, env_name), benchmark
 
 
+class _RunningMeanStd:
+    """gymnasium.wrappers.utils.RunningMeanStd (epsilon 1e-4; Chan's parallel update), one independent instance per sub-env
+    held as arrays, each update feeding one sample per selected env (batch_count 1, batch_var 0).  gymnasium is an
+    external dependency of the reference that cannot be installed here, so this restatement is unpinned."""
+
+    def __init__(self, n, shape, dtype):
+        self.mean, self.var, self.count = np.zeros((n,) + shape, dtype=dtype), np.ones((n,) + shape, dtype=dtype), np.full(n, 1e-4)
+
+    def update(self, x, mask):
+        i = np.flatnonzero(mask)
+        cnt = self.count[i].reshape((-1,) + (1,) * (self.mean.ndim - 1))
+        delta = x[i] - self.mean[i]
+        tot = cnt + 1
+        m2 = self.var[i] * cnt + np.square(delta) * cnt * 1 / tot
+        self.mean[i] = self.mean[i] + delta * 1 / tot
+        self.var[i] = m2 / tot
+        self.count[i] += 1
+
+
 class MetaWorldGpuVectorEnv:
     metadata = {"autoreset_mode": "SameStep", "render_modes": []}
 
     def __init__(self, benchmark="MT1", env_name=None, num_envs=None, seed=None, use_one_hot=False,
                  max_episode_steps=None, terminate_on_success=False, precision="fp32", device_id=0,
                  rank=0, world_size=1, goal_seed=42, task_names=None, lib=None, maxcon=None, maxefc=None,
-                 partially_observable=None):
+                 partially_observable=None, task_select="random", meta_batch_size=None, total_tasks_per_cls=None,
+                 recurrent_info_in_obs=False, normalize_reward_in_recurrent_info=True, reward_function_version="v2",
+                 reward_normalization_method=None, reward_alpha=0.001, normalize_observations=False):
+        """The keyword set of the reference's `_init_each_env` / `make_ml_envs` (metaworld/__init__.py:398-460, :516-618):
+        `task_select` "random" = RandomTaskSelectWrapper, "pseudorandom" = PseudoRandomTaskSelectWrapper;
+        `meta_batch_size` / `total_tasks_per_cls` = the ML split of each class's goals over sub-envs (`tasks[i::k]`);
+        `recurrent_info_in_obs` = RNNBasedMetaRLWrapper; `reward_normalization_method` / `normalize_observations` = the
+        normalisation wrappers.  Only the v2 reward functions have device code."""
+        if reward_function_version != "v2":
+            raise NotImplementedError("only reward_function_version='v2' has device code (SURVEY.md 8f item 4)")
+        if task_select not in ("random", "pseudorandom"):
+            raise ValueError(f"task_select must be 'random' or 'pseudorandom', got {task_select!r}")
+        if reward_normalization_method not in (None, "gymnasium", "exponential"):
+            raise ValueError(f"unknown reward_normalization_method {reward_normalization_method!r}")
         names, goal_key = benchmark_tasks(benchmark, env_name)
         if task_names is not None:          # restrict a benchmark to the tasks that have device code (tests)
             names = [n for n in names if n in task_names]
@@ -68,6 +100,12 @@ class MetaWorldGpuVectorEnv:
             raise NotImplementedError(f"no device-side task code yet for: {missing}")
         self.task_list = names
         ntask = len(names)
+        if meta_batch_size is not None:
+            # _make_ml_envs_inner (metaworld/__init__.py:527-531): meta_batch_size sub-envs, meta_batch_size/ntask per class
+            assert meta_batch_size % ntask == 0, "meta_batch_size must be divisible by envs_per_task"
+            if num_envs not in (None, meta_batch_size):
+                raise ValueError("num_envs and meta_batch_size disagree")
+            num_envs = meta_batch_size
         self.num_envs = int(num_envs) if num_envs else ntask
         if self.num_envs < ntask:
             raise ValueError("num_envs must be >= number of tasks")
@@ -105,13 +143,28 @@ class MetaWorldGpuVectorEnv:
         self.env_task_names = env_task_names
         self.ctx.set_envs([self._task_index[n] for n in env_task_names])
         self.ctx.finalize()
-        self._ngoals = np.array([len(self.goal_tables[n]) for n in env_task_names])
-        # RandomTaskSelectWrapper: every sub-env is seeded with the SAME seed (metaworld/__init__.py:499),
-        # so the n-th reset of any env draws the n-th value of one PCG64 stream.
-        self._stream = {}
-        self._reset_count = np.zeros(self.num_envs, dtype=np.int64)
-        self._next_goal = np.zeros(self.num_envs, dtype=np.int32)
-        self.sample_tasks_on_reset = True
+        # the goals each sub-env may be set to (indices into its task's table).  ML: the sub-envs of one class share its goals
+        # as `tasks[i::k]` (metaworld/__init__.py:533-543); otherwise every env sees the whole table.
+        self._goal_lists = []
+        for i, name in enumerate(names):
+            k = per + (1 if i < rem else 0)
+            ng = len(self.goal_tables[name]) if total_tasks_per_cls is None else min(total_tasks_per_cls, len(self.goal_tables[name]))
+            for j in range(k):
+                if meta_batch_size is None:
+                    self._goal_lists.append(np.arange(ng))
+                else:
+                    sub = np.arange(ng)[j::k]
+                    assert len(sub) == ng // k, f"Invalid division of subtasks, expected {ng // k} got {len(sub)}"
+                    self._goal_lists.append(sub)
+        # RandomTaskSelectWrapper / PseudoRandomTaskSelectWrapper: every sub-env is seeded with the SAME seed
+        # (metaworld/__init__.py:430-431), so the n-th draw of any env is the n-th value of one PCG64 stream.
+        self.task_select = task_select
+        self._stream, self._shuffles = {}, {}
+        self._reset_count = np.zeros(self.num_envs, dtype=np.int64)    # random: draws made; pseudorandom: shuffles made
+        self._task_idx = np.full(self.num_envs, -1, dtype=np.int64)     # pseudorandom: current_task_idx (wrappers.py:180)
+        self._cur_goal = np.full(self.num_envs, -1, dtype=np.int32)     # goal of the running episode (-1 = no task set yet)
+        self._next_goal = np.zeros(self.num_envs, dtype=np.int32)       # goal the next (auto-)reset will use
+        self.sample_tasks_on_reset = task_select == "random"            # wrappers.py:96 / :154
         self.terminate_on_success = bool(terminate_on_success)
         D = self.ctx.D
         lo = np.concatenate([[-0.525, 0.348, -0.0525, -1.0], np.full(14, -np.inf)] * 2 + [np.zeros(3)])
@@ -119,13 +172,29 @@ class MetaWorldGpuVectorEnv:
         if use_one_hot:
             lo, hi = np.concatenate([lo, np.zeros(ntask)]), np.concatenate([hi, np.ones(ntask)])
         self.obs_dtype = np.float32 if use_one_hot else np.float64
+        self._raw_dtype = self.obs_dtype
+        self.recurrent_info_in_obs = bool(recurrent_info_in_obs)
+        self._normalize_reward_in_recurrent_info = bool(normalize_reward_in_recurrent_info)
+        if self.recurrent_info_in_obs:      # RNNBasedMetaRLWrapper (wrappers.py:50-88): obs ++ action ++ reward ++ done, Box default dtype f32
+            lo, hi = np.full(len(lo) + 6, -np.inf), np.full(len(hi) + 6, np.inf)
+            self.obs_dtype = np.float32
+        self.reward_normalization_method, self.reward_alpha = reward_normalization_method, float(reward_alpha)
+        self._rew_mean, self._rew_var = np.zeros(self.num_envs), np.ones(self.num_envs)      # NormalizeRewardsExponential (wrappers.py:233-237)
+        self._disc_ret = np.zeros(self.num_envs)                                               # gymnasium NormalizeReward.discounted_reward
+        self._ret_rms = _RunningMeanStd(self.num_envs, (), np.float64)
+        self.normalize_observations = bool(normalize_observations)
+        if self.normalize_observations:     # gymnasium NormalizeObservation: statistics in the wrapped space's dtype, f32 output
+            self._obs_rms = _RunningMeanStd(self.num_envs, (len(lo),), self.obs_dtype)
+            lo, hi = np.full(len(lo), -np.inf), np.full(len(hi), np.inf)
+            self.obs_dtype = np.float32
+        self._ep_ret = np.zeros(self.num_envs)          # RecordEpisodeStatistics sits outside the normalisers: it sums what they return
         self.single_observation_space = _box(lo, hi, self.obs_dtype)
         self.single_action_space = _box(-np.ones(4), np.ones(4), np.float32)
         self.observation_space = _box(np.tile(lo, (self.num_envs, 1)), np.tile(hi, (self.num_envs, 1)), self.obs_dtype)
         self.action_space = _box(-np.ones((self.num_envs, 4)), np.ones((self.num_envs, 4)), np.float32)
         self._episode_start = np.full(self.num_envs, time.perf_counter())
         self.closed = False
-        assert D == len(lo)
+        assert D == len(lo) - (6 if self.recurrent_info_in_obs else 0)
 
     # ---- RandomTaskSelectWrapper stream (wrappers.py:98-100: self.np_random.choice(len(tasks))) ----
     def _draw(self, n_goals, k):
@@ -138,46 +207,136 @@ class MetaWorldGpuVectorEnv:
             s.append(int(gen.choice(n_goals)))
         return s[k]
 
-    def _advance_goals(self, mask):
-        for e in np.flatnonzero(mask):
-            if self.sample_tasks_on_reset:
-                self._next_goal[e] = self._draw(int(self._ngoals[e]), int(self._reset_count[e]))
+    def _shuffle_perm(self, n, k):
+        """Index permutation of the k-th `np_random.shuffle(tasks)` of an n-task list (wrappers.py:158-161): Generator.shuffle
+        draws do not depend on the list's contents, so one cached stream per distinct n serves all identically seeded sub-envs."""
+        if n not in self._shuffles:
+            self._shuffles[n] = (np.random.Generator(np.random.PCG64(np.random.SeedSequence(self.seed_value))), [])
+        gen, s = self._shuffles[n]
+        while len(s) <= k:
+            order = list(range(n))
+            gen.shuffle(order)          # a Python list, as in the reference (list[Task])
+            s.append(np.array(order, dtype=np.int64))
+        return s[k]
+
+    def _select(self, e, commit):
+        """Goal the next task selection of env e yields (`_set_random_task` wrappers.py:98-100 / `_set_pseudo_random_task`
+        :157-162); with commit=False nothing advances (used to tell the kernel which goal a SAME_STEP auto-reset takes)."""
+        lst = self._goal_lists[e]
+        if self.task_select == "random":
+            g = lst[self._draw(len(lst), int(self._reset_count[e]))]
+            if commit:
                 self._reset_count[e] += 1
+            return int(g)
+        idx = (int(self._task_idx[e]) + 1) % len(lst)
+        if idx == 0:
+            lst = lst[self._shuffle_perm(len(lst), int(self._reset_count[e]))]
+        if commit:
+            if idx == 0:
+                self._goal_lists[e] = lst
+                self._reset_count[e] += 1
+            self._task_idx[e] = idx
+        return int(lst[idx])
+
+    def _begin_episodes(self, mask, force=False):
+        """what `reset()` of the task-select wrapper does to the envs in mask (a new task iff sample_tasks_on_reset, or always
+        for `sample_tasks`), then the look-ahead for their next auto-reset"""
+        sample = self.sample_tasks_on_reset or force
+        for e in np.flatnonzero(mask):
+            if sample:
+                self._cur_goal[e] = self._select(e, commit=True)
+            assert self._cur_goal[e] >= 0, "no task set: call('sample_tasks') first (sawyer_xyz_env.py:699-701)"
+        self._look_ahead(mask)
+
+    def _look_ahead(self, mask):
+        for e in np.flatnonzero(mask):
+            self._next_goal[e] = self._select(e, commit=False) if self.sample_tasks_on_reset else self._cur_goal[e]
+
+    # ---- the observation / reward wrappers between the env and the vectoriser (metaworld/__init__.py:438-449) ----
+    def _wrap_reset_obs(self, obs, mask):
+        """obs of freshly reset envs through RNNBasedMetaRLWrapper.reset (wrappers.py:82-88) and NormalizeObservation"""
+        if self.recurrent_info_in_obs:
+            obs = np.concatenate([obs, np.zeros((len(obs), 6))], axis=1)
+        if self.normalize_observations:
+            obs = self._normalize_obs(obs, mask)
+        return obs
+
+    def _normalize_obs(self, obs, mask):
+        obs = obs.astype(self._obs_rms.mean.dtype)
+        self._obs_rms.update(obs, mask)
+        out = obs.astype(np.float32)
+        idx = np.flatnonzero(mask)
+        out[idx] = np.float32((obs[idx] - self._obs_rms.mean[idx]) / np.sqrt(self._obs_rms.var[idx] + 1e-8))
+        return out
+
+    def _normalize_reward(self, rew, term):
+        if self.reward_normalization_method == "exponential":
+            # NormalizeRewardsExponential.step (wrappers.py:251-258) updates the estimate twice per step: once itself, once
+            # inside _apply_normalize_reward
+            a = self.reward_alpha
+            for _ in range(2):
+                self._rew_mean = (1 - a) * self._rew_mean + a * rew
+                self._rew_var = (1 - a) * self._rew_var + a * np.square(rew - self._rew_mean)
+            return rew / (np.sqrt(self._rew_var) + 1e-8)
+        if self.reward_normalization_method == "gymnasium":
+            self._disc_ret = self._disc_ret * 0.99 * (1 - term) + rew
+            self._ret_rms.update(self._disc_ret, np.ones(self.num_envs, dtype=bool))
+            return rew / np.sqrt(self._ret_rms.var + 1e-8)
+        return rew
 
     # ---- VectorEnv API ----
     def reset(self, *, seed=None, options=None):
         mask = np.ones(self.num_envs, dtype=bool)
-        self._advance_goals(mask)
-        obs = self.ctx.reset(self._next_goal)
-        self._advance_goals(mask)          # pre-draw the goal of the next auto-reset
+        self._begin_episodes(mask)
+        obs = self._wrap_reset_obs(self.ctx.reset(self._cur_goal).astype(self._raw_dtype), mask)
         self._episode_start[:] = time.perf_counter()
+        self._ep_ret[:] = 0
         return obs.astype(self.obs_dtype, copy=True), {}
 
     def step(self, actions):
         obs, rew, term, trunc, succ, info = self.ctx.step(actions, self._next_goal)
         term_b, trunc_b = term.astype(bool), trunc.astype(bool)
+        done = term_b | trunc_b
+        obs = obs.astype(self._raw_dtype)
+        wrapped = self.recurrent_info_in_obs or self.normalize_observations
+        final = self.ctx.final_obs
+        if wrapped:          # the terminal obs goes through the wrappers' step(), the reset obs through their reset()
+            step_obs = np.where(done[:, None], final, obs).astype(self._raw_dtype)
+            if self.recurrent_info_in_obs:
+                a = np.asarray(actions, dtype=np.float64).reshape(self.num_envs, 4)
+                ro = rew / 10.0 if self._normalize_reward_in_recurrent_info else rew
+                step_obs = np.concatenate([step_obs, a, ro[:, None], done[:, None].astype(np.float64)], axis=1)
+            if self.normalize_observations:
+                step_obs = self._normalize_obs(step_obs, np.ones(self.num_envs, dtype=bool))
+            final = step_obs
+            obs = step_obs.copy()
+            if done.any():
+                obs[done] = self._wrap_reset_obs(self.ctx.obs.astype(self._raw_dtype), done)[done]
+        rew = self._normalize_reward(rew.copy(), term_b)
+        self._ep_ret += rew
         infos = {"success": succ.astype(np.float64), "_success": np.ones(self.num_envs, dtype=bool)}
         for k, key in enumerate(INFO_KEYS):
             infos[key] = info[:, k].astype(np.float64)
             infos["_" + key] = infos["_success"]
-        done = term_b | trunc_b
         if done.any():
             now = time.perf_counter()
             fi = {k: np.where(done, v, 0) for k, v in infos.items() if not k.startswith("_")}
             for k in list(fi):
                 fi["_" + k] = done.copy()
-            fi["episode"] = {"r": np.where(done, self.ctx.ep_ret, 0.0), "l": np.where(done, self.ctx.ep_len, 0),
+            ep_ret = self.ctx.ep_ret if self.reward_normalization_method is None else self._ep_ret
+            fi["episode"] = {"r": np.where(done, ep_ret, 0.0), "l": np.where(done, self.ctx.ep_len, 0),
                              "t": np.where(done, np.round(now - self._episode_start, 6), 0.0),
                              "_r": done.copy(), "_l": done.copy(), "_t": done.copy()}
             fi["_episode"] = done.copy()
             infos["final_info"], infos["_final_info"] = fi, done.copy()
             fo = np.empty(self.num_envs, dtype=object)
             for e in np.flatnonzero(done):
-                fo[e] = self.ctx.final_obs[e].astype(self.obs_dtype)
+                fo[e] = final[e].astype(self.obs_dtype)
             infos["final_obs"], infos["_final_obs"] = fo, done.copy()
             self._episode_start[done] = now
-            self._advance_goals(done)
-        return obs.astype(self.obs_dtype, copy=True), rew.copy(), term_b, trunc_b, infos
+            self._ep_ret[done] = 0
+            self._begin_episodes(done)          # the auto-reset the kernel just did used _next_goal == this selection
+        return obs.astype(self.obs_dtype, copy=True), rew, term_b, trunc_b, infos
 
     def get_attr(self, name):
         if name == "task_name":
@@ -187,13 +346,14 @@ class MetaWorldGpuVectorEnv:
         if name == "_partially_observable":
             return (self.partially_observable,) * self.num_envs
         if name == "_last_rand_vec":
-            return tuple(self.goal_tables[n][g] for n, g in zip(self.env_task_names, self._current_goals()))
+            return tuple(self.goal_tables[n][g] if g >= 0 else None for n, g in zip(self.env_task_names, self._cur_goal))
         if name == "tasks":
-            return tuple(self.goal_tables[n] for n in self.env_task_names)
+            return tuple(self.goal_tables[n][l] for n, l in zip(self.env_task_names, self._goal_lists))
+        if name == "sample_tasks_on_reset":
+            return (self.sample_tasks_on_reset,) * self.num_envs
+        if name == "current_task_idx" and self.task_select == "pseudorandom":
+            return tuple(int(i) for i in self._task_idx)
         raise AttributeError(name)
-
-    def _current_goals(self):
-        return [int(self.ctx.read(e, "task", 2)[1]) for e in range(self.num_envs)]
 
     def set_attr(self, name, values):
         """gymnasium VectorEnv.set_attr for the attributes of the reference's wrapper stack that are state here"""
@@ -202,7 +362,7 @@ class MetaWorldGpuVectorEnv:
             assert len(set(bool(v) for v in vals)) == 1, "terminate_on_success is one flag per vector env"
             self.call("toggle_terminate_on_success", bool(vals[0]))
         elif name == "sample_tasks_on_reset":
-            self.sample_tasks_on_reset = bool(vals[0])
+            self.call("toggle_sample_tasks_on_reset", bool(vals[0]))
         else:
             raise NotImplementedError(name)
 
@@ -211,32 +371,45 @@ class MetaWorldGpuVectorEnv:
         used by metaworld/evaluation.py:53-125)."""
         if name == "toggle_sample_tasks_on_reset":
             self.sample_tasks_on_reset = bool(args[0])
+            self._look_ahead(np.ones(self.num_envs, dtype=bool))
             return (None,) * self.num_envs
         if name == "toggle_terminate_on_success":
             self.terminate_on_success = bool(args[0])
             self.ctx.set_terminate_on_success(self.terminate_on_success)
             return (None,) * self.num_envs
-        if name == "sample_tasks":          # RandomTaskSelectWrapper.sample_tasks: draw a task for every env, then reset it
-            saved, self.sample_tasks_on_reset = self.sample_tasks_on_reset, True
+        if name == "sample_tasks":          # (Pseudo)RandomTaskSelectWrapper.sample_tasks: a new task for every env, then reset it
             mask = np.ones(self.num_envs, dtype=bool)
-            self._advance_goals(mask)
-            self.sample_tasks_on_reset = saved
-            obs = self.ctx.reset(self._next_goal).astype(self.obs_dtype, copy=True)
-            self._advance_goals(mask)
+            self._begin_episodes(mask, force=True)
+            obs = self._wrap_reset_obs(self.ctx.reset(self._cur_goal).astype(self._raw_dtype), mask).astype(self.obs_dtype, copy=True)
             self._episode_start[:] = time.perf_counter()
+            self._ep_ret[:] = 0
             return tuple((obs[e], {}) for e in range(self.num_envs))
         if name == "get_checkpoint":
             ck = dict(tasks={n: t.copy() for n, t in self.goal_tables.items()}, reset_count=self._reset_count.copy(),
-                      next_goal=self._next_goal.copy(), seed=self.seed_value, sample_tasks_on_reset=self.sample_tasks_on_reset,
+                      cur_goal=self._cur_goal.copy(), task_idx=self._task_idx.copy(), task_select=self.task_select,
+                      goal_lists=[l.copy() for l in self._goal_lists], seed=self.seed_value,
+                      sample_tasks_on_reset=self.sample_tasks_on_reset,
+                      normalizers=dict(rew_mean=self._rew_mean.copy(), rew_var=self._rew_var.copy(), disc_ret=self._disc_ret.copy(),
+                                       ret_rms=(self._ret_rms.mean.copy(), self._ret_rms.var.copy(), self._ret_rms.count.copy()),
+                                       obs_rms=(self._obs_rms.mean.copy(), self._obs_rms.var.copy(), self._obs_rms.count.copy())
+                                       if self.normalize_observations else None),
                       state=[self.ctx.read(e, "state") for e in range(self.num_envs)])
             return (ck,) + (None,) * (self.num_envs - 1)
         if name == "load_checkpoint":
             ck = args[0][0] if isinstance(args[0], (list, tuple)) else args[0]
             assert all(np.array_equal(ck["tasks"][n], t) for n, t in self.goal_tables.items()), "checkpoint of another benchmark/seed"
-            self._reset_count[:] = ck["reset_count"]; self._next_goal[:] = ck["next_goal"]
+            assert ck["task_select"] == self.task_select and ck["seed"] == self.seed_value
+            self._reset_count[:] = ck["reset_count"]; self._cur_goal[:] = ck["cur_goal"]; self._task_idx[:] = ck["task_idx"]
+            self._goal_lists = [l.copy() for l in ck["goal_lists"]]
             self.sample_tasks_on_reset = ck["sample_tasks_on_reset"]
+            nz = ck["normalizers"]
+            self._rew_mean, self._rew_var, self._disc_ret = nz["rew_mean"].copy(), nz["rew_var"].copy(), nz["disc_ret"].copy()
+            self._ret_rms.mean, self._ret_rms.var, self._ret_rms.count = (x.copy() for x in nz["ret_rms"])
+            if self.normalize_observations:
+                self._obs_rms.mean, self._obs_rms.var, self._obs_rms.count = (x.copy() for x in nz["obs_rms"])
             for e in range(self.num_envs):
                 self.ctx.write(e, "state", ck["state"][e])
+            self._look_ahead(np.ones(self.num_envs, dtype=bool))
             return (None,) * self.num_envs
         return self.get_attr(name)
 

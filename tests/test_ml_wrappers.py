@@ -1,0 +1,153 @@
+"""the ML construction path (`make_ml_envs`: meta_batch_size split, PseudoRandomTaskSelectWrapper,
+RNNBasedMetaRLWrapper, NormalizeRewardsExponential) on the GPU VectorEnv against the reference's own wrapper stack
+(unmodified Python from /root/reference running on the oracle engine through oracle/refshim.py).  Task selection and the
+recurrent tail are exact; obs / reward follow the engine tolerance."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from metaworld_amd import make as mk
+
+needs_ref = pytest.mark.skipif(not os.path.isdir("/root/reference/metaworld"), reason="reference checkout not present")
+
+
+def _pair(hostsim, name, **kw):
+    warnings.filterwarnings("ignore")
+    from oracle import refshim
+    refshim.install()
+    import metaworld
+    ref = metaworld.make_ml_envs(name, **kw)
+    mine = mk.make_ml_envs(name, precision="fp64", lib=hostsim, **kw)
+    return ref, mine
+
+
+def _cmp_obs(a, b, tol=2e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    assert np.abs(a - b).max() <= tol, np.abs(a - b).max()
+
+
+@needs_ref
+@pytest.mark.parametrize("select", ["pseudorandom", "random"])
+def test_ml1_stack_matches_reference(hostsim, select):
+    kw = dict(seed=42, meta_batch_size=5, split="train", task_select=select, recurrent_info_in_obs=True,
+              reward_normalization_method="exponential", terminate_on_success=False, max_episode_steps=6)
+    ref, mine = _pair(hostsim, "reach-v3", **kw)
+    assert mine.num_envs == ref.num_envs == 5
+    assert mine.single_observation_space.shape == ref.single_observation_space.shape == (45,)
+    assert mine.single_observation_space.dtype == ref.single_observation_space.dtype == np.float32
+    for a, b in zip(ref.get_attr("tasks"), mine.get_attr("tasks")):          # tasks[i::k] split of the class's 50 goals
+        import pickle
+        assert np.array_equal(np.stack([pickle.loads(t.data)["rand_vec"] for t in a]), b)
+    rng = np.random.default_rng(0)
+    for rnd in range(13):          # 10 goals per sub-env: wraps and reshuffles once
+        ro, mo = ref.call("sample_tasks"), mine.call("sample_tasks")
+        assert np.array_equal(np.stack(ref.get_attr("_last_rand_vec")), np.stack(mine.get_attr("_last_rand_vec")))
+        if select == "pseudorandom":
+            assert ref.get_attr("current_task_idx") == mine.get_attr("current_task_idx")
+        _cmp_obs(np.stack([o for o, _ in ro]), np.stack([o for o, _ in mo]))
+        if rnd % 4:
+            continue
+        for t in range(8):          # crosses the 6-step horizon: SAME_STEP auto-reset
+            a = rng.uniform(-1, 1, (5, 4)).astype(np.float32)
+            o1, r1, te1, tr1, i1 = ref.step(a)
+            o2, r2, te2, tr2, i2 = mine.step(a)
+            assert o2.dtype == o1.dtype == np.float32
+            assert np.array_equal(te1, te2) and np.array_equal(tr1, tr2)
+            _cmp_obs(o1, o2)
+            assert np.array_equal(o1[:, 39:43], o2[:, 39:43]) and np.array_equal(o1[:, 44], o2[:, 44])     # action, done: exact
+            assert np.abs(r1 - r2).max() <= 1e-5 * max(1.0, np.abs(r1).max())
+            # a pseudorandom env keeps its task over an auto-reset, a random one redraws
+            assert np.array_equal(np.stack(ref.get_attr("_last_rand_vec")), np.stack(mine.get_attr("_last_rand_vec")))
+            if (te1 | tr1).any():
+                for e in np.flatnonzero(te1 | tr1):
+                    _cmp_obs(i1["final_obs"][e], i2["final_obs"][e])
+                    assert i2["final_obs"][e][44] == 1.0
+                f1, f2 = i1["final_info"]["episode"], i2["final_info"]["episode"]
+                assert np.array_equal(f1["l"], f2["l"])
+                assert np.abs(f1["r"] - f2["r"]).max() <= 1e-5 * max(1.0, np.abs(f1["r"]).max())
+    ref.close(); mine.close()
+
+
+@needs_ref
+def test_ml10_train_meta_batch_split_and_toggle(hostsim):
+    """two sub-envs per class (tasks[0::2], tasks[1::2]); sampling toggled on mid-run takes effect at the next auto-reset"""
+    kw = dict(seed=7, meta_batch_size=20, split="train", task_select="pseudorandom", terminate_on_success=False, max_episode_steps=3)
+    ref, mine = _pair(hostsim, "ML10", **kw)
+    assert mine.num_envs == ref.num_envs == 20
+    assert [type(e.unwrapped).__name__ for e in ref.envs] == list(mine.get_attr("task_name"))
+    with pytest.raises(AssertionError):          # no task set before sample_tasks (sawyer_xyz_env.py:699-701)
+        mine.reset()
+    ref.call("sample_tasks"); mine.call("sample_tasks")
+    rng = np.random.default_rng(1)
+    for t in range(10):
+        if t == 4:
+            ref.call("toggle_sample_tasks_on_reset", True); mine.call("toggle_sample_tasks_on_reset", True)
+        if t == 8:
+            ref.call("toggle_sample_tasks_on_reset", False); mine.call("toggle_sample_tasks_on_reset", False)
+        a = rng.uniform(-1, 1, (20, 4)).astype(np.float32)
+        o1, r1, te1, tr1, i1 = ref.step(a)
+        o2, r2, te2, tr2, i2 = mine.step(a)
+        assert np.array_equal(tr1, tr2)
+        for e, (v1, v2) in enumerate(zip(ref.get_attr("_last_rand_vec"), mine.get_attr("_last_rand_vec"))):
+            assert np.array_equal(v1, v2[:len(v1)]), (t, e)          # 3- or 6-long in the reference, one 6-wide table here
+        assert ref.get_attr("current_task_idx") == mine.get_attr("current_task_idx")
+    ref.close(); mine.close()
+
+
+def test_factories_and_errors(hostsim):
+    with pytest.raises(ValueError):
+        mk.make_mt_envs("MT11")
+    with pytest.raises(ValueError):
+        mk.make_ml_envs("ML11")
+    with pytest.raises(AssertionError):          # 5 test classes do not divide 12 (metaworld/__init__.py:527-529)
+        mk.make_ml_envs("ML10", split="test", meta_batch_size=12, lib=hostsim)
+    with pytest.raises(AssertionError):          # 50 goals over 4 sub-envs per class: uneven (metaworld/__init__.py:540-542)
+        mk.make_ml_envs("ML10", split="test", meta_batch_size=20, lib=hostsim)
+    with pytest.raises(NotImplementedError):
+        mk.make_mt_envs("reach-v3", reward_function_version="v1", lib=hostsim)
+    with pytest.raises(NotImplementedError):
+        mk.make_mt_envs("MT10", autoreset_mode="NextStep", lib=hostsim)
+    env = mk.make_ml_envs_test("ML10", seed=3, meta_batch_size=20, total_tasks_per_cls=40, lib=hostsim)
+    assert env.num_envs == 20 and env.terminate_on_success and env.task_select == "pseudorandom" and not env.sample_tasks_on_reset
+    assert all(len(t) == 10 for t in env.get_attr("tasks")) and env.partially_observable
+    env.close()
+    env = mk.make_mt_envs("MT10", seed=5, use_one_hot=True, num_envs=20, lib=hostsim)
+    assert env.num_envs == 20 and env.single_observation_space.shape == (49,)
+    from metaworld_amd import tasks as T
+    assert np.array_equal(env.goal_tables["reach-v3"], T.goal_table("MT10", "reach-v3", 5))          # one seed feeds the goals too
+    env.close()
+    assert mk.register_mw_envs() in (True, False)
+
+
+def test_normalizers_and_checkpoint(hostsim):
+    """gymnasium-style normalisers (restated, unpinned): running statistics per sub-env; the checkpoint carries them"""
+    kw = dict(seed=1, num_envs=3, max_episode_steps=4, reward_normalization_method="gymnasium", normalize_observations=True, lib=hostsim)
+    env = mk.make_mt_envs("reach-v3", **kw)
+    obs, _ = env.reset()
+    assert obs.dtype == np.float32 and np.abs(obs).max() < 2e-2          # first sample: (x - mean) / std ~ 1e-2 x
+    rng = np.random.default_rng(0)
+    acts = rng.uniform(-1, 1, (12, 3, 4)).astype(np.float32)
+    for t in range(6):
+        obs, rew, te, tr, info = env.step(acts[t])
+    ck = env.call("get_checkpoint")[0]
+    tail = [env.step(acts[t]) for t in range(6, 12)]
+    env2 = mk.make_mt_envs("reach-v3", **kw)
+    env2.reset()
+    env2.call("load_checkpoint", ck)
+    for t in range(6, 12):
+        o, r, te, tr, info = env2.step(acts[t])
+        assert np.array_equal(o, tail[t - 6][0]) and np.array_equal(r, tail[t - 6][1])
+    env.close(); env2.close()
+    # raw reward r with return variance v -> r / sqrt(v + 1e-8)
+    env = mk.make_mt_envs("reach-v3", seed=1, num_envs=2, reward_normalization_method="gymnasium", lib=hostsim)
+    raw = mk.make_mt_envs("reach-v3", seed=1, num_envs=2, lib=hostsim)
+    env.reset(); raw.reset()
+    a = np.zeros((2, 4), dtype=np.float32)
+    r_n, r_r = env.step(a)[1], raw.step(a)[1]
+    cnt = 1e-4
+    var = (1.0 * cnt + r_r ** 2 * cnt / (cnt + 1)) / (cnt + 1)
+    assert np.allclose(r_n, r_r / np.sqrt(var + 1e-8), rtol=1e-12)
+    env.close(); raw.close()
