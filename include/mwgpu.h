@@ -89,6 +89,25 @@ int mw_step(mw_ctx* c, const float* actions /*[N][4]*/, const int32_t* next_goal
 int mw_upload_actions(mw_ctx* c, const float* actions /*[nsteps][N][4]*/, int nsteps);
 int mw_step_resident(mw_ctx* c, int nsteps, int action_steps, float* kernel_ms /*HIP-event time of the nsteps launches*/);
 
+/* ---- device-resident boundary (SURVEY.md 8b "outputs_on_device"): the learner's policy runs on the same GPU, so actions and
+ *      outputs never visit the host.  Every pointer is a DEVICE pointer the caller owns (a torch tensor's data_ptr()); a NULL
+ *      output keeps the context's own buffer.  The call launches on the context's stream and returns after that stream has
+ *      drained, so the caller only has to make sure its own writes to `actions` have completed (torch: synchronize the current
+ *      stream first).  Semantics are those of mw_step / mw_reset. ---- */
+typedef struct mw_device_out {
+    double* obs;              /* [N][D] */
+    double* reward;           /* [N] */
+    uint8_t* flags;           /* [4][N]: terminated, truncated, success, done */
+    float* info;              /* [N][6] */
+    double* final_obs;        /* [N][D], rows of finished envs only */
+    double* episode_return;   /* [N], written for finished envs only */
+    int32_t* episode_length;  /* [N], written for finished envs only */
+} mw_device_out;
+int mw_step_device(mw_ctx* c, const float* actions /*device [N][4]*/, const int32_t* next_goal /*device [N] or NULL = last uploaded*/,
+                   const mw_device_out* out /*or NULL*/);
+int mw_reset_device(mw_ctx* c, const uint8_t* mask /*device [N] or NULL = all*/, const int32_t* goal_idx /*device [N]*/,
+                    double* obs_out /*device [N][D] or NULL*/);
+
 /* ---- state access for parity tests (mujoco data.qpos / qvel / mocap_pos, MujocoEnv.set_state) ---- */
 int mw_column_size(mw_ctx* c, int env, const char* what);
 int mw_read(mw_ctx* c, int env, const char* what, double* out, int n);

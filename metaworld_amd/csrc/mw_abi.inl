@@ -99,6 +99,12 @@ int MW_API(step)(mw_ctx* c, const float* a, const int32_t* ng, double* obs, doub
 }
 int MW_API(upload_actions)(mw_ctx* c, const float* a, int nsteps) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->upload_actions(a, nsteps); }); }
 int MW_API(step_resident)(mw_ctx* c, int nsteps, int asteps, float* ms) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->step_device_only(nullptr, nsteps, asteps, ms); }); }
+int MW_API(step_device)(mw_ctx* c, const float* d_act, const int32_t* d_next_goal, const mw_device_out* out) {
+    MW_TRY(c, { MW_NEED_IMPL(c); if (!d_act) throw std::invalid_argument("step_device: actions are required"); c->impl->step_device(d_act, d_next_goal, out); });
+}
+int MW_API(reset_device)(mw_ctx* c, const uint8_t* d_mask, const int32_t* d_goal_idx, double* d_obs) {
+    MW_TRY(c, { MW_NEED_IMPL(c); if (!d_goal_idx) throw std::invalid_argument("reset_device: goal_idx is required"); c->impl->reset_device(d_mask, d_goal_idx, d_obs); });
+}
 int MW_API(column_size)(mw_ctx* c, int env, const char* what) {
     try { MW_NEED_IMPL(c); return c->impl->layout_size(env, what); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
 }

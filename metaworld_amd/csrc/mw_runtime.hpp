@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/mwgpu.h"   // mw_device_out (the C ABI types are plain structs)
 #include "mw_collide.hpp"
 #include "mw_common.hpp"
 #include "mw_phys.hpp"
@@ -289,6 +290,8 @@ public:
     virtual void step(const float* act, const int* next_goal, double* obs, double* reward, uint8_t* term, uint8_t* trunc,
                       uint8_t* success, float* info, double* final_obs, double* ep_ret, int* ep_len) = 0;
     virtual void step_device_only(const float* d_act, int nsteps, int act_stride_steps, float* kernel_ms) = 0;
+    virtual void step_device(const float* d_act, const int* d_next_goal, const mw_device_out* out) = 0;
+    virtual void reset_device(const uint8_t* d_mask, const int* d_goal_idx, double* d_obs) = 0;
     virtual void upload_actions(const float* act, int nsteps) = 0;
     virtual void read_col(int gid, const char* what, int n, double* out) = 0;
     virtual void write_col(int gid, const char* what, int n, const double* in) = 0;
@@ -580,6 +583,32 @@ public:
         if (final_obs) Backend::d2h(final_obs, d_final_, sizeof(double) * N_ * D);
         if (ep_ret) Backend::d2h(ep_ret, d_epret_, sizeof(double) * N_);
         if (ep_len) Backend::d2h(ep_len, d_eplen_, sizeof(int) * N_);
+    }
+
+    // device-resident boundary: actions / goal indices are device pointers, outputs are written straight into the caller's
+    // device buffers (any of them null = the context's own buffer); no host copies, one stream sync before returning
+    void step_device(const float* d_act, const int* d_next_goal, const mw_device_out* out) override {
+        World<T> w = world();
+        w.io.act = d_act;
+        if (d_next_goal) w.io.next_goal = const_cast<int*>(d_next_goal);
+        if (out) {
+            if (out->obs) w.io.obs = out->obs;
+            if (out->reward) w.io.reward = out->reward;
+            if (out->flags) { w.io.terminated = out->flags; w.io.truncated = out->flags + N_; w.io.success = out->flags + 2 * N_; w.io.done = out->flags + 3 * N_; }
+            if (out->info) w.io.info = out->info;
+            if (out->final_obs) w.io.final_obs = out->final_obs;
+            if (out->episode_return) w.io.ep_ret = out->episode_return;
+            if (out->episode_length) w.io.ep_len = out->episode_length;
+        }
+        Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+        Backend::sync();
+    }
+    void reset_device(const uint8_t* d_mask, const int* d_goal_idx, double* d_obs) override {
+        World<T> w = world();
+        w.io.next_goal = const_cast<int*>(d_goal_idx);
+        if (d_obs) w.io.obs = d_obs;
+        Backend::launch(nblocks_, [w, d_mask] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_snap(w, d_mask, b, t, sp); });
+        Backend::sync();
     }
 
     void upload_actions(const float* act, int nsteps) override {

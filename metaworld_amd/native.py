@@ -30,11 +30,25 @@ class MwTask(C.Structure):
                 ("obj_off", (C.c_double * 3) * 2), ("c", C.c_double * 15)]
 
 
+class MwDeviceOut(C.Structure):
+    """mw_device_out (include/mwgpu.h): caller-owned DEVICE output buffers of mw_step_device"""
+    _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("flags", C.c_void_p), ("info", C.c_void_p),
+                ("final_obs", C.c_void_p), ("episode_return", C.c_void_p), ("episode_length", C.c_void_p)]
+
+
 class Lib:
     def __init__(self, path, prefix):
         if not os.path.exists(path):
             raise RuntimeError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        if prefix == "mw_":
+            # One HIP runtime per process: torch wheels bundle their own libamdhip64, and whichever copy is loaded first owns
+            # the device.  Importing torch first (when present) makes libmwgpu.so bind to that copy, so the library and
+            # torch tensors (MetaWorldTorchVectorEnv, RCCL in bench.py) can share the GPU whatever the caller's import order.
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         self.dll = C.CDLL(path)
         self.prefix = prefix
         f = self._f
@@ -57,6 +71,8 @@ class Lib:
         f("step", C.c_int, *([C.c_void_p] * 12))
         f("upload_actions", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
         f("step_resident", C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float))
+        f("step_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MwDeviceOut))
+        f("reset_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
         f("column_size", C.c_int, C.c_void_p, C.c_int, C.c_char_p)
         f("read", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
         f("write", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
@@ -83,7 +99,7 @@ def load(prefix="mw_", path=None) -> Lib:
 
 EXPORTED_SYMBOLS = ["model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
                     "add_model", "add_task", "set_envs", "finalize", "set_terminate_on_success", "destroy", "last_error", "num_envs", "obs_dim",
-                    "reset", "step", "upload_actions", "step_resident", "column_size", "read", "write", "read_int",
+                    "reset", "step", "step_device", "reset_device", "upload_actions", "step_resident", "column_size", "read", "write", "read_int",
                     "debug"]
 
 
@@ -161,6 +177,13 @@ class Context:
                                   self.success.ctypes.data, self.info.ctypes.data, self.final_obs.ctypes.data,
                                   self.ep_ret.ctypes.data, self.ep_len.ctypes.data))
         return self.obs, self.reward, self.terminated, self.truncated, self.success, self.info
+
+    def step_device(self, actions_ptr, next_goal_ptr=None, out: MwDeviceOut | None = None):
+        """mw_step_device: raw device pointers in, outputs into the caller's device buffers"""
+        self._check(self.lib.step_device(self.ptr, actions_ptr, next_goal_ptr, None if out is None else C.byref(out)))
+
+    def reset_device(self, goal_idx_ptr, mask_ptr=None, obs_ptr=None):
+        self._check(self.lib.reset_device(self.ptr, mask_ptr, goal_idx_ptr, obs_ptr))
 
     def upload_actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32)

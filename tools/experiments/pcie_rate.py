@@ -21,3 +21,21 @@ for t in range(300):
     env.ctx.step(acts[t % 64], env._next_goal)
 dt = time.perf_counter() - t0
 print(f"mw_step C ABI only (host in/out): {dt / 300 * 1e3:.2f} ms/step  {n * 300 / dt / 1e3:.1f} k env-steps/s")
+env.close()
+
+# device-resident boundary: actions drawn on the GPU by torch, outputs stay tensors (mw_step_device)
+import torch
+from metaworld_amd.torch_env import MetaWorldTorchVectorEnv
+env = MetaWorldTorchVectorEnv("MT50", num_envs=n, seed=42, use_one_hot=True, precision="fp32")
+env.reset()
+g = torch.Generator(device="cuda").manual_seed(0)
+for t in range(20):
+    env.step(torch.rand((n, 4), device="cuda", generator=g) * 2 - 1)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for t in range(300):
+    obs, rew, term, trunc, info = env.step(torch.rand((n, 4), device="cuda", generator=g) * 2 - 1)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"MetaWorldTorchVectorEnv.step (device in/out): {dt / 300 * 1e3:.2f} ms/step  {n * 300 / dt / 1e3:.1f} k env-steps/s")
+env.close()
