@@ -108,6 +108,17 @@ int mw_step_device(mw_ctx* c, const float* actions /*device [N][4]*/, const int3
 int mw_reset_device(mw_ctx* c, const uint8_t* mask /*device [N] or NULL = all*/, const int32_t* goal_idx /*device [N]*/,
                     double* obs_out /*device [N][D] or NULL*/);
 
+/* ---- scripted policies on the device (metaworld/policies/sawyer_*_v3_policy.py, SawyerXYZPolicy.get_action `policy.py:34-53`;
+ *      device code generated from metaworld_amd/policies.py by tools/gen_device_policies.py).  policy_id[i] = index of env i's
+ *      task in ALL_V3_ENVIRONMENTS order (`env_dict.py:217-270`); observations must show the goal.
+ *      mw_policy_actions: one policy evaluation, host obs in -> host actions out (float32, clipped to [-1, 1]).
+ *      mw_policy_rollout: the closed loop of metaworld/evaluation.py:48-103 with the scripted policy as the agent, entirely on
+ *      the device: reset every env to goal_schedule[0][i], then nsteps x (policy kernel, step kernel); the k-th auto-reset of
+ *      env i takes goal_schedule[min(k, K-1)][i].  Outputs per env: finished episodes, and those in which success was ever 1. ---- */
+int mw_policy_actions(mw_ctx* c, const int32_t* policy_id /*[N]*/, const double* obs /*[N][D]*/, float* actions /*[N][4] out*/);
+int mw_policy_rollout(mw_ctx* c, const int32_t* policy_id /*[N]*/, const int32_t* goal_schedule /*[K][N]*/, int K, int nsteps,
+                      int32_t* episodes /*[N] out or NULL*/, int32_t* successes /*[N] out or NULL*/, float* kernel_ms /*or NULL*/);
+
 /* ---- state access for parity tests (mujoco data.qpos / qvel / mocap_pos, MujocoEnv.set_state) ---- */
 int mw_column_size(mw_ctx* c, int env, const char* what);
 int mw_read(mw_ctx* c, int env, const char* what, double* out, int n);

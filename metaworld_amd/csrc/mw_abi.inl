@@ -105,6 +105,12 @@ int MW_API(step_device)(mw_ctx* c, const float* d_act, const int32_t* d_next_goa
 int MW_API(reset_device)(mw_ctx* c, const uint8_t* d_mask, const int32_t* d_goal_idx, double* d_obs) {
     MW_TRY(c, { MW_NEED_IMPL(c); if (!d_goal_idx) throw std::invalid_argument("reset_device: goal_idx is required"); c->impl->reset_device(d_mask, d_goal_idx, d_obs); });
 }
+int MW_API(policy_actions)(mw_ctx* c, const int32_t* policy_id, const double* obs, float* act) {
+    MW_TRY(c, { MW_NEED_IMPL(c); if (!policy_id || !obs || !act) throw std::invalid_argument("policy_actions: null argument"); c->impl->policy_actions(policy_id, obs, act); });
+}
+int MW_API(policy_rollout)(mw_ctx* c, const int32_t* policy_id, const int32_t* schedule, int K, int nsteps, int32_t* episodes, int32_t* successes, float* ms) {
+    MW_TRY(c, { MW_NEED_IMPL(c); if (!policy_id || !schedule) throw std::invalid_argument("policy_rollout: null argument"); c->impl->policy_rollout(policy_id, schedule, K, nsteps, episodes, successes, ms); });
+}
 int MW_API(column_size)(mw_ctx* c, int env, const char* what) {
     try { MW_NEED_IMPL(c); return c->impl->layout_size(env, what); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
 }

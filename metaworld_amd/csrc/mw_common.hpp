@@ -22,9 +22,11 @@
 #include <hip/hip_runtime.h>
 #define MW_HD __host__ __device__ inline
 #define MW_STAGE_FN __host__ __device__ __attribute__((noinline))   // the big stages: one copy each (code size, compile time)
+#define MW_FP_EXACT _Pragma("clang fp contract(off)")   // first statement of a block: no fused multiply-add (bit-exact restatements)
 #else
 #define MW_HD inline
 #define MW_STAGE_FN inline
+#define MW_FP_EXACT   // the host harness is built with -ffp-contract=off
 #endif
 
 namespace mw {

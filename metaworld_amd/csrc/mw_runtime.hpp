@@ -20,6 +20,7 @@
 #include "mw_collide.hpp"
 #include "mw_common.hpp"
 #include "mw_phys.hpp"
+#include "mw_policies_gen.hpp"
 #include "mw_tasks.hpp"
 
 namespace mw {
@@ -292,6 +293,8 @@ public:
     virtual void step_device_only(const float* d_act, int nsteps, int act_stride_steps, float* kernel_ms) = 0;
     virtual void step_device(const float* d_act, const int* d_next_goal, const mw_device_out* out) = 0;
     virtual void reset_device(const uint8_t* d_mask, const int* d_goal_idx, double* d_obs) = 0;
+    virtual void policy_actions(const int* policy_id, const double* obs, float* act) = 0;
+    virtual void policy_rollout(const int* policy_id, const int* schedule, int K, int nsteps, int* episodes, int* successes, float* kernel_ms) = 0;
     virtual void upload_actions(const float* act, int nsteps) = 0;
     virtual void read_col(int gid, const char* what, int n, double* out) = 0;
     virtual void write_col(int gid, const char* what, int n, const double* in) = 0;
@@ -609,6 +612,64 @@ public:
         if (d_obs) w.io.obs = d_obs;
         Backend::launch(nblocks_, [w, d_mask] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_reset_snap(w, d_mask, b, t, sp); });
         Backend::sync();
+    }
+
+    // ---- scripted policies on the device (generated from metaworld_amd/policies.py) ----
+    struct PolicyState {       // per-env device arrays of a closed-loop rollout
+        int* policy_id; int* schedule; int K; int* episodes; int* successes; uint8_t* ever;
+    };
+    // one thread per env: book the step that just ran (an episode counts as solved if success was ever 1 in it), pick the goal
+    // of the env's next auto-reset from its schedule, then act on the observation the step returned
+    static MW_HD void policy_thread(const IOPtrs& io, const PolicyState& ps, int N, int gid, bool account, bool act) {
+        if (account) {
+            uint8_t ever = ps.ever[gid] | io.success[gid];
+            if (io.done[gid]) { ps.successes[gid] += ever ? 1 : 0; ps.episodes[gid] += 1; ever = 0; }
+            ps.ever[gid] = ever;
+        }
+        if (!act) return;
+        int k = ps.episodes[gid] + 1;
+        const_cast<int*>(io.next_goal)[gid] = ps.schedule[(size_t)(k < ps.K ? k : ps.K - 1) * N + gid];
+        scripted_policy(ps.policy_id[gid], io.obs + (size_t)gid * io.D, const_cast<float*>(io.act) + (size_t)gid * 4);
+    }
+
+    void policy_actions(const int* policy_id, const double* obs, float* act) override {
+        const int D = obs_dim();
+        int* d_pid = (int*)Backend::alloc(sizeof(int) * N_);
+        Backend::h2d(d_pid, policy_id, sizeof(int) * N_);
+        Backend::h2d(d_obs_, obs, sizeof(double) * N_ * D);
+        const double* d_o = d_obs_; float* d_a = d_act_;
+        Backend::launch_flat(N_, [d_pid, d_o, d_a, D] MW_LAMBDA(int gid) { scripted_policy(d_pid[gid], d_o + (size_t)gid * D, d_a + (size_t)gid * 4); });
+        Backend::sync();
+        Backend::d2h(act, d_act_, sizeof(float) * 4 * N_);
+        Backend::free(d_pid);
+    }
+
+    // closed loop entirely on the device: reset to schedule[0], then nsteps x (policy kernel -> step kernel); the k-th
+    // auto-reset of env i takes goal schedule[min(k, K-1)][i].  No host round trip inside the loop.
+    void policy_rollout(const int* policy_id, const int* schedule, int K, int nsteps, int* episodes, int* successes, float* kernel_ms) override {
+        if (K < 1) throw std::invalid_argument("policy_rollout: the goal schedule needs at least one row");
+        PolicyState ps{};
+        ps.policy_id = (int*)Backend::alloc(sizeof(int) * N_); ps.schedule = (int*)Backend::alloc(sizeof(int) * N_ * K); ps.K = K;
+        ps.episodes = (int*)Backend::alloc(sizeof(int) * N_); ps.successes = (int*)Backend::alloc(sizeof(int) * N_);
+        ps.ever = (uint8_t*)Backend::alloc(N_);
+        Backend::h2d(ps.policy_id, policy_id, sizeof(int) * N_);
+        Backend::h2d(ps.schedule, schedule, sizeof(int) * N_ * K);
+        Backend::zero(ps.episodes, sizeof(int) * N_); Backend::zero(ps.successes, sizeof(int) * N_); Backend::zero(ps.ever, N_);
+        reset(nullptr, schedule, nullptr);
+        World<T> w = world();
+        const IOPtrs io = w.io; const int N = N_;
+        Backend::timed_begin();
+        for (int s = 0; s < nsteps; s++) {
+            const bool account = s > 0;
+            Backend::launch_flat(N_, [io, ps, N, account] MW_LAMBDA(int gid) { policy_thread(io, ps, N, gid, account, true); });
+            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+        }
+        if (nsteps > 0) Backend::launch_flat(N_, [io, ps, N] MW_LAMBDA(int gid) { policy_thread(io, ps, N, gid, true, false); });
+        const float ms = Backend::timed_end();
+        if (kernel_ms) *kernel_ms = ms;
+        if (episodes) Backend::d2h(episodes, ps.episodes, sizeof(int) * N_);
+        if (successes) Backend::d2h(successes, ps.successes, sizeof(int) * N_);
+        Backend::free(ps.policy_id); Backend::free(ps.schedule); Backend::free(ps.episodes); Backend::free(ps.successes); Backend::free(ps.ever);
     }
 
     void upload_actions(const float* act, int nsteps) override {

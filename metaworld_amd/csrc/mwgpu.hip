@@ -27,6 +27,13 @@ __global__ void __launch_bounds__(64) k_lanes(F f, int block_words) {
     f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, block_words, 0});
 }
 
+// one thread per environment, no scratchpad: the small per-env kernels around the step (scripted policies, accounting)
+template <class F>
+__global__ void __launch_bounds__(256) k_flat(F f, int n) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < n) f(i);
+}
+
 struct Backend {
     static hipStream_t& stream() { static hipStream_t s = nullptr; return s; }
     static hipEvent_t* events() { static hipEvent_t ev[2] = {nullptr, nullptr}; return ev; }
@@ -76,6 +83,11 @@ struct Backend {
             configured = bytes;
         }
         hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), bytes, stream(), f, bytes / 4);
+        hip_check(hipGetLastError(), "kernel launch");
+    }
+    template <class F>
+    static void launch_flat(int n, F f) {
+        hipLaunchKernelGGL(k_flat<F>, dim3((n + 255) / 256), dim3(256), 0, stream(), f, n);
         hip_check(hipGetLastError(), "kernel launch");
     }
     static void sync() { hip_check(hipStreamSynchronize(stream()), "hipStreamSynchronize"); }

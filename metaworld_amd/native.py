@@ -73,6 +73,8 @@ class Lib:
         f("step_resident", C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float))
         f("step_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MwDeviceOut))
         f("reset_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+        f("policy_actions", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+        f("policy_rollout", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float))
         f("column_size", C.c_int, C.c_void_p, C.c_int, C.c_char_p)
         f("read", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
         f("write", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
@@ -99,7 +101,7 @@ def load(prefix="mw_", path=None) -> Lib:
 
 EXPORTED_SYMBOLS = ["model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
                     "add_model", "add_task", "set_envs", "finalize", "set_terminate_on_success", "destroy", "last_error", "num_envs", "obs_dim",
-                    "reset", "step", "step_device", "reset_device", "upload_actions", "step_resident", "column_size", "read", "write", "read_int",
+                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "upload_actions", "step_resident", "column_size", "read", "write", "read_int",
                     "debug"]
 
 
@@ -184,6 +186,25 @@ class Context:
 
     def reset_device(self, goal_idx_ptr, mask_ptr=None, obs_ptr=None):
         self._check(self.lib.reset_device(self.ptr, mask_ptr, goal_idx_ptr, obs_ptr))
+
+    def policy_actions(self, policy_id, obs):
+        """mw_policy_actions: the device scripted policies on host observations -> float32 [N, 4]"""
+        pid = np.ascontiguousarray(policy_id, dtype=np.int32)
+        o = np.ascontiguousarray(obs, dtype=np.float64)
+        assert pid.shape == (self.N,) and o.shape == (self.N, self.D)
+        act = np.zeros((self.N, 4), dtype=np.float32)
+        self._check(self.lib.policy_actions(self.ptr, pid.ctypes.data, o.ctypes.data, act.ctypes.data))
+        return act
+
+    def policy_rollout(self, policy_id, goal_schedule, nsteps):
+        """mw_policy_rollout -> (episodes [N], successes [N], kernel ms)"""
+        pid = np.ascontiguousarray(policy_id, dtype=np.int32)
+        sch = np.ascontiguousarray(goal_schedule, dtype=np.int32)
+        assert pid.shape == (self.N,) and sch.ndim == 2 and sch.shape[1] == self.N
+        ep, su, ms = np.zeros(self.N, dtype=np.int32), np.zeros(self.N, dtype=np.int32), C.c_float(0)
+        self._check(self.lib.policy_rollout(self.ptr, pid.ctypes.data, sch.ctypes.data, sch.shape[0], int(nsteps),
+                                            ep.ctypes.data, su.ctypes.data, C.byref(ms)))
+        return ep, su, ms.value
 
     def upload_actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32)

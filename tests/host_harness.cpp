@@ -38,6 +38,8 @@ struct Backend {
                 for (int t = 0; t < 64; t++) f(b, t, mw::Scratchpad{pad.data(), words, ns});
         }
     }
+    template <class F>
+    static void launch_flat(int n, F f) { for (int i = 0; i < n; i++) f(i); }
     static int compute_units() { return 256; }
     static void sync() {}
     static std::chrono::steady_clock::time_point& t0() { static std::chrono::steady_clock::time_point t; return t; }
