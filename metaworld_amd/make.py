@@ -55,6 +55,25 @@ def make_ml_envs(name, seed=None, meta_batch_size=20, total_tasks_per_cls=None, 
     raise ValueError("Invalid ML env name. Must either be a valid Metaworld task name (e.g. 'reach-v3'), 'ML10', 'ML25', or 'ML45'.")
 
 
+def make_custom_mt_envs(envs_list, seed=None, use_one_hot=False, vector_strategy="sync", autoreset_mode="SameStep", num_envs=None, **kwargs):
+    """The "Meta-World/custom-mt-envs" entry point (metaworld/__init__.py:741-781): env idx is `make_mt_envs(envs_list[idx],
+    seed=seed + idx, env_id=idx, num_tasks=len(envs_list))`, i.e. MT1 goal tables and a task-selection stream per class."""
+    _check_autoreset(autoreset_mode)
+    return MetaWorldGpuVectorEnv("custom-mt", envs_list=list(envs_list), num_envs=num_envs, seed=seed or None,
+                                 goal_seed=seed or 42, use_one_hot=use_one_hot, **kwargs)
+
+
+def make_custom_ml_envs(train_envs, test_envs, seed=None, meta_batch_size=20, total_tasks_per_cls=None, split="train",
+                        vector_strategy="sync", autoreset_mode="SameStep", num_envs=None, **kwargs):
+    """The "Meta-World/custom-ml-envs" entry point (metaworld/__init__.py:783-821) over CustomML (`:370-395`)."""
+    _check_autoreset(autoreset_mode)
+    if set(train_envs) & set(test_envs):
+        raise ValueError("The test tasks cannot contain any of the train tasks.")
+    return MetaWorldGpuVectorEnv("custom-ml", envs_list=list(train_envs if split == "train" else test_envs), seed=seed,
+                                 goal_seed=42 if seed is None else seed, meta_batch_size=meta_batch_size,
+                                 total_tasks_per_cls=total_tasks_per_cls, partially_observable=kwargs.pop("partially_observable", True), **kwargs)
+
+
 # metaworld/__init__.py:596-604
 make_ml_envs_train = partial(make_ml_envs, terminate_on_success=False, task_select="pseudorandom", split="train")
 make_ml_envs_test = partial(make_ml_envs, terminate_on_success=True, task_select="pseudorandom", split="test")
@@ -85,4 +104,8 @@ def register_mw_envs(namespace="Meta-World-GPU"):
         register(id=f"{namespace}/ML1-{split}", vector_entry_point=partial(ml, "ML1", split), kwargs={})
         for b in _ML:
             register(id=f"{namespace}/{b}-{split}", vector_entry_point=partial(ml, b, split), kwargs={})
+    register(id=f"{namespace}/custom-mt-envs", kwargs={},
+             vector_entry_point=lambda envs_list, vector_strategy="sync", **kw: make_custom_mt_envs(envs_list, **kw))
+    register(id=f"{namespace}/custom-ml-envs", kwargs={},
+             vector_entry_point=lambda train_envs, test_envs, vector_strategy="sync", **kw: make_custom_ml_envs(train_envs, test_envs, **kw))
     return True

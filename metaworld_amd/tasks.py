@@ -140,6 +140,18 @@ def goal_table(benchmark: str, task: str, seed: int = 42) -> np.ndarray:
     return tab[task]
 
 
+def custom_goal_tables(task_list, seed: int) -> dict:
+    """{task: [50][6]} of `_make_tasks` over an arbitrary class list (CustomML `metaworld/__init__.py:370-395`; one-task lists
+    give the MT1(seed) tables the custom MT entry point builds per env, `:741-767`)."""
+    from . import goals
+    key = ("custom", tuple(task_list), seed)
+    if key not in _goal_cache:
+        with open(os.path.join(_HERE, "data", "task_constants.json")) as f:
+            C = json.load(f)
+        _goal_cache[key] = goals.make_tables(list(task_list), seed, C["tasks"])
+    return _goal_cache[key]
+
+
 _model_cache = {}
 
 

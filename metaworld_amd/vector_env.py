@@ -80,7 +80,7 @@ class MetaWorldGpuVectorEnv:
                  rank=0, world_size=1, goal_seed=42, task_names=None, lib=None, maxcon=None, maxefc=None,
                  partially_observable=None, task_select="random", meta_batch_size=None, total_tasks_per_cls=None,
                  recurrent_info_in_obs=False, normalize_reward_in_recurrent_info=True, reward_function_version="v2",
-                 reward_normalization_method=None, reward_alpha=0.001, normalize_observations=False):
+                 reward_normalization_method=None, reward_alpha=0.001, normalize_observations=False, envs_list=None):
         """The keyword set of the reference's `_init_each_env` / `make_ml_envs` (metaworld/__init__.py:398-460, :516-618):
         `task_select` "random" = RandomTaskSelectWrapper, "pseudorandom" = PseudoRandomTaskSelectWrapper;
         `meta_batch_size` / `total_tasks_per_cls` = the ML split of each class's goals over sub-envs (`tasks[i::k]`);
@@ -92,7 +92,13 @@ class MetaWorldGpuVectorEnv:
             raise ValueError(f"task_select must be 'random' or 'pseudorandom', got {task_select!r}")
         if reward_normalization_method not in (None, "gymnasium", "exponential"):
             raise ValueError(f"unknown reward_normalization_method {reward_normalization_method!r}")
-        names, goal_key = benchmark_tasks(benchmark, env_name)
+        custom = benchmark in ("custom-mt", "custom-ml")          # arbitrary class lists (metaworld/__init__.py:741-821)
+        if custom:
+            names, goal_key = list(envs_list), benchmark
+            if len(set(names)) != len(names) or any(n not in T.ALL_V3 for n in names):
+                raise ValueError(f"envs_list must hold distinct v3 task names, got {names}")
+        else:
+            names, goal_key = benchmark_tasks(benchmark, env_name)
         if task_names is not None:          # restrict a benchmark to the tasks that have device code (tests)
             names = [n for n in names if n in task_names]
         missing = [n for n in names if n not in T.TASK_DEFS]
@@ -130,7 +136,12 @@ class MetaWorldGpuVectorEnv:
                                                   tolerance=None if precision in ("fp64", 1) else 1e-6)
                 model_index[mname] = self.ctx.add_model(pk)
                 roles_of[mname], reloc_of[mname] = roles, reloc
-            goals = T.goal_table(goal_key, name, goal_seed)
+            if benchmark == "custom-mt":          # env idx is built as MT1(name, seed + idx)
+                goals = T.custom_goal_tables((name,), goal_seed + oh)[name]
+            elif benchmark == "custom-ml":        # one `_make_tasks` stream over the class list
+                goals = T.custom_goal_tables(tuple(names), goal_seed)[name]
+            else:
+                goals = T.goal_table(goal_key, name, goal_seed)
             self.goal_tables[name] = goals
             ts = T.task_struct(name, model_index[mname], roles_of[mname], reloc_of[mname], onehot_id=oh,
                                partially_observable=self.partially_observable)
@@ -158,6 +169,8 @@ class MetaWorldGpuVectorEnv:
                     self._goal_lists.append(sub)
         # RandomTaskSelectWrapper / PseudoRandomTaskSelectWrapper: every sub-env is seeded with the SAME seed
         # (metaworld/__init__.py:430-431), so the n-th draw of any env is the n-th value of one PCG64 stream.
+        # (the custom MT entry point seeds env idx with seed + idx, `:761`)
+        self._env_seed = [None if seed is None else (seed + names.index(n) if benchmark == "custom-mt" and seed else seed) for n in env_task_names]
         self.task_select = task_select
         self._stream, self._shuffles = {}, {}
         self._reset_count = np.zeros(self.num_envs, dtype=np.int64)    # random: draws made; pseudorandom: shuffles made
@@ -197,22 +210,22 @@ class MetaWorldGpuVectorEnv:
         assert D == len(lo) - (6 if self.recurrent_info_in_obs else 0)
 
     # ---- RandomTaskSelectWrapper stream (wrappers.py:98-100: self.np_random.choice(len(tasks))) ----
-    def _draw(self, n_goals, k):
+    def _draw(self, n_goals, k, seed):
         """k-th draw of Generator(PCG64(seed)).choice(n_goals): every sub-env owns an identically seeded
-        generator and only ever calls choice(len(tasks)), so one cached stream per distinct n serves all."""
-        if n_goals not in self._stream:
-            self._stream[n_goals] = (np.random.Generator(np.random.PCG64(np.random.SeedSequence(self.seed_value))), [])
-        gen, s = self._stream[n_goals]
+        generator and only ever calls choice(len(tasks)), so one cached stream per distinct (n, seed) serves all."""
+        if (n_goals, seed) not in self._stream:
+            self._stream[n_goals, seed] = (np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed))), [])
+        gen, s = self._stream[n_goals, seed]
         while len(s) <= k:
             s.append(int(gen.choice(n_goals)))
         return s[k]
 
-    def _shuffle_perm(self, n, k):
+    def _shuffle_perm(self, n, k, seed):
         """Index permutation of the k-th `np_random.shuffle(tasks)` of an n-task list (wrappers.py:158-161): Generator.shuffle
         draws do not depend on the list's contents, so one cached stream per distinct n serves all identically seeded sub-envs."""
-        if n not in self._shuffles:
-            self._shuffles[n] = (np.random.Generator(np.random.PCG64(np.random.SeedSequence(self.seed_value))), [])
-        gen, s = self._shuffles[n]
+        if (n, seed) not in self._shuffles:
+            self._shuffles[n, seed] = (np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed))), [])
+        gen, s = self._shuffles[n, seed]
         while len(s) <= k:
             order = list(range(n))
             gen.shuffle(order)          # a Python list, as in the reference (list[Task])
@@ -224,13 +237,13 @@ class MetaWorldGpuVectorEnv:
         :157-162); with commit=False nothing advances (used to tell the kernel which goal a SAME_STEP auto-reset takes)."""
         lst = self._goal_lists[e]
         if self.task_select == "random":
-            g = lst[self._draw(len(lst), int(self._reset_count[e]))]
+            g = lst[self._draw(len(lst), int(self._reset_count[e]), self._env_seed[e])]
             if commit:
                 self._reset_count[e] += 1
             return int(g)
         idx = (int(self._task_idx[e]) + 1) % len(lst)
         if idx == 0:
-            lst = lst[self._shuffle_perm(len(lst), int(self._reset_count[e]))]
+            lst = lst[self._shuffle_perm(len(lst), int(self._reset_count[e]), self._env_seed[e])]
         if commit:
             if idx == 0:
                 self._goal_lists[e] = lst

@@ -151,3 +151,45 @@ def test_normalizers_and_checkpoint(hostsim):
     var = (1.0 * cnt + r_r ** 2 * cnt / (cnt + 1)) / (cnt + 1)
     assert np.allclose(r_n, r_r / np.sqrt(var + 1e-8), rtol=1e-12)
     env.close(); raw.close()
+
+
+@needs_ref
+def test_custom_benchmarks_match_reference(hostsim):
+    """"Meta-World/custom-mt-envs" (env idx = MT1(name, seed + idx), its own stream) and CustomML (one stream over the list)"""
+    warnings.filterwarnings("ignore")
+    from oracle import refshim
+    refshim.install()
+    import gymnasium as gym
+    import metaworld
+    import pickle
+    from functools import partial
+    lst, seed = ["drawer-close-v3", "reach-v3", "window-open-v3"], 11
+    ref = gym.vector.SyncVectorEnv([partial(metaworld.make_mt_envs, n, num_tasks=3, env_id=i, seed=seed + i, use_one_hot=True, max_episode_steps=3)
+                                    for i, n in enumerate(lst)], autoreset_mode="SameStep")          # metaworld/__init__.py:752-767
+    mine = mk.make_custom_mt_envs(lst, seed=seed, use_one_hot=True, max_episode_steps=3, precision="fp64", lib=hostsim)
+    assert mine.single_observation_space.shape == ref.single_observation_space.shape == (42,)
+    for a, b in zip(ref.get_attr("tasks"), mine.get_attr("tasks")):
+        rv = [pickle.loads(t.data)["rand_vec"] for t in a]
+        assert all(np.array_equal(v, w[:len(v)]) for v, w in zip(rv, b))
+    o1, _ = ref.reset(); o2, _ = mine.reset()
+    _cmp_obs(o1, o2)
+    rng = np.random.default_rng(2)
+    for t in range(10):
+        a = rng.uniform(-1, 1, (3, 4)).astype(np.float32)
+        o1, r1, te1, tr1, i1 = ref.step(a); o2, r2, te2, tr2, i2 = mine.step(a)
+        assert np.array_equal(tr1, tr2)
+        for v1, v2 in zip(ref.get_attr("_last_rand_vec"), mine.get_attr("_last_rand_vec")):
+            assert np.array_equal(v1, v2[:len(v1)])          # per-env streams (seed + idx) drive the redraws
+        _cmp_obs(o1, o2)
+    ref.close(); mine.close()
+
+    bench = metaworld.CustomML(["reach-v3", "drawer-close-v3"], ["window-open-v3"], seed=seed)
+    mine = mk.make_custom_ml_envs(["reach-v3", "drawer-close-v3"], ["window-open-v3"], seed=seed, meta_batch_size=4, lib=hostsim)
+    got = mine.get_attr("tasks")
+    for k, name in enumerate(["reach-v3", "reach-v3", "drawer-close-v3", "drawer-close-v3"]):
+        rv = [pickle.loads(t.data)["rand_vec"] for t in bench.train_tasks if t.env_name == name][k % 2::2]
+        assert all(np.array_equal(v, w[:len(v)]) for v, w in zip(rv, got[k])) and len(rv) == len(got[k]) == 25
+    assert mine.partially_observable
+    mine.close()
+    with pytest.raises(ValueError):
+        mk.make_custom_ml_envs(["reach-v3"], ["reach-v3"], lib=hostsim)
