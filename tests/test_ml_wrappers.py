@@ -193,3 +193,43 @@ def test_custom_benchmarks_match_reference(hostsim):
     mine.close()
     with pytest.raises(ValueError):
         mk.make_custom_ml_envs(["reach-v3"], ["reach-v3"], lib=hostsim)
+
+
+def _task_names(envs):
+    from metaworld_amd import tasks as T
+    cls_to_name = {T.TASK_CONST[n]["cls"]: n for n in T.ALL_V3}
+    return [cls_to_name[c] for c in envs.get_attr("task_name")]          # metaworld/evaluation.py:38-45
+
+
+@pytest.mark.parametrize("env_name", ["reach-v3", "button-press-v3", "stick-pull-v3"])
+@pytest.mark.parametrize("split", ("train", "test"))
+def test_ml1(hostsim, env_name, split):
+    """mirror of the reference's tests/metaworld/test_gym_make.py:126-155 (`test_ml1`)"""
+    gen = mk.make_ml_envs_train if split == "train" else mk.make_ml_envs_test
+    envs = gen(env_name, meta_batch_size=10, max_episode_steps=10, lib=hostsim)
+    assert envs.num_envs == 10
+    assert all(t == env_name for t in _task_names(envs))
+    assert sum(len(t) for t in envs.get_attr("tasks")) == 50
+    assert all(envs.get_attr("_partially_observable"))
+    envs.close()
+
+
+@pytest.mark.parametrize("benchmark", ("ML10", "ML45"))
+@pytest.mark.parametrize("split", ("train", "test"))
+def test_ml_benchmarks(hostsim, benchmark, split):
+    """mirror of the reference's tests/metaworld/test_gym_make.py:158-211 (`test_ml_benchmarks`)"""
+    from metaworld_amd import tasks as T
+    meta_batch_size = 20 if benchmark != "ML45" else 45
+    total_tasks_per_cls = 45 if benchmark == "ML45" else (40 if split == "test" else 50)
+    gen = mk.make_ml_envs_train if split == "train" else mk.make_ml_envs_test
+    envs = gen(benchmark, meta_batch_size=meta_batch_size, max_episode_steps=10, total_tasks_per_cls=total_tasks_per_cls, lib=hostsim)
+    assert envs.num_envs == meta_batch_size
+    names = _task_names(envs)
+    expected = T.benchmark_task_names(f"{benchmark}-{split}")
+    assert set(names) == set(expected)
+    per = {t: 0 for t in expected}
+    for tasks, n in zip(envs.get_attr("tasks"), names):
+        per[n] += len(tasks)
+    assert all(v == total_tasks_per_cls for v in per.values())
+    assert all(envs.get_attr("_partially_observable"))
+    envs.close()
