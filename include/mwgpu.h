@@ -119,6 +119,12 @@ int mw_policy_actions(mw_ctx* c, const int32_t* policy_id /*[N]*/, const double*
 int mw_policy_rollout(mw_ctx* c, const int32_t* policy_id /*[N]*/, const int32_t* goal_schedule /*[K][N]*/, int K, int nsteps,
                       int32_t* episodes /*[N] out or NULL*/, int32_t* successes /*[N] out or NULL*/, float* kernel_ms /*or NULL*/);
 
+/* ---- calibration of the lanes-per-workgroup choice (no reference counterpart): ticks == NULL (re)starts accumulating, per
+ *      workgroup, the wall-clock ticks (100 MHz) its mw_step_resident launches take; otherwise copies them out together with
+ *      the model index of each workgroup's group.  Returns the number of workgroups, < 0 on error.  The model option
+ *      "lanes_per_block" (mw_model_set_option) is the knob this calibrates (tools/calibrate_lpb.py). ---- */
+int mw_wave_profile(mw_ctx* c, int64_t* ticks /*[capacity] or NULL*/, int32_t* model_of_block /*[capacity] or NULL*/, int capacity);
+
 /* ---- state access for parity tests (mujoco data.qpos / qvel / mocap_pos, MujocoEnv.set_state) ---- */
 int mw_column_size(mw_ctx* c, int env, const char* what);
 int mw_read(mw_ctx* c, int env, const char* what, double* out, int n);

@@ -27,6 +27,7 @@ int MW_API(model_set_option)(mw_model* m, const char* name, double v) {
     std::string k = name;
     if (k == "timestep") m->d.timestep = v; else if (k == "tolerance") m->d.tolerance = v;
     else if (k == "reset_tolerance") m->d.reset_tolerance = v;
+    else if (k == "lanes_per_block") m->d.lanes_per_block = (int)v;
     else if (k == "meaninertia") m->d.meaninertia = v; else if (k == "gravity_z") m->d.gravity[2] = v;
     else if (k == "iterations") m->d.sz.iterations = (int)v; else if (k == "ls_iterations") m->d.sz.ls_iterations = (int)v;
     else if (k == "maxcon") m->d.sz.maxcon = (int)v; else if (k == "maxefc") m->d.sz.maxefc = (int)v;
@@ -110,6 +111,9 @@ int MW_API(policy_actions)(mw_ctx* c, const int32_t* policy_id, const double* ob
 }
 int MW_API(policy_rollout)(mw_ctx* c, const int32_t* policy_id, const int32_t* schedule, int K, int nsteps, int32_t* episodes, int32_t* successes, float* ms) {
     MW_TRY(c, { MW_NEED_IMPL(c); if (!policy_id || !schedule) throw std::invalid_argument("policy_rollout: null argument"); c->impl->policy_rollout(policy_id, schedule, K, nsteps, episodes, successes, ms); });
+}
+int MW_API(wave_profile)(mw_ctx* c, int64_t* ticks, int32_t* model_of_block, int capacity) {
+    try { MW_NEED_IMPL(c); return c->impl->wave_profile((long long*)ticks, model_of_block, capacity); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
 }
 int MW_API(column_size)(mw_ctx* c, int env, const char* what) {
     try { MW_NEED_IMPL(c); return c->impl->layout_size(env, what); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }

@@ -23,10 +23,12 @@
 #define MW_HD __host__ __device__ inline
 #define MW_STAGE_FN __host__ __device__ __attribute__((noinline))   // the big stages: one copy each (code size, compile time)
 #define MW_FP_EXACT _Pragma("clang fp contract(off)")   // first statement of a block: no fused multiply-add (bit-exact restatements)
+#define MW_WALL_CLOCK() ((long long)wall_clock64())      // constant-rate (100 MHz) counter: per-workgroup durations (mw_wave_profile)
 #else
 #define MW_HD inline
 #define MW_STAGE_FN inline
 #define MW_FP_EXACT   // the host harness is built with -ffp-contract=off
+#define MW_WALL_CLOCK() 0LL
 #endif
 
 namespace mw {
@@ -263,7 +265,7 @@ __device__ inline int sub_scan(const Env<T>& e, const int* n, int* off) {
 #else
 #define MW_SUBS(e, sub) for (int sub = 0; sub < (e).nsub; sub++)
 #define MW_SLOT(sub) (sub)
-constexpr int MW_NSLOT = 16;
+constexpr int MW_NSLOT = 64;
 #define MW_SYNC()
 template <typename T>
 inline T sub_sum(const Env<T>& e, const T* p) {

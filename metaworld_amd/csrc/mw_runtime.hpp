@@ -34,6 +34,7 @@ struct ModelData {
     Sizes sz{};
     double timestep = 0.0025, tolerance = 1e-10, meaninertia = 1, gravity[3] = {0, 0, -9.81};
     double reset_tolerance = 0;   // solver tolerance of the (double precision) reset-snapshot build; 0 = same as tolerance
+    int lanes_per_block = 0;      // environments per workgroup for this model's group; 0 = the runtime's own choice (finalize)
     const std::vector<int>& I(const std::string& k) const {
         auto it = ints.find(k);
         if (it == ints.end()) throw std::runtime_error("model is missing int field " + k);
@@ -296,6 +297,7 @@ public:
     virtual void policy_actions(const int* policy_id, const double* obs, float* act) = 0;
     virtual void policy_rollout(const int* policy_id, const int* schedule, int K, int nsteps, int* episodes, int* successes, float* kernel_ms) = 0;
     virtual void upload_actions(const float* act, int nsteps) = 0;
+    virtual int wave_profile(long long* ticks, int* model_of_block, int capacity) = 0;
     virtual void read_col(int gid, const char* what, int n, double* out) = 0;
     virtual void write_col(int gid, const char* what, int n, const double* in) = 0;
     virtual void read_icol(int gid, const char* what, int n, int* out) = 0;
@@ -434,6 +436,12 @@ public:
                 if (best < 0) break;
                 lpb_of[best] /= 2;
                 if (blocks() > budget) { lpb_of[best] *= 2; break; }
+            }
+            for (auto& kv : by_model) {          // the caller's calibrated choice (metaworld_amd/lpb_policy.py) wins over the proxy
+                const int l = models[kv.first]->lanes_per_block;
+                if (l == 0) continue;
+                if (l != 1 && l != 2 && l != 4 && l != 8 && l != 16 && l != 32 && l != 64) throw std::runtime_error("lanes_per_block must be a power of two <= 64");
+                lpb_of[kv.first] = l;
             }
             if (ov) {
                 const int l = atoi(ov);
@@ -688,10 +696,32 @@ public:
         Backend::timed_begin();
         for (int s = 0; s < nsteps; s++) {
             w.io.act = base + (size_t)(act_steps > 0 ? s % act_steps : 0) * 4 * N_;
-            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+            long long* ticks = d_wave_ticks_;
+            Backend::launch(nblocks_, [w, ticks] MW_LAMBDA(int b, int t, Scratchpad sp) {
+                const long long t0 = ticks ? MW_WALL_CLOCK() : 0;
+                lane_step(w, b, t, sp);
+                if (ticks && t == 0) ticks[b] += MW_WALL_CLOCK() - t0;
+            });
         }
         float ms = Backend::timed_end();
         if (kernel_ms) *kernel_ms = ms;
+    }
+
+    // per-workgroup wall-clock ticks of the resident step launches (calibration of the lanes-per-workgroup choice)
+    long long* d_wave_ticks_ = nullptr;
+    int wave_profile(long long* ticks, int* model_of_block, int capacity) override {
+        if (!ticks) {
+            if (!d_wave_ticks_) d_wave_ticks_ = (long long*)Backend::alloc(sizeof(long long) * nblocks_);
+            Backend::zero(d_wave_ticks_, sizeof(long long) * nblocks_);
+            Backend::sync();
+            return nblocks_;
+        }
+        if (!d_wave_ticks_) throw std::runtime_error("wave_profile: not started");
+        if (capacity < nblocks_) throw std::invalid_argument("wave_profile: buffer too small");
+        Backend::d2h(ticks, d_wave_ticks_, sizeof(long long) * nblocks_);
+        if (model_of_block)
+            for (auto& g : groups_) { const int nb = (g.nenv + g.lpb - 1) / g.lpb; for (int b = 0; b < nb; b++) model_of_block[g.block0 + b] = g.model; }
+        return nblocks_;
     }
 
     void debug(int what, int n) override {

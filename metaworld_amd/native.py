@@ -75,6 +75,7 @@ class Lib:
         f("reset_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
         f("policy_actions", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
         f("policy_rollout", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float))
+        f("wave_profile", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
         f("column_size", C.c_int, C.c_void_p, C.c_int, C.c_char_p)
         f("read", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
         f("write", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
@@ -101,7 +102,7 @@ def load(prefix="mw_", path=None) -> Lib:
 
 EXPORTED_SYMBOLS = ["model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
                     "add_model", "add_task", "set_envs", "finalize", "set_terminate_on_success", "destroy", "last_error", "num_envs", "obs_dim",
-                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "upload_actions", "step_resident", "column_size", "read", "write", "read_int",
+                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "wave_profile", "upload_actions", "step_resident", "column_size", "read", "write", "read_int",
                     "debug"]
 
 
@@ -205,6 +206,16 @@ class Context:
         self._check(self.lib.policy_rollout(self.ptr, pid.ctypes.data, sch.ctypes.data, sch.shape[0], int(nsteps),
                                             ep.ctypes.data, su.ctypes.data, C.byref(ms)))
         return ep, su, ms.value
+
+    def wave_profile_start(self):
+        """mw_wave_profile(NULL): zero the per-workgroup tick counters -> number of workgroups"""
+        return self._check(self.lib.wave_profile(self.ptr, None, None, 0))
+
+    def wave_profile_read(self, nblocks):
+        """-> (ticks int64 [nblocks] at 100 MHz, model index int32 [nblocks])"""
+        ticks, model = np.zeros(nblocks, dtype=np.int64), np.zeros(nblocks, dtype=np.int32)
+        self._check(self.lib.wave_profile(self.ptr, ticks.ctypes.data, model.ctypes.data, nblocks))
+        return ticks, model
 
     def upload_actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32)

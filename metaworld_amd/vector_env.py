@@ -80,7 +80,8 @@ class MetaWorldGpuVectorEnv:
                  rank=0, world_size=1, goal_seed=42, task_names=None, lib=None, maxcon=None, maxefc=None,
                  partially_observable=None, task_select="random", meta_batch_size=None, total_tasks_per_cls=None,
                  recurrent_info_in_obs=False, normalize_reward_in_recurrent_info=True, reward_function_version="v2",
-                 reward_normalization_method=None, reward_alpha=0.001, normalize_observations=False, envs_list=None):
+                 reward_normalization_method=None, reward_alpha=0.001, normalize_observations=False, envs_list=None,
+                 lanes_per_block="auto"):
         """The keyword set of the reference's `_init_each_env` / `make_ml_envs` (metaworld/__init__.py:398-460, :516-618):
         `task_select` "random" = RandomTaskSelectWrapper, "pseudorandom" = PseudoRandomTaskSelectWrapper;
         `meta_batch_size` / `total_tasks_per_cls` = the ML split of each class's goals over sub-envs (`tasks[i::k]`);
@@ -125,6 +126,21 @@ class MetaWorldGpuVectorEnv:
         self.ctx = native.Context(self._lib, precision=1 if precision in ("fp64", 1) else 0, device_id=device_id,
                                   rank=rank, world_size=world_size, max_episode_steps=max_episode_steps or 500,
                                   terminate_on_success=terminate_on_success, one_hot=use_one_hot, num_tasks=ntask)
+        # env -> task (task-major contiguous blocks, like the reference's enumerate order)
+        per, rem = divmod(self.num_envs, ntask)
+        env_task_names = []
+        for i, name in enumerate(names):
+            env_task_names += [name] * (per + (1 if i < rem else 0))
+        self.env_task_names = env_task_names
+        # lanes per workgroup of every model group: "auto" = from the measured wave times (lpb_policy.py), None = the runtime's
+        # proxy, or an explicit {model name: lanes}
+        envs_per_model = {}
+        for n in env_task_names:
+            envs_per_model[T.TASK_CONST[n]["model"]] = envs_per_model.get(T.TASK_CONST[n]["model"], 0) + 1
+        if lanes_per_block == "auto":
+            from . import lpb_policy
+            lanes_per_block = lpb_policy.choose(envs_per_model, "fp64" if precision in ("fp64", 1) else "fp32")
+        self.lanes_per_block = dict(lanes_per_block or {})
         # models and tasks
         model_index, roles_of, reloc_of = {}, {}, {}
         self._task_index = {}
@@ -134,6 +150,8 @@ class MetaWorldGpuVectorEnv:
             if mname not in model_index:
                 pk, roles, reloc = T.packed_model(mname, maxcon=maxcon, maxefc=maxefc,
                                                   tolerance=None if precision in ("fp64", 1) else 1e-6)
+                if mname in self.lanes_per_block:
+                    pk["options"]["lanes_per_block"] = self.lanes_per_block[mname]
                 model_index[mname] = self.ctx.add_model(pk)
                 roles_of[mname], reloc_of[mname] = roles, reloc
             if benchmark == "custom-mt":          # env idx is built as MT1(name, seed + idx)
@@ -146,12 +164,7 @@ class MetaWorldGpuVectorEnv:
             ts = T.task_struct(name, model_index[mname], roles_of[mname], reloc_of[mname], onehot_id=oh,
                                partially_observable=self.partially_observable)
             self._task_index[name] = self.ctx.add_task(ts, goals)
-        # env -> task (task-major contiguous blocks, like the reference's enumerate order)
-        per, rem = divmod(self.num_envs, ntask)
-        env_task_names = []
-        for i, name in enumerate(names):
-            env_task_names += [name] * (per + (1 if i < rem else 0))
-        self.env_task_names = env_task_names
+        self.model_index = model_index
         self.ctx.set_envs([self._task_index[n] for n in env_task_names])
         self.ctx.finalize()
         # the goals each sub-env may be set to (indices into its task's table).  ML: the sub-envs of one class share its goals

@@ -24,7 +24,7 @@ struct Backend {
     // scratchpad rows per lane: MW_LDS_ROWS (default 24, so that typical scenes exercise both the scratchpad rows
     // and the column-store fallback rows of the solver)
     static int lds_rows() { const char* v = std::getenv("MW_LDS_ROWS"); return v ? std::atoi(v) : 24; }
-    // emulated sub-lanes per environment (MW_NSUB = 1, 2, 4 or 8; default 8 = the small-batch device configuration)
+    // emulated sub-lanes per environment (MW_NSUB = a power of two up to 64; default 8 = the small-batch device configuration)
     static int nsub() { const char* v = std::getenv("MW_NSUB"); return v ? std::atoi(v) : 8; }
     template <class F>
     static void launch(int nblocks, F f) {   // one call per environment (locate() rejects threads >= lanes per workgroup): the sub-lanes are emulated inside (MW_SUBS)

@@ -82,7 +82,7 @@ def test_sub_lane_and_scratchpad_invariance(hostsim, task, monkeypatch):
     from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
     acts = np.random.default_rng(0).uniform(-1, 1, (25, 4, 4)).astype(np.float32)
     runs = {}
-    for nsub, rows in (("1", "0"), ("1", "300"), ("4", "24"), ("8", "24"), ("8", "300")):
+    for nsub, rows in (("1", "0"), ("1", "300"), ("4", "24"), ("8", "24"), ("8", "300"), ("32", "24"), ("64", "24")):
         monkeypatch.setenv("MW_NSUB", nsub); monkeypatch.setenv("MW_LDS_ROWS", rows)
         env = MetaWorldGpuVectorEnv("MT1", task, num_envs=4, seed=3, precision="fp64", lib=hostsim)
         env.reset()
@@ -96,7 +96,7 @@ def test_sub_lane_and_scratchpad_invariance(hostsim, task, monkeypatch):
     ref = runs[("1", "0")]
     assert np.abs(runs[("1", "300")][0] - ref[0]).max() == 0          # the scratchpad is storage only
     assert np.abs(runs[("8", "300")][0] - runs[("8", "24")][0]).max() == 0
-    for k in (("4", "24"), ("8", "24")):
+    for k in (("4", "24"), ("8", "24"), ("32", "24"), ("64", "24")):          # 32 / 64 sub-lanes = 2 / 1 environments per wave
         assert (runs[k][1] == ref[1]).all()
         assert np.abs(runs[k][0] - ref[0]).max() < 1e-6     # resting multi-contact bodies amplify the summation-order noise
 

@@ -3,7 +3,8 @@
 `episodes` whole 500-step episodes of its task, one goal per episode (env j of a task starts at goal j and walks the table),
 policy kernel + step kernel back to back with no host round trip; success = `info["success"]` ever 1 within the episode, the
 reference's gate is 0.8 per task (tests/metaworld/test_scripted_policies.py:35).
-usage: tools/policy_eval_device.py [num_envs] [episodes] [precision] [benchmark]"""
+usage: tools/policy_eval_device.py [num_envs] [episodes] [precision] [benchmark] [lockstep]
+(lockstep = 1: every env of a task gets the same goal, like the reference's identically seeded task-selection streams do)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +20,8 @@ env = MetaWorldGpuVectorEnv(bench, num_envs=n, seed=42, precision=prec, partiall
 names = np.array(env.env_task_names)
 pid = np.array([T.ALL_V3.index(t) for t in names], dtype=np.int32)
 rank_in_task = np.concatenate([np.arange((names == t).sum()) for t in env.task_list])          # envs are task-major contiguous
-sched = (rank_in_task[None, :] + np.arange(episodes + 1)[:, None]) % 50
+lockstep = len(sys.argv) > 5 and sys.argv[5] == "1"
+sched = ((0 if lockstep else rank_in_task[None, :]) + np.arange(episodes + 1)[:, None] + np.zeros((1, n), dtype=int)) % 50
 t0 = time.perf_counter()
 ep, su, ms = env.ctx.policy_rollout(pid, sched, 500 * episodes)
 dt = time.perf_counter() - t0
