@@ -23,31 +23,37 @@ ALGO_BYTES_PER_ENV_STEP = {"fp32": 900.0, "fp64": 1600.0}   # ac
 HBM_PEAK_GBPS = 8000.0                                        # MI355X_MICROARCH.md
 
 
-def cpu_baseline(workload_task, seconds=15.0):
-    """The CPU oracle (fp64 C restatement, 1 thread) stepping the same kind of env: 5 substeps + forward per env-step.
-    Physics only (the reference's Python obs/reward layer is not part of the port): an upper bound on the port's speed."""
+def cpu_baseline(task_names, seconds=15.0):
+    """The CPU oracle (fp64 C restatement, 1 thread) stepping the same workload: every task of the benchmark gets an equal
+    share of the env-steps (as in the vector env), random actions, 5 substeps + forward per env-step.  Physics only (the
+    reference's Python obs/reward layer is not part of the port): an upper bound on the port's speed."""
     from metaworld_amd import tasks as T
     from oracle.mjlite import OracleData, OracleModel
-    om = OracleModel(T.compiled_model(T.TASK_CONST[workload_task]["model"]))
-    om.view("eq_data")[:] = [0, 0, 0, 0, 0, 0, -1, 0, 0, 0, 5.0]
-    d = OracleData(om)
     rng = np.random.default_rng(0)
-    hi = np.array(T.TASK_CONST[workload_task]["hand_init_pos"])
-    d.mocap_pos[:] = hi; d.mocap_quat[:] = [1, 0, 1, 0]; d.ctrl[:] = [-1, 1]
-    d.step(250)
-    lo_, hi_ = np.array(T.TASK_CONST[workload_task]["mocap_low"]), np.array(T.TASK_CONST[workload_task]["mocap_high"])
+    sims = []
+    for task in task_names:
+        c = T.TASK_CONST[task]
+        om = OracleModel(T.compiled_model(c["model"]))
+        om.view("eq_data")[:] = [0, 0, 0, 0, 0, 0, -1, 0, 0, 0, 5.0]
+        d = OracleData(om)
+        d.mocap_pos[:] = np.array(c["hand_init_pos"]); d.mocap_quat[:] = [1, 0, 1, 0]; d.ctrl[:] = [-1, 1]
+        d.step(100)
+        sims.append((om, d, np.array(c["mocap_low"]), np.array(c["mocap_high"])))
+    chunk = 10
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        for _ in range(50):
-            a = rng.uniform(-1, 1, 4)
-            d.mocap_pos[:] = np.clip(d.mocap_pos + 0.01 * a[:3], lo_, hi_)
-            d.ctrl[:] = [a[3], -a[3]]
-            d.step(5)
-            d.forward()
-            n += 1
+        for om, d, lo_, hi_ in sims:          # one round = `chunk` env-steps of every task
+            for _ in range(chunk):
+                a = rng.uniform(-1, 1, 4)
+                d.mocap_pos[:] = np.clip(d.mocap_pos + 0.01 * a[:3], lo_, hi_)
+                d.ctrl[:] = [a[3], -a[3]]
+                d.step(5)
+                d.forward()
+                n += 1
     dt = time.perf_counter() - t0
+    what = task_names[0] if len(task_names) == 1 else f"{len(task_names)} tasks in equal shares"
     return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} env-steps of {workload_task} (random actions, 5 substeps + forward each, physics only) in {dt:.1f}s on 1 host thread"}
+            "sample": f"{n} env-steps of {what} (random actions, 5 substeps + forward each, physics only) in {dt:.1f}s on 1 host thread"}
 
 
 def main():
@@ -81,11 +87,11 @@ def main():
     if bench == "MT1":
         env = MetaWorldGpuVectorEnv("MT1", "reach-v3", num_envs=args.envs, seed=42 + rank, precision=args.precision,
                                     device_id=local_rank, rank=rank, world_size=world)
-        workload, wl_task = f"MT1 reach-v3, {args.envs} batched envs/GPU, {args.precision}, random actions", "reach-v3"
+        workload, wl_task = f"MT1 reach-v3, {args.envs} batched envs/GPU, {args.precision}, random actions", ["reach-v3"]
     else:
         env = MetaWorldGpuVectorEnv(bench, num_envs=args.envs, seed=42 + rank, use_one_hot=True, precision=args.precision,
                                     device_id=local_rank, rank=rank, world_size=world)
-        workload, wl_task = f"{bench} sync-vector, {args.envs} envs/GPU, {args.precision}, random actions", "reach-v3"
+        workload, wl_task = f"{bench} sync-vector, {args.envs} envs/GPU, {args.precision}, random actions", list(env.task_list)
     N = env.num_envs
     env.reset()
     T_act = 64
