@@ -29,3 +29,11 @@ def test_product_path_fails_loudly_without_gpu_or_library(tmp_path):
         lib = native.load()
         with pytest.raises(RuntimeError):
             native.Context(lib)     # hipGetDeviceCount == 0 -> error, never a CPU fallback
+
+
+def test_bench_cpu_baseline_leg_runs_on_the_oracle():
+    """bench.py's `cpu_baseline` (the oracle engine timed on a bounded sample of the task mix) works without a GPU"""
+    import bench
+    r = bench.cpu_baseline(["reach-v3", "box-close-v3"], seconds=0.5)
+    assert r["kind"] == "port" and r["cores"] == 1 and r["unit"] == "env-steps/s" and 1e2 < r["value"] < 1e6
+    assert "2 tasks in equal shares" in r["sample"]
