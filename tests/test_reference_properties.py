@@ -85,3 +85,30 @@ def test_observations_match(hostsim):
 def test_observations_match_gpu(gpulib):
     """all 50 tasks, two lanes each: identical inputs in different lanes / waves give bit-identical trajectories"""
     _observations_match(gpulib, 150)
+
+
+def test_target_positions_unique_and_benchmarks_identical(hostsim):
+    """tests/integration/test_new_api.py: `check_target_poss_unique` (:249-275: the 50 rand_vecs of a task give 50 distinct
+    goals, except the four envs that only randomise the object), `test_identical_environments` (:278-330: equal seeds give
+    equal tasks, the ML1 test split differs from its train split) and the goal visibility asserted in `test_all_mt50` /
+    `test_all_ml45` (:146, :212)."""
+    from metaworld_amd import tasks as T
+    env = MetaWorldGpuVectorEnv("MT50", seed=42, precision="fp64", lib=hostsim)
+    goals = np.stack([env.ctx.reset(np.full(50, g, dtype=np.int32))[:, 36:39].copy() for g in range(50)], axis=1)          # [task, goal, 3]
+    env.close()
+    assert np.any(goals != 0, axis=(1, 2)).all()                                              # MT: goal visible
+    fixed_goal = {"hammer-v3", "sweep-into-v3", "bin-picking-v3", "basketball-v3"}
+    for k, name in enumerate(T.ALL_V3):
+        if name not in fixed_goal:
+            assert len(np.unique(goals[k], axis=0)) == 50, name
+    for bench, name in (("MT1", "sweep-into-v3"), ("ML1-train", "sweep-into-v3"), ("MT10", "reach-v3"), ("ML10-train", "reach-v3")):
+        T._goal_cache.clear()
+        a = T.goal_table(bench, name, 10).copy()
+        T._goal_cache.clear()
+        assert np.array_equal(a, T.goal_table(bench, name, 10))
+        assert not np.array_equal(a, T.goal_table(bench, name, 11))
+    assert not np.array_equal(T.goal_table("ML1-train", "sweep-into-v3", 10), T.goal_table("ML1-test", "sweep-into-v3", 10))
+    ml = MetaWorldGpuVectorEnv("ML10-test", seed=42, precision="fp64", lib=hostsim)
+    o, _ = ml.reset()
+    assert np.all(o[:, -3:] == 0)                                                             # ML: goal hidden
+    ml.close()
