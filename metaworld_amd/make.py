@@ -55,6 +55,27 @@ def make_ml_envs(name, seed=None, meta_batch_size=20, total_tasks_per_cls=None, 
     raise ValueError("Invalid ML env name. Must either be a valid Metaworld task name (e.g. 'reach-v3'), 'ML10', 'ML25', or 'ML45'.")
 
 
+def make_goal_observable(env_name, seed=None, num_envs=1, **kwargs):
+    """The single-goal classes `ALL_V3_ENVIRONMENTS_GOAL_OBSERVABLE[name](seed)` ("Meta-World/goal_observable",
+    metaworld/env_dict.py:171-212, metaworld/__init__.py:683-693): seed the legacy RNG, build the env, reset once, freeze -- the
+    very draws that make goal 0 of MT1(name, seed), so this is the MT1 env restricted to that goal, goal visible."""
+    name = env_name[:-len("-goal-observable")] if env_name.endswith("-goal-observable") else env_name
+    if name not in T.ALL_V3:
+        raise KeyError(env_name)
+    return MetaWorldGpuVectorEnv("MT1", name, num_envs=num_envs, seed=seed, goal_seed=42 if seed is None else seed,
+                                 total_tasks_per_cls=1, partially_observable=False, **kwargs)
+
+
+def make_goal_hidden(env_name, seed=None, num_envs=1, **kwargs):
+    """`ALL_V3_ENVIRONMENTS_GOAL_HIDDEN[name](seed)` ("Meta-World/goal_hidden", metaworld/__init__.py:671-681): the same single
+    goal with the goal slots of the observation zeroed."""
+    name = env_name[:-len("-goal-hidden")] if env_name.endswith("-goal-hidden") else env_name
+    if name not in T.ALL_V3:
+        raise KeyError(env_name)
+    return MetaWorldGpuVectorEnv("MT1", name, num_envs=num_envs, seed=seed, goal_seed=42 if seed is None else seed,
+                                 total_tasks_per_cls=1, partially_observable=True, **kwargs)
+
+
 def make_custom_mt_envs(envs_list, seed=None, use_one_hot=False, vector_strategy="sync", autoreset_mode="SameStep", num_envs=None, **kwargs):
     """The "Meta-World/custom-mt-envs" entry point (metaworld/__init__.py:741-781): env idx is `make_mt_envs(envs_list[idx],
     seed=seed + idx, env_id=idx, num_tasks=len(envs_list))`, i.e. MT1 goal tables and a task-selection stream per class."""
@@ -104,6 +125,8 @@ def register_mw_envs(namespace="Meta-World-GPU"):
         register(id=f"{namespace}/ML1-{split}", vector_entry_point=partial(ml, "ML1", split), kwargs={})
         for b in _ML:
             register(id=f"{namespace}/{b}-{split}", vector_entry_point=partial(ml, b, split), kwargs={})
+    register(id=f"{namespace}/goal_observable", vector_entry_point=lambda env_name, seed=None, **kw: make_goal_observable(env_name, seed, **kw), kwargs={})
+    register(id=f"{namespace}/goal_hidden", vector_entry_point=lambda env_name, seed=None, **kw: make_goal_hidden(env_name, seed, **kw), kwargs={})
     register(id=f"{namespace}/custom-mt-envs", kwargs={},
              vector_entry_point=lambda envs_list, vector_strategy="sync", **kw: make_custom_mt_envs(envs_list, **kw))
     register(id=f"{namespace}/custom-ml-envs", kwargs={},

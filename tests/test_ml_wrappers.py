@@ -233,3 +233,38 @@ def test_ml_benchmarks(hostsim, benchmark, split):
     assert all(v == total_tasks_per_cls for v in per.values())
     assert all(envs.get_attr("_partially_observable"))
     envs.close()
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ["door-open-v3", "pick-place-v3", "hammer-v3"])
+def test_single_goal_envs_match_reference(hostsim, name):
+    """tests/integration/test_single_goal_envs.py: `<name>-goal-observable` / `-goal-hidden` (seed) hold one frozen goal --
+    the same draws as goal 0 of MT1(name, seed) -- shown or hidden in the observation; equal seeds give equal envs."""
+    warnings.filterwarnings("ignore")
+    from oracle import refshim
+    refshim.install()
+    from metaworld.env_dict import ALL_V3_ENVIRONMENTS_GOAL_HIDDEN, ALL_V3_ENVIRONMENTS_GOAL_OBSERVABLE
+    for seed in (5, 10):
+        ref = ALL_V3_ENVIRONMENTS_GOAL_OBSERVABLE[name + "-goal-observable"](seed=seed)
+        mine = mk.make_goal_observable(name + "-goal-observable", seed=seed, num_envs=2, precision="fp64", lib=hostsim)
+        o_ref, _ = ref.reset()
+        o, _ = mine.reset()
+        rv = mine.get_attr("_last_rand_vec")[0]
+        assert np.array_equal(ref._last_rand_vec, rv[:len(ref._last_rand_vec)])
+        _cmp_obs(o_ref, o[0]); assert np.array_equal(o[0], o[1])
+        a = np.random.default_rng(seed).uniform(-1, 1, (3, 4)).astype(np.float32)
+        for t in range(3):
+            o_ref, r_ref, *_ = ref.step(a[t])
+            o, r, *_ = mine.step(np.stack([a[t], a[t]]))
+            _cmp_obs(o_ref, o[0]); assert abs(r_ref - r[0]) < 1e-6
+        o2, _ = mine.reset()
+        assert np.array_equal(mine.get_attr("_last_rand_vec")[0], rv)          # one goal, frozen
+        hid_ref = ALL_V3_ENVIRONMENTS_GOAL_HIDDEN[name + "-goal-hidden"](seed=seed)
+        hid = mk.make_goal_hidden(name, seed=seed, precision="fp64", lib=hostsim)
+        oh_ref, _ = hid_ref.reset(); oh, _ = hid.reset()
+        assert np.all(oh[0, -3:] == 0) and np.all(oh_ref[-3:] == 0)
+        _cmp_obs(oh_ref, oh[0])
+        assert np.array_equal(hid.get_attr("_last_rand_vec")[0], rv)
+        mine.close(); hid.close()
+    with pytest.raises(KeyError):
+        mk.make_goal_observable("no-such-v3", lib=hostsim)
