@@ -70,8 +70,10 @@ struct Backend {
     static int lds_bytes(int nblocks) {
         static const char* ov = getenv("MW_LDS_BYTES");
         if (ov) return atoi(ov);
+        static const char* wv = getenv("MW_WAVES_PER_CU");   // experiments: 8 = let two waves share a SIMD (256 VGPRs each)
+        const int max_per_cu = wv ? atoi(wv) : 4;
         int per_cu = (nblocks + num_cu() - 1) / num_cu();
-        per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+        per_cu = per_cu < 1 ? 1 : (per_cu > max_per_cu ? max_per_cu : per_cu);
         return (max_lds() / per_cu) & ~1023;
     }
     template <class F>
