@@ -9,9 +9,16 @@ from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
 HAND_LOW, HAND_HIGH = np.array([-0.525, 0.348, -0.0525]), np.array([0.525, 1.025, 0.7])          # sawyer_xyz_env.py:146-150
 
 
-def test_reset_returns_same_obj_and_goal(hostsim):
+@pytest.fixture(scope="module")
+def mt50(hostsim):
+    env = MetaWorldGpuVectorEnv("MT50", seed=42, precision="fp64", lib=hostsim)          # one build of the 2500 reset snapshots
+    yield env
+    env.close()
+
+
+def test_reset_returns_same_obj_and_goal(mt50):
     """test_sawyer_xyz_env.py:8-47: resetting an env twice on the same task gives the same object pose and goal"""
-    env = MetaWorldGpuVectorEnv("MT50", seed=42, precision="fp64", lib=hostsim)
+    env = mt50
     env.call("toggle_sample_tasks_on_reset", False)
     with pytest.raises(AssertionError):
         env.reset()                               # no task yet (sawyer_xyz_env.py:699-701)
@@ -26,7 +33,7 @@ def test_reset_returns_same_obj_and_goal(hostsim):
     bb = np.array([n == "basketball-v3" for n in env.env_task_names])
     assert np.array_equal(o1[~bb, -3:], o2[~bb, -3:]) and np.array_equal(o1[~bb], o3[~bb])          # also after the env has moved
     assert np.allclose(o3[bb, -3:] - o2[bb, -3:], o2[bb, -3:] - o1[bb, -3:], atol=1e-12) and not np.allclose(o1[bb, -3:], o2[bb, -3:])
-    env.close()
+    env.call("toggle_sample_tasks_on_reset", True)
 
 
 def _reach_limit(lib, n=100):
@@ -87,15 +94,14 @@ def test_observations_match_gpu(gpulib):
     _observations_match(gpulib, 150)
 
 
-def test_target_positions_unique_and_benchmarks_identical(hostsim):
+def test_target_positions_unique_and_benchmarks_identical(hostsim, mt50):
     """tests/integration/test_new_api.py: `check_target_poss_unique` (:249-275: the 50 rand_vecs of a task give 50 distinct
     goals, except the four envs that only randomise the object), `test_identical_environments` (:278-330: equal seeds give
     equal tasks, the ML1 test split differs from its train split) and the goal visibility asserted in `test_all_mt50` /
     `test_all_ml45` (:146, :212)."""
     from metaworld_amd import tasks as T
-    env = MetaWorldGpuVectorEnv("MT50", seed=42, precision="fp64", lib=hostsim)
+    env = mt50
     goals = np.stack([env.ctx.reset(np.full(50, g, dtype=np.int32))[:, 36:39].copy() for g in range(50)], axis=1)          # [task, goal, 3]
-    env.close()
     assert np.any(goals != 0, axis=(1, 2)).all()                                              # MT: goal visible
     fixed_goal = {"hammer-v3", "sweep-into-v3", "bin-picking-v3", "basketball-v3"}
     for k, name in enumerate(T.ALL_V3):
