@@ -3,14 +3,29 @@
 
 One "step" = one VectorEnv.step over the rank's env batch (mocap update + 5 physics substeps + forward +
 obs/reward + wrappers + SAME_STEP auto-reset), actions resident in HBM, outputs left in HBM.
-`python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under torch.distributed.run
-(one process per GPU, weak scaling: --envs per GPU).  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1 needs one process per GPU: when the script is not already running under
+torch.distributed.run (no WORLD_SIZE in the environment) it re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`; when it is, WORLD_SIZE must equal N.
+Weak scaling: --envs per GPU; the ranks own independent env shards (no data-path collective) and exchange only the
+12-byte per-env bookkeeping record, all-gathered over RCCL INSIDE the timed loop (mw_step_resident_gather: the gather of
+step k overlaps the kernel of step k+1 on a side stream).  Rank 0 prints ONE JSON line.
+
+The headline precision is fp64 ("parity mode": the reference computes in float64 and this is the precision whose GPU tests
+assert obs / reward <= 1e-5 against the reference traces); the fp32 throughput mode is reported beside it at N = 1.
+The episode phases of the batch are staggered uniformly over the 500-step horizon (mw_set_episode_phase + an untimed
+500-step pre-roll), so every timed window samples whole episodes -- resets, free motion and late-episode contacts in their
+true proportions -- whatever --steps is.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,17 +34,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = {"fp32": 900.0, "fp64": 1600.0}   # action + state in, state + obs out
-HBM_PEAK_GBPS = 8000.0                                        # MI355X_MICROARCH.md
+# action + persistent state in, state + observation out, per env-step.  fp32: 0.9 KB + the 50-wide one-hot
+# (200 B) = 1.1 KB; fp64: 1.6 KB + the one-hot as float64 (400 B) = 2.0 KB.  Without one-hot (MT1): 0.9 / 1.6 KB.
+ALGO_BYTES_PER_ENV_STEP = {("fp32", True): 1100.0, ("fp64", True): 2000.0, ("fp32", False): 900.0, ("fp64", False): 1600.0}
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md
+N_SIMD, F_CLK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 2 cycles
+HORIZON = 500                   # SawyerXYZEnv.max_path_length (sawyer_xyz_env.py:153) = TimeLimit default
 
 
-def cpu_baseline(task_names, seconds=15.0):
-    """The CPU oracle (fp64 C restatement, 1 thread) stepping the same workload: every task of the benchmark gets an equal
-    share of the env-steps (as in the vector env), random actions, 5 substeps + forward per env-step.  Physics only (the
-    reference's Python obs/reward layer is not part of the port): an upper bound on the port's speed."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _oracle_worker(task_names, seconds, seed):
+    """The CPU oracle (independent fp64 C restatement of the engine) stepping the workload on ONE core: every task of the
+    benchmark an equal share of the env-steps, random actions, 5 substeps + forward per env-step (physics only)."""
     from metaworld_amd import tasks as T
     from oracle.mjlite import OracleData, OracleModel
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     sims = []
     for task in task_names:
         c = T.TASK_CONST[task]
@@ -50,119 +69,261 @@ def cpu_baseline(task_names, seconds=15.0):
                 d.step(5)
                 d.forward()
                 n += 1
+    return n, time.perf_counter() - t0
+
+
+def _full_step_port(task_names, seconds):
+    """The WHOLE step (physics + observation + reward + wrappers, the product's own lane programs compiled for the host,
+    tests/host_harness.cpp, OpenMP over envs) on all host cores: the stand-in for the reference's Python obs / reward layer,
+    which cannot run on the GPU box (no mujoco / gymnasium / metaworld there)."""
+    so = os.path.join(ROOT, "tests", "_build", "libmw_hostsim.so")
+    if not os.path.exists(so):
+        return None
+    from metaworld_amd import native
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    lib = native.load("mwh_", so)
+    n = 4 * (os.cpu_count() or 1)
+    n = max(n, len(task_names))
+    os.environ.setdefault("MW_NSUB", "1")
+    # the task mix as a custom MT benchmark with 2 goals per task (every goal costs one faithful 500-substep reset on the host)
+    env = MetaWorldGpuVectorEnv("custom-mt", envs_list=list(task_names), num_envs=n, seed=1, precision="fp64", lib=lib,
+                                use_one_hot=len(task_names) > 1, total_tasks_per_cls=2)
+    env.reset()
+    rng = np.random.default_rng(0)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        env.ctx.step(rng.uniform(-1, 1, (n, 4)).astype(np.float32))
+        steps += 1
     dt = time.perf_counter() - t0
+    env.close()
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": os.cpu_count() or 1,
+            "sample": f"{n} envs x {steps} full steps (physics + obs + reward + wrappers, host build of the lane programs, OpenMP) in {dt:.1f}s"}
+
+
+def cpu_baseline(task_names, seconds=10.0):
+    """cpu_baseline of the JSON line: the oracle on 1 core and on all cores (one process per core), physics only; plus the
+    full step (with obs / reward) of the host build of the lane programs on all cores.  All three are stand-ins for the
+    reference's own SyncVectorEnv / AsyncVectorEnv, which needs mujoco + gymnasium (absent here and on the GPU box)."""
+    import multiprocessing as mp
+    n1, dt1 = _oracle_worker(task_names, seconds, 0)
+    cores = os.cpu_count() or 1
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.starmap(_oracle_worker, [(task_names, seconds, 1 + r) for r in range(cores)])
+    rate_all = sum(n / dt for n, dt in res)
     what = task_names[0] if len(task_names) == 1 else f"{len(task_names)} tasks in equal shares"
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{n} env-steps of {what} (random actions, 5 substeps + forward each, physics only) in {dt:.1f}s on 1 host thread"}
+    out = {"value": rate_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "single_core_value": n1 / dt1,
+           "sample": f"oracle engine (fp64 C restatement; stand-in, not Farama/MuJoCo): {sum(n for n, _ in res)} env-steps of {what} "
+                     f"(random actions, 5 substeps + forward each, physics only) in {seconds:.0f}s on {cores} processes; "
+                     f"1 process: {n1} env-steps in {dt1:.1f}s"}
+    full = _full_step_port(task_names, min(seconds, 8.0))
+    if full:
+        out["full_step_port"] = full
+    return out
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_command(argv, n):
+    """the torch.distributed.run command line `python bench.py --gpus n ...` re-executes itself under"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000, help="timed steps (default covers two full 500-step episodes incl. the auto-reset waves)")
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=500, help="timed steps (the staggered batch makes any window a whole-episode sample)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--benchmark", default="auto")
-    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--benchmark", default="MT50")
+    ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"], help="headline precision (fp64 = the parity-qualified mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra fp64 (parity precision) measurement at N=1")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra-precision", action="store_true", help="skip the measurement of the other precision at N=1")
+    ap.add_argument("--no-stagger", action="store_true", help="all envs start their episodes together (early-episode window)")
+    ap.add_argument("--allow-status", action="store_true", help="do not abort on capacity overflow / instability flags")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the launcher path (gloo: CPU test of the launcher)")
+    ap.add_argument("--host-harness", action="store_true", help="TEST ONLY: drive the CPU harness instead of the GPU library")
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------------ one measurement
+def build_env(args, precision, rank, world, local_rank, lib=None):
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    if args.benchmark == "MT1":
+        return MetaWorldGpuVectorEnv("MT1", "reach-v3", num_envs=args.envs, seed=42 + rank, precision=precision, device_id=local_rank,
+                                     rank=rank, world_size=world, lib=lib)
+    return MetaWorldGpuVectorEnv(args.benchmark, num_envs=args.envs, seed=42 + rank, use_one_hot=True, precision=precision,
+                                 device_id=local_rank, rank=rank, world_size=world, lib=lib)
+
+
+def prepare(env, args, rank):
+    """reset, stagger the episode phases (untimed pre-roll of one horizon), upload the action stream, warm up"""
+    N = env.num_envs
+    env.reset()
+    acts = np.random.default_rng(rank).uniform(-1, 1, (64, N, 4)).astype(np.float32)
+    env.ctx.upload_actions(acts)
+    if not args.no_stagger:
+        env.ctx.set_episode_phase((np.arange(N, dtype=np.int64) * 7919 % HORIZON).astype(np.int32))
+        env.ctx.step_resident(HORIZON)
+    env.ctx.step_resident(args.warmup)
+    env.ctx.status(clear=True)
+
+
+def check_outputs(env, allow):
+    st = env.ctx.status(clear=True)
+    if st["flags"] and not allow:
+        raise RuntimeError(f"bench: the step kernel raised status flags {st} (1/2 = constraint-row / contact capacity exceeded, 4 = "
+                           "non-finite state): the measured steps are not the reference's computation")
+    obs = env.ctx.step(np.zeros((env.num_envs, 4), dtype=np.float32), env._next_goal)[0]
+    if not np.isfinite(obs).all():
+        raise RuntimeError("bench: non-finite observation after the timed region")
+    return st
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # one process per GPU: re-execute under torch.distributed.run (the driver's own launch line does the same)
+        cmd = launcher_command(sys.argv[1:] if argv is None else argv, args.gpus)
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or drop the launcher and let "
+                         "bench.py spawn the ranks itself)")
     import torch
     dist = None
+    on_gpu = not args.host_harness
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
+    lib = None
+    if args.host_harness:
+        import __graft_entry__ as g
+        from metaworld_amd import native
+        lib = native.load("mwh_", g.build_host_harness())
+        local_rank = 0
     from metaworld_amd import tasks as T
-    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
-    bench = args.benchmark
-    if bench == "auto":   # the metric's config (MT50) once every task has device code; until then the largest supported set
-        bench = "MT50" if len(T.supported_tasks()) == 50 else "MT1"
-    if bench == "MT1":
-        env = MetaWorldGpuVectorEnv("MT1", "reach-v3", num_envs=args.envs, seed=42 + rank, precision=args.precision,
-                                    device_id=local_rank, rank=rank, world_size=world)
-        workload, wl_task = f"MT1 reach-v3, {args.envs} batched envs/GPU, {args.precision}, random actions", ["reach-v3"]
-    else:
-        env = MetaWorldGpuVectorEnv(bench, num_envs=args.envs, seed=42 + rank, use_one_hot=True, precision=args.precision,
-                                    device_id=local_rank, rank=rank, world_size=world)
-        workload, wl_task = f"{bench} sync-vector, {args.envs} envs/GPU, {args.precision}, random actions", list(env.task_list)
+    env = build_env(args, args.precision, rank, world, local_rank, lib)
     N = env.num_envs
-    env.reset()
-    T_act = 64
-    acts = np.random.default_rng(rank).uniform(-1, 1, (T_act, N, 4)).astype(np.float32)
-    env.ctx.upload_actions(acts)
-    env.ctx.step_resident(args.warmup)
+    one_hot = args.benchmark != "MT1"
+    wl_task = ["reach-v3"] if args.benchmark == "MT1" else list(env.task_list)
+    workload = (f"MT1 reach-v3, {N} batched envs/GPU" if args.benchmark == "MT1" else f"{args.benchmark} sync-vector, {N} envs/GPU") + \
+        f", {args.precision}, random actions"
+
+    # cross-rank bookkeeping: the communicator lives inside the library (RCCL over xGMI); its id travels over torch.distributed
+    gather_mode = "none (1 rank)"
+    if world > 1:
+        dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+        uid = torch.from_numpy(env.ctx.comm_unique_id()).to(dev) if rank == 0 else torch.zeros(128, dtype=torch.uint8, device=dev)
+        dist.broadcast(uid, 0)
+        env.ctx.comm_init(uid.cpu().numpy(), rank, world)
+        gather_mode = "RCCL all-gather inside the library, per step, side stream (mw_step_resident_gather)" if on_gpu else \
+            "host-harness shared-memory all-gather, per step (TEST)"
+    prepare(env, args, rank)
 
     def barrier():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = env.ctx.step_resident(args.steps)     # K launches on the library's stream, bracketed by HIP events
+    # K launches on the library's stream bracketed by HIP events; with > 1 rank the per-step all-gather is inside the loop
+    kernel_ms = env.ctx.step_resident_gather(args.steps) if world > 1 else env.ctx.step_resident(args.steps)
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        tw = torch.tensor([wall], device="cuda")
+        tw = torch.tensor([wall], device="cuda" if on_gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
-    if world > 1:   # the one real exchange of this path: per-step bookkeeping all-gather over RCCL (not in the timed loop)
-        from metaworld_amd.vector_env import gather_bookkeeping
-        env.ctx.step(acts[0], env._next_goal)
-        gather_bookkeeping(env.bookkeeping(), device=torch.device("cuda", local_rank))
+    status = check_outputs(env, args.allow_status)
+    book = env.ctx.gather_bookkeeping()          # [world, N] records of the last step on every rank
+    assert book.shape == (world, N)
     if rank == 0:
         total_steps = N * world * args.steps
         value = total_steps / wall
         per_launch_s = kernel_ms / 1e3 / args.steps
-        bytes_launch = ALGO_BYTES_PER_ENV_STEP[args.precision] * N
-        ach = bytes_launch / per_launch_s / 1e9
-        traffic = None                 # HBM bytes per launch from the committed PMC profile of this exact workload
-        prof = os.path.join(ROOT, "profiles", "r01_mt50_pmc.json")
-        if os.path.exists(prof):
+        algo = ALGO_BYTES_PER_ENV_STEP[(args.precision, one_hot)]
+        ach = algo * N / per_launch_s / 1e9
+        roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                    "traffic": None, "kernel_ms_per_launch": kernel_ms / args.steps, "algorithmic_bytes_per_env_step": algo,
+                    "note": "achieved = algorithmic bytes/env-step x envs / HIP-event kernel time (events on the library's own stream); "
+                            "traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of the committed rocprofv3 PMC profile of this command; "
+                            "the step kernel is bound by the latency of its per-environment dependency chain, not by HBM (DESIGN.md 5): "
+                            "see alu_issue"}
+        prof = os.path.join(ROOT, "profiles", f"r02_mt50_{args.precision}_pmc.json")
+        if os.path.exists(prof) and world == 1:
             with open(prof) as f:
                 pj = json.load(f)
-            if pj.get("workload") == workload and world == 1:
-                traffic = pj["fetch_bytes_per_launch"] + pj["write_bytes_per_launch"]
+            if pj.get("workload") == workload:
+                roofline["traffic"] = pj["fetch_bytes_per_launch"] + pj["write_bytes_per_launch"]
+                # the bound that actually moves (SURVEY.md 8d): VALU issue.  A wave64 VALU instruction holds its SIMD for 2
+                # cycles, so the chip issues N_SIMD x f_clk / 2 wave-instructions per second at most.
+                valu = pj["valu_wave_instr_per_launch"]
+                slots = N_SIMD * F_CLK_HZ / 2
+                roofline["alu_issue"] = {
+                    "valu_wave_instr_per_env_step": valu / N, "achieved_wave_instr_per_s": valu / per_launch_s,
+                    "peak_wave_instr_per_s": slots, "frac": valu / per_launch_s / slots,
+                    "lane_utilisation": pj.get("lane_utilisation"), "wave_slot_occupancy": pj.get("wave_slot_occupancy"),
+                    "wait_frac": pj.get("wait_frac"),
+                    "note": "VALU wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU) / this run's kernel time vs "
+                            "1024 SIMDs x 2.4 GHz / 2; lane_utilisation = envs x sub-lanes doing distinct work / (waves x 64); "
+                            "wave_slot_occupancy = SQ_WAVE_CYCLES x 4 / (1024 SIMDs x kernel cycles); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
         out = {"metric": "env-steps/sec (whole node) MT50 @4096 envs/GPU; achieved HBM GB/s vs peak", "value": value,
                "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.precision == "fp32" else "f64", "data": "synthetic",
                "config": {"workload": workload, "envs_per_gpu": N, "tasks_with_device_code": len(T.supported_tasks()),
-                          "parallelism": f"dp{world} (independent env shards, no data-path collective)"},
-               "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                            "traffic": traffic, "kernel_ms_per_launch": kernel_ms / args.steps,
-                            "note": "achieved = algorithmic bytes/env-step x envs / HIP-event kernel time; traffic = FETCH_SIZE + "
-                                    "WRITE_SIZE bytes per launch of the committed rocprofv3 profile (profiles/r01_mt50_pmc.json); the "
-                                    "step kernel is bound by the latency of its per-environment dependency chain, not by HBM (DESIGN.md 5)"}}
-        if world == 1 and args.precision == "fp32" and not args.no_parity_mode:
-            # the same workload in the parity precision (fp64 state/arithmetic: obs/reward <= 1e-5 vs the reference traces)
+                          "episode_phase": "all envs start together (early-episode window)" if args.no_stagger else
+                          f"staggered uniformly over the {HORIZON}-step horizon (mw_set_episode_phase + untimed {HORIZON}-step pre-roll): "
+                          "every window samples whole episodes incl. auto-resets",
+                          "parallelism": f"dp{world} (independent env shards, no data-path collective)", "bookkeeping_gather": gather_mode,
+                          "status_flags": status},
+               "roofline": roofline}
+        if world == 1 and not args.no_extra_precision and on_gpu:
+            other = "fp32" if args.precision == "fp64" else "fp64"
             env.close()
-            env64 = MetaWorldGpuVectorEnv(bench, "reach-v3" if bench == "MT1" else None, num_envs=args.envs, seed=42 + rank,
-                                          use_one_hot=bench != "MT1", precision="fp64", device_id=local_rank)
-            env64.reset()
-            env64.ctx.upload_actions(acts)
-            env64.ctx.step_resident(args.warmup)
+            env2 = build_env(args, other, rank, world, local_rank, lib)
+            prepare(env2, args, rank)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            k64 = env64.ctx.step_resident(args.steps)
+            k2 = env2.ctx.step_resident(args.steps)
             torch.cuda.synchronize()
-            w64 = time.perf_counter() - t1
-            out["parity_mode"] = {"dtype": "f64", "value": N * args.steps / w64, "unit": "env-steps/s", "ms_per_step": w64 / args.steps * 1e3,
-                                  "kernel_ms_per_launch": k64 / args.steps}
-            env64.close()
+            w2 = time.perf_counter() - t1
+            st2 = check_outputs(env2, args.allow_status)
+            key = "throughput_mode" if other == "fp32" else "parity_mode"
+            out[key] = {"dtype": "f32" if other == "fp32" else "f64", "value": N * args.steps / w2, "unit": "env-steps/s",
+                        "ms_per_step": w2 / args.steps * 1e3, "kernel_ms_per_launch": k2 / args.steps, "status_flags": st2,
+                        "note": "fp32 state and arithmetic: success flags exact, obs / reward within the single-precision contact-geometry "
+                                "floor (not 1e-5 on every task, DESIGN.md 6)" if other == "fp32" else "fp64 state and arithmetic"}
+            env2.close()
         if world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl_task)
-        print(json.dumps(out))
-    env.close()
+        print(json.dumps(out), flush=True)
+    if not env.closed:
+        env.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -54,7 +54,8 @@ typedef struct mw_task {
  * hull vertex graph of big meshes (mesh_nbradr, mesh_nbr, mesh_start, mesh_hill) for the hill-climbing support function.
  * Options: timestep, tolerance (solver tolerance of the context's precision), reset_tolerance (tolerance of the
  * double-precision reset-snapshot build; default = tolerance), meaninertia, gravity_z, iterations, ls_iterations,
- * maxcon, maxefc (contact / constraint-row capacities per environment), nreloc. */
+ * maxcon, maxefc (contact / constraint-row capacities per environment), nreloc, lanes_per_block (environments per
+ * 64-thread workgroup of this model's group, a power of two; 0 = the runtime's choice). */
 mw_model* mw_model_new(void);
 int mw_model_set_int(mw_model* m, const char* field, const int32_t* v, int n);
 int mw_model_set_real(mw_model* m, const char* field, const double* v, int n);
@@ -85,9 +86,17 @@ int mw_step(mw_ctx* c, const float* actions /*[N][4]*/, const int32_t* next_goal
             float* info /*[N][6] near_object, grasp_success, grasp_reward, in_place_reward, obj_to_target, unscaled_reward; or NULL*/,
             double* final_obs /*[N][D] or NULL*/, double* episode_return /*[N] or NULL*/, int32_t* episode_length /*[N] or NULL*/);
 
+/* gymnasium TimeLimit._elapsed_steps and SawyerXYZEnv.curr_path_length (sawyer_xyz_env.py:596) of every env := elapsed[i]
+ * (0 <= elapsed[i] < max_episode_steps): env i truncates and auto-resets after max_episode_steps - elapsed[i] more steps.
+ * No reference counterpart (its sub-envs all start at 0 and truncate together); used to stagger the episode phases of a batch. */
+int mw_set_episode_phase(mw_ctx* c, const int32_t* elapsed /*[N]*/);
+
 /* ---- throughput path: actions resident in HBM, outputs left in HBM (bench.py) ---- */
 int mw_upload_actions(mw_ctx* c, const float* actions /*[nsteps][N][4]*/, int nsteps);
 int mw_step_resident(mw_ctx* c, int nsteps, int action_steps, float* kernel_ms /*HIP-event time of the nsteps launches*/);
+/* the same loop with the per-step cross-rank bookkeeping gather inside it (mw_comm_init first when world_size > 1): launch k+1
+ * overlaps the all-gather of step k on the side stream; returns after both streams have drained */
+int mw_step_resident_gather(mw_ctx* c, int nsteps, int action_steps, float* kernel_ms);
 
 /* ---- device-resident boundary (SURVEY.md 8b "outputs_on_device"): the learner's policy runs on the same GPU, so actions and
  *      outputs never visit the host.  Every pointer is a DEVICE pointer the caller owns (a torch tensor's data_ptr()); a NULL
@@ -119,11 +128,29 @@ int mw_policy_actions(mw_ctx* c, const int32_t* policy_id /*[N]*/, const double*
 int mw_policy_rollout(mw_ctx* c, const int32_t* policy_id /*[N]*/, const int32_t* goal_schedule /*[K][N]*/, int K, int nsteps,
                       int32_t* episodes /*[N] out or NULL*/, int32_t* successes /*[N] out or NULL*/, float* kernel_ms /*or NULL*/);
 
-/* ---- calibration of the lanes-per-workgroup choice (no reference counterpart): ticks == NULL (re)starts accumulating, per
- *      workgroup, the wall-clock ticks (100 MHz) its mw_step_resident launches take; otherwise copies them out together with
- *      the model index of each workgroup's group.  Returns the number of workgroups, < 0 on error.  The model option
- *      "lanes_per_block" (mw_model_set_option) is the knob this calibrates (tools/calibrate_lpb.py). ---- */
-int mw_wave_profile(mw_ctx* c, int64_t* ticks /*[capacity] or NULL*/, int32_t* model_of_block /*[capacity] or NULL*/, int capacity);
+/* ---- cross-rank bookkeeping gather (no reference counterpart: the reference's SyncVectorEnv lives in one
+ *      process).  Envs are independent, so stepping needs no communication; the one exchange is this 12-byte record per
+ *      env and step, all-gathered over RCCL (xGMI) so that every rank sees the global done / success / task-id / episode
+ *      statistics that `metaworld/evaluation.py:79-82` reads from `final_info`.  The step kernel writes the record; the
+ *      collective runs on a side stream and overlaps the next step's kernel. ---- */
+typedef struct mw_bookkeeping {
+    uint8_t done;              /* terminated | truncated */
+    uint8_t success;           /* info["success"] of this step */
+    int16_t task_id;           /* index in ALL_V3_ENVIRONMENTS (metaworld/env_dict.py:217-270) */
+    float episode_return;      /* RecordEpisodeStatistics running return (the episode's total where done) */
+    int32_t episode_length;    /*   "" length */
+} mw_bookkeeping;
+int mw_comm_unique_id(uint8_t* id_out /*[128] ncclUniqueId, created on the calling rank*/);
+int mw_comm_init(mw_ctx* c, const uint8_t* id /*[128], the same bytes on every rank*/, int rank, int world_size);
+/* all-gather the records of the LAST step; out = [world_size][N] records, a HOST pointer (out_on_device = 0) or a DEVICE
+ * pointer (1); NULL keeps the result in the context's own device buffer.  world_size 1 needs no communicator. */
+int mw_gather_bookkeeping(mw_ctx* c, mw_bookkeeping* out, int out_on_device);
+
+/* ---- run-time status (SURVEY.md 5 "failure detection"): status[0] = OR of the per-env flags since the last clear
+ *      (1 = constraint-row capacity exceeded, 2 = contact capacity exceeded -- rows / contacts were DROPPED, the step differs
+ *      from the reference's; 4 = non-finite state, the env was reset: the intent of sawyer_xyz_env.py:603-619),
+ *      status[1..3] = number of env-steps that raised each flag. ---- */
+int mw_status(mw_ctx* c, int32_t* status /*[4]*/, int clear);
 
 /* ---- state access for parity tests (mujoco data.qpos / qvel / mocap_pos, MujocoEnv.set_state) ---- */
 int mw_column_size(mw_ctx* c, int env, const char* what);

@@ -65,12 +65,16 @@ int MW_API(add_task)(mw_ctx* c, const mw_task* t, const double* goals, int ngoal
         for (int k = 0; k < 3; k++) { s.hand_init[k] = t->hand_init[k]; s.mocap_low[k] = t->mocap_low[k]; s.mocap_high[k] = t->mocap_high[k]; s.goal_low[k] = t->goal_low[k]; s.goal_high[k] = t->goal_high[k]; }
         for (int k = 0; k < 15; k++) s.c[k] = t->c[k];
         s.c[15] = t->onehot_id;
+        if (!goals || ngoals <= 0) throw std::runtime_error("a task needs at least one goal (rand_vec)");
         s.goals.assign(goals, goals + 6 * (size_t)ngoals);
         c->tasks.push_back(s);
         return (int)c->tasks.size() - 1;
     } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
 }
-int MW_API(set_envs)(mw_ctx* c, const int32_t* env_task, int n) { c->env_task.assign(env_task, env_task + n); return 0; }
+int MW_API(set_envs)(mw_ctx* c, const int32_t* env_task, int n) {
+    if (!env_task || n <= 0) { c->error = "set_envs: empty env list"; return -1; }
+    c->env_task.assign(env_task, env_task + n); return 0;
+}
 int MW_API(set_terminate_on_success)(mw_ctx* c, int on) {
     c->cfg.terminate_on_success = on ? 1 : 0;
     if (c->impl) c->impl->cfg.terminate_on_success = c->cfg.terminate_on_success;
@@ -79,18 +83,19 @@ int MW_API(set_terminate_on_success)(mw_ctx* c, int on) {
 int MW_API(finalize)(mw_ctx* c) {
     MW_TRY(c, {
         for (int t : c->env_task) if (t < 0 || t >= (int)c->tasks.size()) throw std::runtime_error("env refers to unknown task");
+        Backend::use(c->cfg.device_id);
         if (c->cfg.precision == 1) c->impl.reset(new mw::Context<double, Backend>());
         else c->impl.reset(new mw::Context<float, Backend>());
         c->impl->cfg = c->cfg; c->impl->models = c->models; c->impl->tasks = c->tasks; c->impl->env_task = c->env_task;
         c->impl->finalize();
     });
 }
-void MW_API(destroy)(mw_ctx* c) { delete c; }
+void MW_API(destroy)(mw_ctx* c) { if (c) { try { Backend::use(c->cfg.device_id); } catch (...) {} delete c; } }
 const char* MW_API(last_error)(const mw_ctx* c) { return c ? c->error.c_str() : "null context"; }
 int MW_API(num_envs)(const mw_ctx* c) { return (int)c->env_task.size(); }
 int MW_API(obs_dim)(const mw_ctx* c) { return 39 + (c->cfg.one_hot ? c->cfg.num_tasks : 0); }
 
-#define MW_NEED_IMPL(c) if (!(c)->impl) throw std::runtime_error("context not finalized")
+#define MW_NEED_IMPL(c) if (!(c)->impl) throw std::runtime_error("context not finalized"); Backend::use((c)->cfg.device_id)
 int MW_API(reset)(mw_ctx* c, const uint8_t* mask, const int32_t* goal_idx, double* obs_out) {
     MW_TRY(c, { MW_NEED_IMPL(c); c->impl->reset(mask, goal_idx, obs_out); });
 }
@@ -112,9 +117,16 @@ int MW_API(policy_actions)(mw_ctx* c, const int32_t* policy_id, const double* ob
 int MW_API(policy_rollout)(mw_ctx* c, const int32_t* policy_id, const int32_t* schedule, int K, int nsteps, int32_t* episodes, int32_t* successes, float* ms) {
     MW_TRY(c, { MW_NEED_IMPL(c); if (!policy_id || !schedule) throw std::invalid_argument("policy_rollout: null argument"); c->impl->policy_rollout(policy_id, schedule, K, nsteps, episodes, successes, ms); });
 }
-int MW_API(wave_profile)(mw_ctx* c, int64_t* ticks, int32_t* model_of_block, int capacity) {
-    try { MW_NEED_IMPL(c); return c->impl->wave_profile((long long*)ticks, model_of_block, capacity); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
+int MW_API(step_resident_gather)(mw_ctx* c, int nsteps, int asteps, float* ms) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->step_resident_gather(nsteps, asteps, ms); }); }
+int MW_API(comm_unique_id)(uint8_t* id_out) {
+    try { if (!id_out) return -1; Backend::comm_unique_id(id_out); return 0; } catch (...) { return -1; }
 }
+int MW_API(comm_init)(mw_ctx* c, const uint8_t* id, int rank, int world) {
+    MW_TRY(c, { MW_NEED_IMPL(c); if (world > 1 && !id) throw std::invalid_argument("comm_init: id is required when world_size > 1"); c->impl->comm_init(id, rank, world); });
+}
+int MW_API(gather_bookkeeping)(mw_ctx* c, mw_bookkeeping* out, int out_on_device) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->gather_bookkeeping(out, out_on_device); }); }
+int MW_API(set_episode_phase)(mw_ctx* c, const int32_t* elapsed) { MW_TRY(c, { MW_NEED_IMPL(c); if (!elapsed) throw std::invalid_argument("set_episode_phase: null argument"); c->impl->set_episode_phase(elapsed); }); }
+int MW_API(status)(mw_ctx* c, int32_t* out, int clear) { MW_TRY(c, { MW_NEED_IMPL(c); if (!out) throw std::invalid_argument("status: null output"); c->impl->status(out, clear); }); }
 int MW_API(column_size)(mw_ctx* c, int env, const char* what) {
     try { MW_NEED_IMPL(c); return c->impl->layout_size(env, what); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
 }

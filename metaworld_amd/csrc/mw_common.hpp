@@ -23,12 +23,10 @@
 #define MW_HD __host__ __device__ inline
 #define MW_STAGE_FN __host__ __device__ __attribute__((noinline))   // the big stages: one copy each (code size, compile time)
 #define MW_FP_EXACT _Pragma("clang fp contract(off)")   // first statement of a block: no fused multiply-add (bit-exact restatements)
-#define MW_WALL_CLOCK() ((long long)wall_clock64())      // constant-rate (100 MHz) counter: per-workgroup durations (mw_wave_profile)
 #else
 #define MW_HD inline
 #define MW_STAGE_FN inline
 #define MW_FP_EXACT   // the host harness is built with -ffp-contract=off
-#define MW_WALL_CLOCK() 0LL
 #endif
 
 namespace mw {
@@ -193,6 +191,15 @@ struct Env {
     int sub, nsub;     // sub-lane of this thread and sub-lanes per environment (cooperative row sweeps, see below)
     int thr;           // thread index inside the workgroup
     int lds_rows;      // constraint rows whose solver scalars fit in the scratchpad (the rest stay in the column store)
+#if defined(MW_BOUNDS)   // debug build: every column-store access is range-checked; a violation is recorded and redirected to element 0
+    unsigned nreal_b, nint_b;
+    int* oob;          // context status word: [0] |= 8, [1] = kind (1 real, 2 int, 3 scratchpad), [2] = index, [3] = limit
+    MW_HD unsigned chk(int i, unsigned lim, int kind) const {
+        if ((unsigned)i < lim) return (unsigned)i;
+        if (oob) { oob[0] |= 8; oob[1] = kind; oob[2] = i; oob[3] = (int)lim; }
+        return 0u;
+    }
+#endif
     // lpb = environments per workgroup of this environment's group; threads t, t + lpb, ... are its sub-lanes
     MW_HD void set_scratchpad(Scratchpad sp, int thread, int lpb) {
         const bool host = sp.host_nsub > 0;
@@ -217,8 +224,15 @@ struct Env {
     }
     MW_HD CModel<T>& model() const { return *(CModel<T>*)(unsigned long long)m; }
     MW_HD CLayout& lay() const { return model().L; }
+#if defined(MW_BOUNDS)
+    MW_HD GRef<T> R(int i) const { return ((MW_GLOBAL T*)col)[chk(i, nreal_b, 1) * stride]; }
+    MW_HD GRef<int> I(int i) const { return ((MW_GLOBAL int*)icol)[chk(i, nint_b, 2) * stride]; }
+    MW_HD int S(int row, int f) const { return (int)chk(row, (unsigned)lds_rows, 3) * SR_N + f; }   // scratchpad slot of (row, field)
+#else
     MW_HD GRef<T> R(int i) const { return ((MW_GLOBAL T*)col)[(unsigned)i * stride]; }
     MW_HD GRef<int> I(int i) const { return ((MW_GLOBAL int*)icol)[(unsigned)i * stride]; }
+    MW_HD int S(int row, int f) const { return row * SR_N + f; }
+#endif
 };
 
 // Cooperative sweeps.  When a batch is too small to fill the chip the runtime puts only `lpb` < 64 environments in a

@@ -652,12 +652,12 @@ enum { SR_D = 0, SR_JAR, SR_JV, SR_FRI, SR_INFO, SR_STATE, SR_FORCE, SR_BLK };
 MW_HD constexpr int sr_slot(int f) { return f == SR_D ? 3 : f == SR_JAR ? 6 : f == SR_JV ? 7 : f == SR_FRI ? 8 : f == SR_INFO ? 9 : f == SR_STATE ? 10 : 5; }
 template <typename T>
 MW_HD T sr_get(const Env<T> e, int i, int f) {
-    if (i < e.lds_rows) return e.lds[(i * SR_N + f) * e.lds_stride];
+    if (i < e.lds_rows) return e.lds[e.S(i, f) * e.lds_stride];
     return EX(e, i, sr_slot(f));
 }
 template <typename T>
 MW_HD void sr_set(const Env<T> e, int i, int f, T v) {
-    if (i < e.lds_rows) e.lds[(i * SR_N + f) * e.lds_stride] = v;
+    if (i < e.lds_rows) e.lds[e.S(i, f) * e.lds_stride] = v;
     else EX(e, i, sr_slot(f)) = v;
 }
 
@@ -668,11 +668,11 @@ template <typename T, bool IN_LDS>
 struct Rows {
     Env<T> e;
     MW_HD T get(int i, int f) const {
-        if (IN_LDS) return e.lds[(i * SR_N + f) * e.lds_stride];
+        if (IN_LDS) return e.lds[e.S(i, f) * e.lds_stride];
         return sr_get(e, i, f);
     }
     MW_HD void set(int i, int f, T v) const {
-        if (IN_LDS) e.lds[(i * SR_N + f) * e.lds_stride] = v;
+        if (IN_LDS) e.lds[e.S(i, f) * e.lds_stride] = v;
         else sr_set(e, i, f, v);
     }
 };
@@ -748,7 +748,7 @@ MW_HD void uc_row(const R& rows, const Env<T> e, int i, T* cost) {
 // first row of constraint block k (scratchpad copy of the list built by make_constraints)
 template <typename T>
 MW_HD int block_row(const Env<T> e, int k) {
-    if (k < e.lds_rows) return (int)e.lds[(k * SR_N + SR_BLK) * e.lds_stride];
+    if (k < e.lds_rows) return (int)e.lds[e.S(k, SR_BLK) * e.lds_stride];
     return IEFC(e, k, 2);
 }
 

@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/mwgpu.h"   // mw_device_out (the C ABI types are plain structs)
+#include "../../include/mwgpu.h"   // mw_device_out, mw_bookkeeping (the C ABI types are plain structs)
 #include "mw_collide.hpp"
 #include "mw_common.hpp"
 #include "mw_phys.hpp"
@@ -131,8 +131,13 @@ struct IOPtrs {
     double* final_obs;       // [N][D] (valid where done)
     double* ep_ret;          // [N]   (valid where done)
     int* ep_len;             // [N]
+    mw_bookkeeping* book;    // [N] packed per-step record for the cross-rank gather, or null
+    int* status;             // [4] context status: OR of the per-env flags, env-steps with row overflow / contact overflow / instability
     int D;
 };
+
+// per-env status bits of one step (icount[3]); sticky in the context status word until mw_status clears it
+enum { ST_ROW_OVERFLOW = 1, ST_CON_OVERFLOW = 2, ST_UNSTABLE = 4 };
 
 template <typename T>
 struct World {
@@ -142,6 +147,7 @@ struct World {
     const T* snap;            // reset snapshots
     const long long* snap_off;  // per task: element offset of goal 0
     const int* snap_stride;   // per task: elements per snapshot (= nstate + 39)
+    const int* snap_ngoal;    // per task: number of goals (snapshots)
     int max_episode_steps, terminate_on_success, one_hot, num_tasks;
     IOPtrs io;
 };
@@ -165,6 +171,9 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Scratchpad sp, Env<T
     e->icol = G.icol + chunk * G.L.nint * lpb + lin;
     e->m = &G.m; e->stride = (unsigned)lpb;
     e->cache_layout(G.L, G.m.sz.nv);
+#if defined(MW_BOUNDS)
+    e->nreal_b = (unsigned)G.L.nreal; e->nint_b = (unsigned)G.L.nint; e->oob = w.io.status;
+#endif
     *gid = G.gid[lane];
     return true;
 }
@@ -178,6 +187,8 @@ MW_HD void write_obs(const World<T>& w, const TaskDesc<T>& td, double* dst, cons
 
 template <typename T>
 MW_HD void load_snapshot(const World<T>& w, const Env<T> e, int task, int goal, T* obs39) {
+    const int ng = w.snap_ngoal[task];
+    goal = goal < 0 ? 0 : (goal >= ng ? ng - 1 : goal);   // device-pointer entry points cannot be range-checked on the host
     const T* s = w.snap + w.snap_off[task] + (long long)goal * w.snap_stride[task];
     const int ns = e.lay().nstate;
     const V3<T> persist = tk3(e, TK_PERSIST0);
@@ -196,7 +207,7 @@ MW_HD void lane_reset_full(const World<T>& w, int block, int thread, Scratchpad 
     const TaskDesc<T>& td = w.tasks[task];
     T obs[39];
     env_reset(e, td, obs);
-    if (w.io.obs) write_obs(w, td, w.io.obs + (size_t)gid * w.io.D, obs, (int)td.c[15]);
+    if (w.io.obs && e.sub == 0) write_obs(w, td, w.io.obs + (size_t)gid * w.io.D, obs, (int)td.c[15]);
 }
 
 // reset from snapshot for masked envs (mask may be null = all); goal from io.next_goal
@@ -209,8 +220,19 @@ MW_HD void lane_reset_snap(const World<T>& w, const uint8_t* mask, int block, in
     const TaskDesc<T>& td = w.tasks[task];
     T obs[39];
     load_snapshot(w, e, task, w.io.next_goal[gid], obs);
-    if (w.io.obs) write_obs(w, td, w.io.obs + (size_t)gid * w.io.D, obs, (int)td.c[15]);
+    if (w.io.obs && e.sub == 0) write_obs(w, td, w.io.obs + (size_t)gid * w.io.D, obs, (int)td.c[15]);
 }
+
+// RecordEpisodeStatistics sums the float64 rewards in float64 (gymnasium); a single-precision context keeps the running
+// return as an unevaluated (hi, lo) pair of floats in the task block, so that it is summed in double there as well
+template <typename T>
+MW_HD double ep_return_add(const Env<T> e, T reward) {
+    const double acc = (double)TK(e, TK_EPRET) + (double)TK(e, TK_EPRET_LO) + (double)reward;
+    const T hi = (T)acc;
+    TK(e, TK_EPRET) = hi; TK(e, TK_EPRET_LO) = (T)(acc - (double)hi);
+    return acc;
+}
+MW_HD bool mw_finite(double x) { return x - x == 0; }
 
 // one VectorEnv.step for one env: SawyerXYZEnv.step + TimeLimit + AutoTerminateOnSuccess + OneHot +
 // RecordEpisodeStatistics + SAME_STEP auto-reset (metaworld/__init__.py:430-454, :465)
@@ -223,27 +245,63 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     T act[4], obs[39], reward, success;
     Info info;
     for (int k = 0; k < 4; k++) act[k] = (T)w.io.act[(size_t)gid * 4 + k];
+    e.I(e.lay().icount + 3) = 0;
     env_step(e, td, act, obs, &reward, &success, &info);
+    // Instability guard (the intent of the reference's dead `_did_see_sim_exception` branch, sawyer_xyz_env.py:603-619, and
+    // of MuJoCo's own reset on a bad QACC): a non-finite step returns the last stable observation with reward 0, ends the
+    // episode as truncated (so the SAME_STEP auto-reset below restores a valid state) and raises ST_UNSTABLE.
+    int flags = e.I(e.lay().icount + 3);
+    bool bad = !mw_finite((double)reward);
+    for (int k = 0; k < 18; k++) bad |= !mw_finite((double)obs[k]);
+    if (bad) {
+        flags |= ST_UNSTABLE;
+        for (int k = 0; k < 18; k++) { obs[k] = obs[18 + k]; TK(e, TK_PREVOBS + k) = obs[18 + k]; }
+        reward = 0; success = 0; info = Info{0, 0, 0, 0, 0, 0};
+    }
     TK(e, TK_SUCCESS) = success;
-    TK(e, TK_ELAPSED) += 1; TK(e, TK_EPRET) += reward; TK(e, TK_EPLEN) += 1;
-    const bool truncated = TK(e, TK_PATHLEN) >= td.max_path_length || TK(e, TK_ELAPSED) >= w.max_episode_steps;
+    TK(e, TK_ELAPSED) += 1; TK(e, TK_EPLEN) += 1;
+    const double ep_ret = ep_return_add(e, reward);
+    const bool truncated = bad || TK(e, TK_PATHLEN) >= td.max_path_length || TK(e, TK_ELAPSED) >= w.max_episode_steps;
     const bool terminated = w.terminate_on_success && success == T(1);
+    const bool done = terminated || truncated;
     const IOPtrs& io = w.io;
-    io.reward[gid] = (double)reward;
-    io.terminated[gid] = terminated; io.truncated[gid] = truncated; io.success[gid] = success == T(1);
-    io.done[gid] = terminated || truncated;
-    if (io.info) {
-        float* f = io.info + (size_t)gid * 6;
-        f[0] = info.near_object; f[1] = info.grasp_success; f[2] = info.grasp_reward; f[3] = info.in_place_reward;
-        f[4] = info.obj_to_target; f[5] = info.unscaled_reward;
+    const bool writer = e.sub == 0;          // the sub-lanes of an environment hold identical values: one of them stores
+    const int ep_len = (int)TK(e, TK_EPLEN);
+    if (writer) {
+        io.reward[gid] = (double)reward;
+        io.terminated[gid] = terminated; io.truncated[gid] = truncated; io.success[gid] = success == T(1);
+        io.done[gid] = done;
+        if (io.info) {
+            float* f = io.info + (size_t)gid * 6;
+            f[0] = info.near_object; f[1] = info.grasp_success; f[2] = info.grasp_reward; f[3] = info.in_place_reward;
+            f[4] = info.obj_to_target; f[5] = info.unscaled_reward;
+        }
+        if (io.book) {
+            mw_bookkeeping b;
+            b.done = done; b.success = success == T(1); b.task_id = (int16_t)td.kind; b.episode_return = (float)ep_ret; b.episode_length = ep_len;
+            io.book[gid] = b;
+        }
+        if (flags && io.status) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            atomicOr(io.status, flags);
+            if (flags & ST_ROW_OVERFLOW) atomicAdd(io.status + 1, 1);
+            if (flags & ST_CON_OVERFLOW) atomicAdd(io.status + 2, 1);
+            if (flags & ST_UNSTABLE) atomicAdd(io.status + 3, 1);
+#else
+#pragma omp critical(mw_status)
+            { io.status[0] |= flags; io.status[1] += (flags & ST_ROW_OVERFLOW) != 0; io.status[2] += (flags & ST_CON_OVERFLOW) != 0; io.status[3] += (flags & ST_UNSTABLE) != 0; }
+#endif
+        }
     }
     const int oh = (int)td.c[15];
-    if (terminated || truncated) {
-        if (io.final_obs) write_obs(w, td, io.final_obs + (size_t)gid * io.D, obs, oh);
-        io.ep_ret[gid] = (double)TK(e, TK_EPRET); io.ep_len[gid] = (int)TK(e, TK_EPLEN);
+    if (done) {
+        if (writer) {
+            if (io.final_obs) write_obs(w, td, io.final_obs + (size_t)gid * io.D, obs, oh);
+            io.ep_ret[gid] = ep_ret; io.ep_len[gid] = ep_len;
+        }
         load_snapshot(w, e, task, io.next_goal[gid], obs);
     }
-    write_obs(w, td, io.obs + (size_t)gid * io.D, obs, oh);
+    if (writer) write_obs(w, td, io.obs + (size_t)gid * io.D, obs, oh);
 }
 
 // debugging / parity hooks: run raw physics on every lane
@@ -291,13 +349,17 @@ public:
     virtual void reset(const uint8_t* mask, const int* goal_idx, double* obs_out) = 0;
     virtual void step(const float* act, const int* next_goal, double* obs, double* reward, uint8_t* term, uint8_t* trunc,
                       uint8_t* success, float* info, double* final_obs, double* ep_ret, int* ep_len) = 0;
-    virtual void step_device_only(const float* d_act, int nsteps, int act_stride_steps, float* kernel_ms) = 0;
+    virtual void step_device_only(const float* d_act, int nsteps, int act_stride_steps, float* kernel_ms, bool gather = false) = 0;
     virtual void step_device(const float* d_act, const int* d_next_goal, const mw_device_out* out) = 0;
     virtual void reset_device(const uint8_t* d_mask, const int* d_goal_idx, double* d_obs) = 0;
     virtual void policy_actions(const int* policy_id, const double* obs, float* act) = 0;
     virtual void policy_rollout(const int* policy_id, const int* schedule, int K, int nsteps, int* episodes, int* successes, float* kernel_ms) = 0;
     virtual void upload_actions(const float* act, int nsteps) = 0;
-    virtual int wave_profile(long long* ticks, int* model_of_block, int capacity) = 0;
+    virtual void step_resident_gather(int nsteps, int act_stride_steps, float* kernel_ms) = 0;
+    virtual void comm_init(const void* id128, int rank, int world) = 0;
+    virtual void gather_bookkeeping(mw_bookkeeping* out, int out_on_device) = 0;
+    virtual void status(int* out4, int clear) = 0;
+    virtual void set_episode_phase(const int* elapsed) = 0;
     virtual void read_col(int gid, const char* what, int n, double* out) = 0;
     virtual void write_col(int gid, const char* what, int n, const double* in) = 0;
     virtual void read_icol(int gid, const char* what, int n, int* out) = 0;
@@ -345,17 +407,27 @@ class Context : public ContextBase {
     int* d_eplen_ = nullptr;
     std::vector<long long> snap_off_;
     std::vector<int> snap_stride_;
+    int* d_snap_ngoal_ = nullptr;
+    int* d_status_ = nullptr;                 // [4], see mw_status
+    mw_bookkeeping* d_book_ = nullptr;        // [2][N]: the step kernel writes slot (step parity), the gather reads it
+    mw_bookkeeping* d_book_all_ = nullptr;    // [2][world][N] gathered records
+    int book_slot_ = 0;                       // slot the LAST step wrote
+    typename Backend::Comm* comm_ = nullptr;
+    std::vector<int> h_next_goal_;            // host mirror of d_next_goal_ (masked resets update only their envs)
+    std::vector<uint8_t> was_reset_;          // step() before the first reset() of an env is an error
+    int world_size() const { return comm_ ? comm_->world : 1; }
 
     World<T> world(bool with_io = true) const {
         World<T> w{};
         w.groups = d_groups_; w.ngroups = (int)groups_.size(); w.tasks = d_tasks_;
-        w.snap = d_snap_; w.snap_off = d_snap_off_; w.snap_stride = d_snap_stride_;
+        w.snap = d_snap_; w.snap_off = d_snap_off_; w.snap_stride = d_snap_stride_; w.snap_ngoal = d_snap_ngoal_;
         w.max_episode_steps = cfg.max_episode_steps; w.terminate_on_success = cfg.terminate_on_success;
         w.one_hot = cfg.one_hot; w.num_tasks = cfg.num_tasks;
         if (with_io) {
             w.io.act = d_act_; w.io.next_goal = d_next_goal_; w.io.obs = d_obs_; w.io.reward = d_reward_;
             w.io.terminated = d_flags_; w.io.truncated = d_flags_ + N_; w.io.success = d_flags_ + 2 * N_; w.io.done = d_flags_ + 3 * N_;
             w.io.info = d_info_; w.io.final_obs = d_final_; w.io.ep_ret = d_epret_; w.io.ep_len = d_eplen_; w.io.D = obs_dim();
+            w.io.status = d_status_; w.io.book = d_book_ ? d_book_ + (size_t)book_slot_ * N_ : nullptr;
         }
         return w;
     }
@@ -404,6 +476,8 @@ public:
         Backend::free(d_groups_); Backend::free(d_tasks_); Backend::free(d_snap_); Backend::free(d_snap_off_); Backend::free(d_snap_stride_);
         Backend::free(d_act_); Backend::free(d_next_goal_); Backend::free(d_mask_); Backend::free(d_obs_); Backend::free(d_reward_);
         Backend::free(d_final_); Backend::free(d_epret_); Backend::free(d_flags_); Backend::free(d_info_); Backend::free(d_eplen_);
+        Backend::free(d_snap_ngoal_); Backend::free(d_status_); Backend::free(d_book_); Backend::free(d_book_all_);
+        Backend::comm_free(comm_);
     }
 
     void finalize() override {
@@ -437,7 +511,7 @@ public:
                 lpb_of[best] /= 2;
                 if (blocks() > budget) { lpb_of[best] *= 2; break; }
             }
-            for (auto& kv : by_model) {          // the caller's calibrated choice (metaworld_amd/lpb_policy.py) wins over the proxy
+            for (auto& kv : by_model) {          // an explicit per-model choice (model option "lanes_per_block") wins over the proxy
                 const int l = models[kv.first]->lanes_per_block;
                 if (l == 0) continue;
                 if (l != 1 && l != 2 && l != 4 && l != 8 && l != 16 && l != 32 && l != 64) throw std::runtime_error("lanes_per_block must be a power of two <= 64");
@@ -474,6 +548,10 @@ public:
         d_flags_ = (uint8_t*)Backend::alloc(4 * N_); d_info_ = (float*)Backend::alloc(sizeof(float) * 6 * N_);
         d_eplen_ = (int*)Backend::alloc(sizeof(int) * N_); Backend::zero(d_eplen_, sizeof(int) * N_);
         d_act_ = (float*)Backend::alloc(sizeof(float) * 4 * N_); act_capacity_steps_ = 1;
+        d_status_ = (int*)Backend::alloc(sizeof(int) * 4); Backend::zero(d_status_, sizeof(int) * 4);
+        d_book_ = (mw_bookkeeping*)Backend::alloc(sizeof(mw_bookkeeping) * 2 * N_); Backend::zero(d_book_, sizeof(mw_bookkeeping) * 2 * N_);
+        d_book_all_ = (mw_bookkeeping*)Backend::alloc(sizeof(mw_bookkeeping) * 2 * N_); Backend::zero(d_book_all_, sizeof(mw_bookkeeping) * 2 * N_);
+        h_next_goal_.assign(N_, 0); was_reset_.assign(N_, 0);
         for (int i = 0; i < N_; i++) set_task_field(groups_[env_group_[i]], env_lane_[i], TK_TASK, env_task[i]);
         build_snapshots();
     }
@@ -491,7 +569,7 @@ public:
     // context: every episode then starts from the reference's reset state (to ~1e-7 after the cast) instead of from a
     // single-precision replay of the 500 settling substeps.
     void build_snapshots() override {
-        Backend::free(d_snap_); Backend::free(d_snap_off_); Backend::free(d_snap_stride_);
+        Backend::free(d_snap_); Backend::free(d_snap_off_); Backend::free(d_snap_stride_); Backend::free(d_snap_ngoal_);
         std::vector<T> snap;
         if (sizeof(T) == 8) compute_snapshots(snap);
         else {
@@ -516,6 +594,10 @@ public:
         Backend::h2d(d_snap_off_, snap_off_.data(), sizeof(long long) * tasks.size());
         d_snap_stride_ = (int*)Backend::alloc(sizeof(int) * tasks.size());
         Backend::h2d(d_snap_stride_, snap_stride_.data(), sizeof(int) * tasks.size());
+        std::vector<int> ngoal;
+        for (auto& t : tasks) ngoal.push_back((int)(t.goals.size() / 6));
+        d_snap_ngoal_ = (int*)Backend::alloc(sizeof(int) * tasks.size());
+        Backend::h2d(d_snap_ngoal_, ngoal.data(), sizeof(int) * tasks.size());
     }
     void compute_snapshots(std::vector<T>& snap) {
         snap_off_.assign(tasks.size(), 0); snap_stride_.assign(tasks.size(), 0);
@@ -567,8 +649,21 @@ public:
         }
     }
 
+    int ngoals_of(int env) const { return (int)(tasks[env_task[env]].goals.size() / 6); }
+    void check_goals(const int* goal_idx, const uint8_t* mask, const char* who) const {
+        for (int i = 0; i < N_; i++) {
+            if (mask && !mask[i]) continue;
+            if (goal_idx[i] < 0 || goal_idx[i] >= ngoals_of(i))
+                throw std::out_of_range(std::string(who) + ": goal index " + std::to_string(goal_idx[i]) + " of env " + std::to_string(i) +
+                                        " is outside its task's goal table [0, " + std::to_string(ngoals_of(i)) + ")");
+        }
+    }
     void reset(const uint8_t* mask, const int* goal_idx, double* obs_out) override {
-        Backend::h2d(d_next_goal_, goal_idx, sizeof(int) * N_);
+        if (!goal_idx) throw std::invalid_argument("reset: goal_idx is required");
+        check_goals(goal_idx, mask, "reset");
+        for (int i = 0; i < N_; i++)
+            if (!mask || mask[i]) { h_next_goal_[i] = goal_idx[i]; was_reset_[i] = 1; }     // a masked reset leaves the other envs' look-ahead goals alone
+        Backend::h2d(d_next_goal_, h_next_goal_.data(), sizeof(int) * N_);
         const uint8_t* dm = nullptr;
         if (mask) { Backend::h2d(d_mask_, mask, N_); dm = d_mask_; }
         World<T> w = world();
@@ -576,29 +671,40 @@ public:
         Backend::sync();
         if (obs_out) Backend::d2h(obs_out, d_obs_, sizeof(double) * N_ * obs_dim());
     }
+    void need_reset_done(const char* who) const {
+        for (int i = 0; i < N_; i++)
+            if (!was_reset_[i]) throw std::logic_error(std::string(who) + ": env " + std::to_string(i) + " has never been reset (call reset first)");
+    }
 
     void step(const float* act, const int* next_goal, double* obs, double* reward, uint8_t* term, uint8_t* trunc,
               uint8_t* success, float* info, double* final_obs, double* ep_ret, int* ep_len) override {
-        Backend::h2d(d_act_, act, sizeof(float) * 4 * N_);
-        if (next_goal) Backend::h2d(d_next_goal_, next_goal, sizeof(int) * N_);
+        if (!act) throw std::invalid_argument("step: actions are required");
+        need_reset_done("step");
+        if (next_goal) { check_goals(next_goal, nullptr, "step"); h_next_goal_.assign(next_goal, next_goal + N_); }
+        Backend::h2d_async(d_act_, act, sizeof(float) * 4 * N_);
+        if (next_goal) Backend::h2d_async(d_next_goal_, h_next_goal_.data(), sizeof(int) * N_);
+        book_slot_ ^= 1;
         World<T> w = world();
         Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
-        Backend::sync();
+        // all outputs are queued behind the kernel on the context's stream and drained by ONE synchronisation
         const int D = obs_dim();
-        if (obs) Backend::d2h(obs, d_obs_, sizeof(double) * N_ * D);
-        if (reward) Backend::d2h(reward, d_reward_, sizeof(double) * N_);
-        if (term) Backend::d2h(term, d_flags_, N_);
-        if (trunc) Backend::d2h(trunc, d_flags_ + N_, N_);
-        if (success) Backend::d2h(success, d_flags_ + 2 * N_, N_);
-        if (info) Backend::d2h(info, d_info_, sizeof(float) * 6 * N_);
-        if (final_obs) Backend::d2h(final_obs, d_final_, sizeof(double) * N_ * D);
-        if (ep_ret) Backend::d2h(ep_ret, d_epret_, sizeof(double) * N_);
-        if (ep_len) Backend::d2h(ep_len, d_eplen_, sizeof(int) * N_);
+        if (obs) Backend::d2h_async(obs, d_obs_, sizeof(double) * N_ * D);
+        if (reward) Backend::d2h_async(reward, d_reward_, sizeof(double) * N_);
+        if (term) Backend::d2h_async(term, d_flags_, N_);
+        if (trunc) Backend::d2h_async(trunc, d_flags_ + N_, N_);
+        if (success) Backend::d2h_async(success, d_flags_ + 2 * N_, N_);
+        if (info) Backend::d2h_async(info, d_info_, sizeof(float) * 6 * N_);
+        if (final_obs) Backend::d2h_async(final_obs, d_final_, sizeof(double) * N_ * D);
+        if (ep_ret) Backend::d2h_async(ep_ret, d_epret_, sizeof(double) * N_);
+        if (ep_len) Backend::d2h_async(ep_len, d_eplen_, sizeof(int) * N_);
+        Backend::sync();
     }
 
     // device-resident boundary: actions / goal indices are device pointers, outputs are written straight into the caller's
     // device buffers (any of them null = the context's own buffer); no host copies, one stream sync before returning
     void step_device(const float* d_act, const int* d_next_goal, const mw_device_out* out) override {
+        need_reset_done("step_device");
+        book_slot_ ^= 1;
         World<T> w = world();
         w.io.act = d_act;
         if (d_next_goal) w.io.next_goal = const_cast<int*>(d_next_goal);
@@ -615,6 +721,7 @@ public:
         Backend::sync();
     }
     void reset_device(const uint8_t* d_mask, const int* d_goal_idx, double* d_obs) override {
+        was_reset_.assign(N_, 1);          // (a device-side mask cannot be inspected here; goal indices are clamped in the kernel)
         World<T> w = world();
         w.io.next_goal = const_cast<int*>(d_goal_idx);
         if (d_obs) w.io.obs = d_obs;
@@ -689,39 +796,61 @@ public:
         Backend::h2d(d_act_, act, sizeof(float) * 4 * N_ * nsteps);
     }
 
-    // bench path: actions already resident on the device; outputs stay on the device
-    void step_device_only(const float* d_act, int nsteps, int act_steps, float* kernel_ms) override {
-        World<T> w = world();
+    // bench path: actions already resident on the device; outputs stay on the device.  With gather = true the per-step
+    // cross-rank bookkeeping all-gather (RCCL, side stream) is part of the loop: the kernel of step k+1 overlaps the
+    // collective of step k (two record slots), and the call returns when both streams have drained.
+    void step_device_only(const float* d_act, int nsteps, int act_steps, float* kernel_ms, bool gather = false) override {
+        need_reset_done("step_resident");
+        if (gather && world_size() > 1 && !comm_) throw std::logic_error("step_resident_gather: call mw_comm_init first");
         const float* base = d_act ? d_act : d_act_;
         Backend::timed_begin();
         for (int s = 0; s < nsteps; s++) {
+            book_slot_ ^= 1;
+            World<T> w = world();
             w.io.act = base + (size_t)(act_steps > 0 ? s % act_steps : 0) * 4 * N_;
-            long long* ticks = d_wave_ticks_;
-            Backend::launch(nblocks_, [w, ticks] MW_LAMBDA(int b, int t, Scratchpad sp) {
-                const long long t0 = ticks ? MW_WALL_CLOCK() : 0;
-                lane_step(w, b, t, sp);
-                if (ticks && t == 0) ticks[b] += MW_WALL_CLOCK() - t0;
-            });
+            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+            if (gather) gather_async();
         }
         float ms = Backend::timed_end();
+        if (gather) Backend::sync_side();
         if (kernel_ms) *kernel_ms = ms;
     }
+    void step_resident_gather(int nsteps, int act_steps, float* kernel_ms) override { step_device_only(nullptr, nsteps, act_steps, kernel_ms, true); }
 
-    // per-workgroup wall-clock ticks of the resident step launches (calibration of the lanes-per-workgroup choice)
-    long long* d_wave_ticks_ = nullptr;
-    int wave_profile(long long* ticks, int* model_of_block, int capacity) override {
-        if (!ticks) {
-            if (!d_wave_ticks_) d_wave_ticks_ = (long long*)Backend::alloc(sizeof(long long) * nblocks_);
-            Backend::zero(d_wave_ticks_, sizeof(long long) * nblocks_);
-            Backend::sync();
-            return nblocks_;
+    // ---- cross-rank bookkeeping ----
+    void comm_init(const void* id128, int rank, int world) override {
+        if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("comm_init: bad rank / world size");
+        Backend::comm_free(comm_); comm_ = nullptr;
+        if (world > 1) comm_ = Backend::comm_init(id128, rank, world);
+        Backend::free(d_book_all_);
+        d_book_all_ = (mw_bookkeeping*)Backend::alloc(sizeof(mw_bookkeeping) * 2 * (size_t)world * N_);
+        Backend::zero(d_book_all_, sizeof(mw_bookkeeping) * 2 * (size_t)world * N_);
+        Backend::sync();
+        cfg.rank = rank; cfg.world_size = world;
+    }
+    mw_bookkeeping* gathered() const { return d_book_all_ + (size_t)book_slot_ * world_size() * N_; }
+    void gather_async() {          // records of the step just queued on the main stream -> every rank, on the side stream
+        const mw_bookkeeping* src = d_book_ + (size_t)book_slot_ * N_;
+        Backend::allgather_side(comm_, src, gathered(), sizeof(mw_bookkeeping) * (size_t)N_, book_slot_);
+    }
+    void gather_bookkeeping(mw_bookkeeping* out, int out_on_device) override {
+        gather_async();
+        const size_t bytes = sizeof(mw_bookkeeping) * (size_t)world_size() * N_;
+        if (out) Backend::copy_side(out, gathered(), bytes, out_on_device != 0);
+        Backend::sync_side();
+    }
+    // TimeLimit._elapsed_steps and curr_path_length of every env := elapsed[i]: env i then truncates (and auto-resets) after
+    // max_episode_steps - elapsed[i] more steps.  Staggers the synchronised auto-reset waves of a freshly reset batch.
+    void set_episode_phase(const int* elapsed) override {
+        for (int i = 0; i < N_; i++) {
+            if (elapsed[i] < 0 || elapsed[i] >= cfg.max_episode_steps) throw std::out_of_range("set_episode_phase: elapsed steps outside [0, max_episode_steps)");
+            set_task_field(groups_[env_group_[i]], env_lane_[i], TK_ELAPSED, elapsed[i]);
+            set_task_field(groups_[env_group_[i]], env_lane_[i], TK_PATHLEN, elapsed[i]);
         }
-        if (!d_wave_ticks_) throw std::runtime_error("wave_profile: not started");
-        if (capacity < nblocks_) throw std::invalid_argument("wave_profile: buffer too small");
-        Backend::d2h(ticks, d_wave_ticks_, sizeof(long long) * nblocks_);
-        if (model_of_block)
-            for (auto& g : groups_) { const int nb = (g.nenv + g.lpb - 1) / g.lpb; for (int b = 0; b < nb; b++) model_of_block[g.block0 + b] = g.model; }
-        return nblocks_;
+    }
+    void status(int* out4, int clear) override {
+        Backend::d2h(out4, d_status_, sizeof(int) * 4);
+        if (clear) { Backend::zero(d_status_, sizeof(int) * 4); Backend::sync(); }
     }
 
     void debug(int what, int n) override {

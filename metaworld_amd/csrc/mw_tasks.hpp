@@ -31,7 +31,8 @@ enum {
     TK_EXTRA = 39,    // task-specific scalars [16]
     TK_SUCCESS = 55,  // last success flag
     TK_PERSIST0 = 56, // 3 reals that survive resets (basketball's drifting goal-site local position)
-    TK_END = 59
+    TK_EPRET_LO = 59, // low part of the episode return (fp32 contexts sum it as a (hi, lo) float pair = in double)
+    TK_END = 60
 };
 static_assert(TK_END <= TASK_NREAL, "task block too small");
 
@@ -1254,7 +1255,7 @@ MW_HD void task_after_reset(const Env<T> e, const TaskDesc<T>& td, V3<T> persist
 template <typename T>
 MW_HD void env_reset(const Env<T> e, const TaskDesc<T>& td, T* obs39) {
     reset_data(e);
-    TK(e, TK_PATHLEN) = 0; TK(e, TK_ELAPSED) = 0; TK(e, TK_EPRET) = 0; TK(e, TK_EPLEN) = 0; TK(e, TK_SUCCESS) = 0;
+    TK(e, TK_PATHLEN) = 0; TK(e, TK_ELAPSED) = 0; TK(e, TK_EPRET) = 0; TK(e, TK_EPRET_LO) = 0; TK(e, TK_EPLEN) = 0; TK(e, TK_SUCCESS) = 0;
     for (int k = 0; k < 16; k++) TK(e, TK_EXTRA + k) = 0;
     const V3<T> persist = tk3(e, TK_PERSIST0);
     task_model_writes(e, td);

@@ -6,7 +6,11 @@
 // mw_common.hpp, so each per-env load/store of a wave is one contiguous request.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <rccl/rccl.h>   // types only: the entry points are resolved with dlsym (struct Rccl)
 
 #include <stdexcept>
 #include <string>
@@ -34,21 +38,66 @@ __global__ void __launch_bounds__(256) k_flat(F f, int n) {
     if (i < n) f(i);
 }
 
+// RCCL entry points, resolved at run time (mw_comm_init): no link-time dependency, and when torch is in the process its
+// already loaded librccl.so.1 is the one that answers (same SONAME), so the library and torch.distributed share one RCCL.
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    static Rccl& get() {
+        static Rccl r;
+        if (!r.handle) {
+            for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
+                if ((r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+            if (!r.handle) throw std::runtime_error(std::string("libmwgpu: cannot load RCCL: ") + dlerror());
+            auto sym = [&](const char* n) { void* p = dlsym(r.handle, n); if (!p) throw std::runtime_error(std::string("RCCL symbol missing: ") + n); return p; };
+            r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+            r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+            r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+            r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+            r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        }
+        return r;
+    }
+    void check(ncclResult_t e, const char* what) const {
+        if (e != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + (GetErrorString ? GetErrorString(e) : "RCCL error"));
+    }
+};
+
+// One stream / event pair / side stream per HIP device, created on first use; every ABI entry selects its context's
+// device first (Backend::use), so contexts on different devices can live in one process.
 struct Backend {
-    static hipStream_t& stream() { static hipStream_t s = nullptr; return s; }
-    static hipEvent_t* events() { static hipEvent_t ev[2] = {nullptr, nullptr}; return ev; }
+    struct Dev { hipStream_t stream = nullptr, side = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr}; int max_lds = 65536, num_cu = 256; bool ready = false; };
+    static constexpr int MAX_DEV = 64;
+    static Dev& dev() { static Dev d[MAX_DEV]; return d[cur()]; }
+    static int& cur() { static thread_local int c = 0; return c; }
+    static hipStream_t& stream() { return dev().stream; }
+    static hipEvent_t* events() { return dev().ev; }
+    static void use(int device) {
+        if (device < 0 || device >= MAX_DEV) throw std::runtime_error("libmwgpu: bad device id");
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        cur() = device;
+    }
     static void init(int device) {
         int n = 0;
         hip_check(hipGetDeviceCount(&n), "hipGetDeviceCount");
         if (n <= 0) throw std::runtime_error("libmwgpu: no HIP device visible (this library has no CPU fallback)");
-        hip_check(hipSetDevice(device), "hipSetDevice");
-        hip_check(hipDeviceGetAttribute(&max_lds(), hipDeviceAttributeMaxSharedMemoryPerBlock, device), "hipDeviceGetAttribute");
-        hip_check(hipDeviceGetAttribute(&num_cu(), hipDeviceAttributeMultiprocessorCount, device), "hipDeviceGetAttribute");
-        if (!stream()) {
-            hip_check(hipStreamCreateWithFlags(&stream(), hipStreamNonBlocking), "hipStreamCreate");
-            hip_check(hipEventCreate(&events()[0]), "hipEventCreate");
-            hip_check(hipEventCreate(&events()[1]), "hipEventCreate");
+        if (device >= n) throw std::runtime_error("libmwgpu: device_id out of range");
+        use(device);
+        Dev& d = dev();
+        if (d.ready) return;
+        hip_check(hipDeviceGetAttribute(&d.max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device), "hipDeviceGetAttribute");
+        hip_check(hipDeviceGetAttribute(&d.num_cu, hipDeviceAttributeMultiprocessorCount, device), "hipDeviceGetAttribute");
+        hip_check(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking), "hipStreamCreate");
+        for (int k = 0; k < 2; k++) {
+            hip_check(hipEventCreate(&d.ev[k]), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&d.xev[k], hipEventDisableTiming), "hipEventCreate");
         }
+        d.ready = true;
     }
     static void* alloc(size_t bytes) { void* p = nullptr; hip_check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc"); return p; }
     static void free(void* p) { if (p) (void)hipFree(p); }
@@ -61,28 +110,31 @@ struct Backend {
         hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream()), "hipMemcpy D2H");
         hip_check(hipStreamSynchronize(stream()), "sync");
     }
+    // queued copies (no sync): a batch of them is drained by one sync()
+    static void d2h_async(void* dst, const void* src, size_t bytes) { hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream()), "hipMemcpy D2H"); }
+    static void h2d_async(void* dst, const void* src, size_t bytes) { hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream()), "hipMemcpy H2D"); }
+    static void* alloc_host(size_t bytes) { void* p = nullptr; hip_check(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault), "hipHostMalloc"); return p; }
+    static void free_host(void* p) { if (p) (void)hipHostFree(p); }
     // LDS per workgroup: everything a CU has when the grid leaves one wave per CU, an equal share when several
     // workgroups must share a CU (the 512-VGPR lane programs allow at most one wave per SIMD, i.e. 4 per CU).
     // MW_LDS_BYTES overrides (experiments / tests of the column-store fallback rows).
-    static int& max_lds() { static int v = 65536; return v; }
-    static int& num_cu() { static int v = 256; return v; }
-    static int compute_units() { return num_cu(); }
+    static int compute_units() { return dev().num_cu; }
     static int lds_bytes(int nblocks) {
         static const char* ov = getenv("MW_LDS_BYTES");
         if (ov) return atoi(ov);
         static const char* wv = getenv("MW_WAVES_PER_CU");   // experiments: 8 = let two waves share a SIMD (256 VGPRs each)
         const int max_per_cu = wv ? atoi(wv) : 4;
-        int per_cu = (nblocks + num_cu() - 1) / num_cu();
+        int per_cu = (nblocks + compute_units() - 1) / compute_units();
         per_cu = per_cu < 1 ? 1 : (per_cu > max_per_cu ? max_per_cu : per_cu);
-        return (max_lds() / per_cu) & ~1023;
+        return (dev().max_lds / per_cu) & ~1023;
     }
     template <class F>
     static void launch(int nblocks, F f) {
-        static int configured = 0;
+        static int configured[MAX_DEV] = {0};
         const int bytes = lds_bytes(nblocks);
-        if (bytes > configured) {
+        if (bytes > configured[cur()]) {
             hip_check(hipFuncSetAttribute((const void*)k_lanes<F>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute(LDS)");
-            configured = bytes;
+            configured[cur()] = bytes;
         }
         hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), bytes, stream(), f, bytes / 4);
         hip_check(hipGetLastError(), "kernel launch");
@@ -100,6 +152,45 @@ struct Backend {
         float ms = 0;
         hip_check(hipEventElapsedTime(&ms, events()[0], events()[1]), "hipEventElapsedTime");
         return ms;
+    }
+    // ---- cross-rank exchange (RCCL over xGMI): one communicator per context, collectives on the device's SIDE stream so
+    //      that the gather of step k overlaps the kernel of step k+1 ----
+    struct Comm { ncclComm_t comm = nullptr; int rank = 0, world = 1; };
+    static void comm_unique_id(void* out128) {
+        ncclUniqueId id;
+        Rccl& r = Rccl::get();
+        r.check(r.GetUniqueId(&id), "ncclGetUniqueId");
+        static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+        memcpy(out128, &id, sizeof(id));
+    }
+    static Comm* comm_init(const void* id128, int rank, int world) {
+        Rccl& r = Rccl::get();
+        ncclUniqueId id;
+        memcpy(&id, id128, sizeof(id));
+        Comm* c = new Comm();
+        c->rank = rank; c->world = world;
+        r.check(r.CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
+        return c;
+    }
+    static void comm_free(Comm* c) { if (c) { if (c->comm) (void)Rccl::get().CommDestroy(c->comm); delete c; } }
+    // side stream waits for everything queued on the main stream so far, then all-gathers `bytes` per rank
+    static void allgather_side(Comm* c, const void* send, void* recv, size_t bytes, int slot) {
+        if (!c) { allgather_side_local(send, recv, bytes, slot); return; }
+        Dev& d = dev();
+        hip_check(hipEventRecord(d.xev[slot & 1], d.stream), "hipEventRecord");
+        hip_check(hipStreamWaitEvent(d.side, d.xev[slot & 1], 0), "hipStreamWaitEvent");
+        Rccl& r = Rccl::get();
+        r.check(r.AllGather(send, recv, bytes, ncclInt8, c->comm, d.side), "ncclAllGather");
+    }
+    static void sync_side() { hip_check(hipStreamSynchronize(dev().side), "hipStreamSynchronize(side)"); }
+    static void allgather_side_local(const void* send, void* recv, size_t bytes, int slot) {   // world size 1: a device copy
+        Dev& d = dev();
+        hip_check(hipEventRecord(d.xev[slot & 1], d.stream), "hipEventRecord");
+        hip_check(hipStreamWaitEvent(d.side, d.xev[slot & 1], 0), "hipStreamWaitEvent");
+        hip_check(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, d.side), "hipMemcpy D2D");
+    }
+    static void copy_side(void* dst, const void* src, size_t bytes, bool dst_on_device) {
+        hip_check(hipMemcpyAsync(dst, src, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, dev().side), "hipMemcpy (side)");
     }
 };
 }  // namespace

@@ -102,7 +102,12 @@ make_ml_envs_test = partial(make_ml_envs, terminate_on_success=True, task_select
 
 def register_mw_envs(namespace="Meta-World-GPU"):
     """Register the vector ids of metaworld/__init__.py:655-823 that sit on the hot path.  No-op (returns False) when
-    gymnasium is not installed.  Unlike the reference's lambdas (`:711-718`), `num_envs` is honoured."""
+    gymnasium is not installed.  Unlike the reference's lambdas (`:711-718`), `num_envs` is honoured.
+
+    `register_mw_envs("Meta-World")` is the opt-in drop-in: it registers the REFERENCE's own ids ("Meta-World/MT50", ...), so an
+    unmodified `gym.make_vec("Meta-World/MT50", seed=..., use_one_hot=True)` resolves to the GPU VectorEnv (call it after, or
+    instead of, `import metaworld`, whose import-time registration `:823` it overrides).  The default namespace keeps both
+    registrations side by side."""
     try:
         from gymnasium.envs.registration import register
     except Exception:
@@ -118,7 +123,9 @@ def register_mw_envs(namespace="Meta-World-GPU"):
         return gen(env_name or bench, seed=seed, meta_batch_size=meta_batch_size, total_tasks_per_cls=total_tasks_per_cls,
                    vector_strategy=vector_strategy, autoreset_mode=autoreset_mode, **kw)
 
-    register(id=f"{namespace}/MT1", vector_entry_point=partial(mt, "MT1"), kwargs={})
+    # "Meta-World/MT1" is a plain (non-vector) entry point in the reference (`:655-667`); here MT1 is a VectorEnv of num_envs
+    # copies of the one task (BASELINE config 2 has no reference spelling), so it is registered as a vector entry point too
+    register(id=f"{namespace}/MT1", vector_entry_point=lambda env_name, **kw: mt(env_name, **kw), kwargs={})
     for b in _MT:
         register(id=f"{namespace}/{b}", vector_entry_point=partial(mt, b), kwargs={})
     for split in ("train", "test"):

@@ -36,6 +36,12 @@ class MwDeviceOut(C.Structure):
                 ("final_obs", C.c_void_p), ("episode_return", C.c_void_p), ("episode_length", C.c_void_p)]
 
 
+# mw_bookkeeping (include/mwgpu.h): 12 bytes per env and step
+BOOKKEEPING_DTYPE = np.dtype([("done", np.uint8), ("success", np.uint8), ("task_id", np.int16), ("episode_return", np.float32),
+                              ("episode_length", np.int32)])
+assert BOOKKEEPING_DTYPE.itemsize == 12
+
+
 class Lib:
     def __init__(self, path, prefix):
         if not os.path.exists(path):
@@ -75,7 +81,12 @@ class Lib:
         f("reset_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
         f("policy_actions", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
         f("policy_rollout", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float))
-        f("wave_profile", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
+        f("step_resident_gather", C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float))
+        f("comm_unique_id", C.c_int, C.c_void_p)
+        f("comm_init", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+        f("gather_bookkeeping", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+        f("status", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+        f("set_episode_phase", C.c_int, C.c_void_p, C.c_void_p)
         f("column_size", C.c_int, C.c_void_p, C.c_int, C.c_char_p)
         f("read", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
         f("write", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
@@ -102,7 +113,7 @@ def load(prefix="mw_", path=None) -> Lib:
 
 EXPORTED_SYMBOLS = ["model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
                     "add_model", "add_task", "set_envs", "finalize", "set_terminate_on_success", "destroy", "last_error", "num_envs", "obs_dim",
-                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "wave_profile", "upload_actions", "step_resident", "column_size", "read", "write", "read_int",
+                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "upload_actions", "step_resident", "step_resident_gather", "comm_unique_id", "comm_init", "gather_bookkeeping", "status", "set_episode_phase", "column_size", "read", "write", "read_int",
                     "debug"]
 
 
@@ -207,15 +218,40 @@ class Context:
                                             ep.ctypes.data, su.ctypes.data, C.byref(ms)))
         return ep, su, ms.value
 
-    def wave_profile_start(self):
-        """mw_wave_profile(NULL): zero the per-workgroup tick counters -> number of workgroups"""
-        return self._check(self.lib.wave_profile(self.ptr, None, None, 0))
+    # ---- cross-rank bookkeeping gather (RCCL inside the library) ----
+    def comm_unique_id(self):
+        """mw_comm_unique_id -> 128 bytes (an ncclUniqueId); create on rank 0, hand the same bytes to every rank"""
+        buf = np.zeros(128, dtype=np.uint8)
+        if self.lib.comm_unique_id(buf.ctypes.data) != 0:
+            raise RuntimeError("mwgpu: cannot create a communicator id (is RCCL loadable?)")
+        return buf
 
-    def wave_profile_read(self, nblocks):
-        """-> (ticks int64 [nblocks] at 100 MHz, model index int32 [nblocks])"""
-        ticks, model = np.zeros(nblocks, dtype=np.int64), np.zeros(nblocks, dtype=np.int32)
-        self._check(self.lib.wave_profile(self.ptr, ticks.ctypes.data, model.ctypes.data, nblocks))
-        return ticks, model
+    def comm_init(self, unique_id, rank, world_size):
+        uid = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)
+        self._check(self.lib.comm_init(self.ptr, None if uid is None else uid.ctypes.data, int(rank), int(world_size)))
+        self.world_size = int(world_size)
+
+    def gather_bookkeeping(self):
+        """mw_gather_bookkeeping -> structured array [world, N] of the LAST step's records on every rank"""
+        out = np.zeros((getattr(self, "world_size", 1), self.N), dtype=BOOKKEEPING_DTYPE)
+        self._check(self.lib.gather_bookkeeping(self.ptr, out.ctypes.data, 0))
+        return out
+
+    def step_resident_gather(self, nsteps):
+        ms = C.c_float(0)
+        self._check(self.lib.step_resident_gather(self.ptr, nsteps, self._resident_steps, C.byref(ms)))
+        return ms.value
+
+    def set_episode_phase(self, elapsed):
+        e = np.ascontiguousarray(elapsed, dtype=np.int32)
+        assert e.shape == (self.N,)
+        self._check(self.lib.set_episode_phase(self.ptr, e.ctypes.data))
+
+    def status(self, clear=False):
+        """mw_status -> dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps)"""
+        out = np.zeros(4, dtype=np.int32)
+        self._check(self.lib.status(self.ptr, out.ctypes.data, int(bool(clear))))
+        return dict(flags=int(out[0]), row_overflow_steps=int(out[1]), contact_overflow_steps=int(out[2]), unstable_steps=int(out[3]))
 
     def upload_actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32)

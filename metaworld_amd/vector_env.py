@@ -81,7 +81,7 @@ class MetaWorldGpuVectorEnv:
                  partially_observable=None, task_select="random", meta_batch_size=None, total_tasks_per_cls=None,
                  recurrent_info_in_obs=False, normalize_reward_in_recurrent_info=True, reward_function_version="v2",
                  reward_normalization_method=None, reward_alpha=0.001, normalize_observations=False, envs_list=None,
-                 lanes_per_block="auto"):
+                 lanes_per_block=None, raise_on_status=False):
         """The keyword set of the reference's `_init_each_env` / `make_ml_envs` (metaworld/__init__.py:398-460, :516-618):
         `task_select` "random" = RandomTaskSelectWrapper, "pseudorandom" = PseudoRandomTaskSelectWrapper;
         `meta_batch_size` / `total_tasks_per_cls` = the ML split of each class's goals over sub-envs (`tasks[i::k]`);
@@ -132,14 +132,7 @@ class MetaWorldGpuVectorEnv:
         for i, name in enumerate(names):
             env_task_names += [name] * (per + (1 if i < rem else 0))
         self.env_task_names = env_task_names
-        # lanes per workgroup of every model group: "auto" = from the measured wave times (lpb_policy.py), None = the runtime's
-        # proxy, or an explicit {model name: lanes}
-        envs_per_model = {}
-        for n in env_task_names:
-            envs_per_model[T.TASK_CONST[n]["model"]] = envs_per_model.get(T.TASK_CONST[n]["model"], 0) + 1
-        if lanes_per_block == "auto":
-            from . import lpb_policy
-            lanes_per_block = lpb_policy.choose(envs_per_model, "fp64" if precision in ("fp64", 1) else "fp32")
+        # lanes per workgroup of every model group: None = the runtime's own choice, or an explicit {model name: lanes}
         self.lanes_per_block = dict(lanes_per_block or {})
         # models and tasks
         model_index, roles_of, reloc_of = {}, {}, {}
@@ -160,6 +153,8 @@ class MetaWorldGpuVectorEnv:
                 goals = T.custom_goal_tables(tuple(names), goal_seed)[name]
             else:
                 goals = T.goal_table(goal_key, name, goal_seed)
+            if total_tasks_per_cls is not None:          # only the first total_tasks_per_cls goals of a class are ever selected
+                goals = goals[:max(1, int(total_tasks_per_cls))]
             self.goal_tables[name] = goals
             ts = T.task_struct(name, model_index[mname], roles_of[mname], reloc_of[mname], onehot_id=oh,
                                partially_observable=self.partially_observable)
@@ -220,6 +215,7 @@ class MetaWorldGpuVectorEnv:
         self.action_space = _box(-np.ones((self.num_envs, 4)), np.ones((self.num_envs, 4)), np.float32)
         self._episode_start = np.full(self.num_envs, time.perf_counter())
         self.closed = False
+        self.raise_on_status = raise_on_status
         assert D == len(lo) - (6 if self.recurrent_info_in_obs else 0)
 
     # ---- RandomTaskSelectWrapper stream (wrappers.py:98-100: self.np_random.choice(len(tasks))) ----
@@ -312,6 +308,9 @@ class MetaWorldGpuVectorEnv:
 
     # ---- VectorEnv API ----
     def reset(self, *, seed=None, options=None):
+        """`seed` is accepted and has no effect, as in the reference: `SawyerXYZEnv.reset` drops it (`super().reset()` is called
+        without it, metaworld/sawyer_xyz_env.py:664-678), so neither the task-selection stream (seeded once by `env.seed(seed)`
+        at construction, metaworld/__init__.py:428-429) nor the goal tables change."""
         mask = np.ones(self.num_envs, dtype=bool)
         self._begin_episodes(mask)
         obs = self._wrap_reset_obs(self.ctx.reset(self._cur_goal).astype(self._raw_dtype), mask)
@@ -320,7 +319,14 @@ class MetaWorldGpuVectorEnv:
         return obs.astype(self.obs_dtype, copy=True), {}
 
     def step(self, actions):
-        obs, rew, term, trunc, succ, info = self.ctx.step(actions, self._next_goal)
+        a = np.asarray(actions)
+        # SawyerXYZEnv.step: `assert len(action) == 4` (metaworld/sawyer_xyz_env.py:591); the vectoriser iterates over the batch
+        assert a.shape == (self.num_envs, 4), f"Actions should be size 4, got {a.shape[1:] if a.ndim > 1 else a.shape}"
+        if (self._cur_goal < 0).any():          # SawyerXYZEnv._get_state_rand_vec without a task (`:699-701`) / step before reset
+            raise RuntimeError("step() called before reset(): no task has been set for some sub-envs")
+        obs, rew, term, trunc, succ, info = self.ctx.step(a, self._next_goal)
+        if self.raise_on_status:
+            self.check_status()
         term_b, trunc_b = term.astype(bool), trunc.astype(bool)
         done = term_b | trunc_b
         obs = obs.astype(self._raw_dtype)
@@ -438,6 +444,23 @@ class MetaWorldGpuVectorEnv:
             self._look_ahead(np.ones(self.num_envs, dtype=bool))
             return (None,) * self.num_envs
         return self.get_attr(name)
+
+    # ---- run-time status (no reference counterpart; SURVEY.md 5 "failure detection") ----
+    def status(self, clear=False):
+        """dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps) accumulated since the last clear: flag 1 / 2 =
+        the constraint-row / contact capacity of a scene (metaworld_amd/data/model_caps.json) was exceeded and rows / contacts
+        were DROPPED; 4 = a non-finite state was caught and the env reset (the intent of sawyer_xyz_env.py:603-619)."""
+        return self.ctx.status(clear)
+
+    def check_status(self):
+        st = self.ctx.status(clear=True)
+        if st["flags"] & 3:
+            raise RuntimeError(f"contact / constraint-row capacity exceeded, results differ from the reference: {st} "
+                               "(raise maxcon / maxefc)")
+        if st["flags"] & 4:
+            import warnings
+            warnings.warn(f"non-finite simulation state caught; the affected envs were truncated and reset: {st}")
+        return st
 
     def bookkeeping(self):
         """[N, 5] float64 record (done, success, task_id, episode_return, episode_length) of the last step:

@@ -531,7 +531,23 @@ def _make_gymnasium(mujoco_mod):
 
     envs_mujoco.MujocoEnv = MujocoEnv
     envs.mujoco = envs_mujoco
-    registration.register = lambda *a, **k: None
+    # minimal registry: what `register(id, entry_point=..., vector_entry_point=..., kwargs=...)` / `gym.make_vec(id, num_envs=..., **kw)`
+    # do for a spec that has a vector entry point (gymnasium 1.1 `make_vec`: `env_creator(num_envs=num_envs, **spec_kwargs)`)
+    registration.registry = {}
+
+    def _register(id, entry_point=None, vector_entry_point=None, kwargs=None, **_ignored):
+        registration.registry[id] = dict(entry_point=entry_point, vector_entry_point=vector_entry_point, kwargs=dict(kwargs or {}))
+
+    def _make_vec(id, num_envs=None, vectorization_mode=None, vector_kwargs=None, wrappers=None, **kwargs):
+        spec = registration.registry.get(id)
+        if spec is None:
+            raise KeyError(f"Environment `{id}` doesn't exist.")
+        if spec["vector_entry_point"] is None:
+            raise NotImplementedError("the gymnasium stand-in only builds specs that have a vector_entry_point")
+        kw = dict(spec["kwargs"]); kw.update(kwargs)
+        return spec["vector_entry_point"](num_envs=num_envs, **kw)
+
+    registration.register = _register
     envs.registration = registration
 
     # ---- vector: SyncVectorEnv with SAME_STEP / NEXT_STEP autoreset (dict-of-arrays infos) ----
@@ -630,7 +646,8 @@ def _make_gymnasium(mujoco_mod):
     gym.Env, gym.Wrapper, gym.ObservationWrapper = Env, Wrapper, ObservationWrapper
     gym.spaces, gym.utils, gym.envs, gym.wrappers, gym.vector = spaces, utils, envs, wrappers, vector
     gym.Space = Space
-    gym.make = gym.make_vec = _unsupported
+    gym.make = _unsupported
+    gym.make_vec, gym.register = _make_vec, _register
     gym.__version__ = "1.1-oracle-standin"
     mods = {"gymnasium": gym, "gymnasium.spaces": spaces, "gymnasium.utils": utils,
             "gymnasium.utils.seeding": seeding, "gymnasium.utils.ezpickle": ezpickle, "gymnasium.envs": envs,

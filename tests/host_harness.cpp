@@ -2,8 +2,15 @@
 // the GPU (metaworld_amd/csrc/*.hpp) for the host, with a plain loop over (block, thread) standing in for
 // the wavefronts, so that the kernel logic can be checked against the oracle in a container without a GPU.
 // Exports the ABI of include/mwgpu.h under the prefix mwh_.  Never loaded by the product path.
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -16,6 +23,53 @@
 namespace {
 struct Backend {
     static void init(int) {}
+    static void use(int) {}
+    static void d2h_async(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+    static void h2d_async(void* d, const void* s, size_t n) { std::memcpy(d, s, n); }
+    // Cross-rank exchange of the harness: the ranks are processes on one host, the "collective" is a POSIX shared-memory
+    // segment named by the 128-byte id (tests/test_multirank_gloo.py hands the id from rank 0 to the others over gloo,
+    // exactly as the RCCL unique id travels in the product path).
+    struct Shm { std::atomic<int> count, gen; };
+    struct Comm { int rank = 0, world = 1; char* base = nullptr; size_t cap = 1 << 20; std::string name; };
+    static void comm_unique_id(void* out128) {
+        static int counter = 0;
+        std::memset(out128, 0, 128);
+        std::snprintf((char*)out128, 128, "/mwh_%d_%d", (int)getpid(), counter++);
+    }
+    static Comm* comm_init(const void* id128, int rank, int world) {
+        Comm* c = new Comm();
+        c->rank = rank; c->world = world; c->name = (const char*)id128;
+        const size_t total = sizeof(Shm) + c->cap * world;
+        int fd = shm_open(c->name.c_str(), O_CREAT | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)total) != 0) throw std::runtime_error("host harness: shm_open failed");
+        c->base = (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (c->base == (char*)MAP_FAILED) throw std::runtime_error("host harness: mmap failed");
+        return c;          // a fresh segment is zero-filled: count = gen = 0
+    }
+    static void comm_free(Comm* c) {
+        if (!c) return;
+        if (c->base) munmap(c->base, sizeof(Shm) + c->cap * c->world);
+        if (c->rank == 0) shm_unlink(c->name.c_str());
+        delete c;
+    }
+    static void barrier(Comm* c) {
+        Shm* h = (Shm*)c->base;
+        const int g = h->gen.load();
+        if (h->count.fetch_add(1) + 1 == c->world) { h->count.store(0); h->gen.fetch_add(1); }
+        else while (h->gen.load() == g) sched_yield();
+    }
+    static void allgather_side(Comm* c, const void* send, void* recv, size_t bytes, int) {
+        if (!c) { std::memcpy(recv, send, bytes); return; }
+        if (bytes > c->cap) throw std::runtime_error("host harness: all-gather block larger than the shared segment");
+        char* data = c->base + sizeof(Shm);
+        std::memcpy(data + c->cap * c->rank, send, bytes);
+        barrier(c);
+        for (int r = 0; r < c->world; r++) std::memcpy((char*)recv + bytes * r, data + c->cap * r, bytes);
+        barrier(c);
+    }
+    static void sync_side() {}
+    static void copy_side(void* d, const void* s, size_t n, bool) { std::memcpy(d, s, n); }
     static void* alloc(size_t bytes) { return std::malloc(bytes ? bytes : 16); }
     static void free(void* p) { std::free(p); }
     static void zero(void* p, size_t bytes) { std::memset(p, 0, bytes); }

@@ -1,0 +1,115 @@
+"""Parity at the BASELINE.json sizes (MT50 @ 4096 envs and MT10 @ 10 240 envs, built exactly as bench.py builds them: the
+runtime's own lanes-per-workgroup choice per scene, one-hot on, fp64 = the headline precision).  The golden traces cannot be
+replayed at this size, so the full-size batch is tied to what IS pinned at small size:
+  (a) one env per task, taken from the big batch, must reproduce -- to summation-order accuracy -- a small MT1 batch of the
+      same (task, goal, action stream), the configuration the per-task golden-trace tests pin against the reference Python;
+  (b) after ~50 steps of random actions, the oracle engine (oracle/mjl_core.c) synchronised to the device state of one env per
+      task must produce the same next physics step (qpos / qvel to 1e-9 / 1e-7, identical contact and constraint-row counts);
+  (c) no capacity-overflow / instability flag may be raised anywhere in the batch.
+"""
+import numpy as np
+import pytest
+
+from metaworld_amd import tasks as T
+from tests.helpers import WELD
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [("MT50", 4096), ("MT10", 10240)]
+
+
+def _oracle_synced_to(ctx, e, task):
+    from oracle.mjlite import OracleData, OracleModel
+    mname = T.TASK_CONST[task]["model"]
+    pk, roles, reloc = T.packed_model(mname)
+    om = OracleModel(T.compiled_model(mname))
+    om.view("eq_data")[:] = WELD
+    rel = ctx.read(e, "reloc")
+    bp = om.view("body_pos").reshape(-1, 3)
+    for b, slot in enumerate(pk["ints"]["body_relocid"]):
+        if slot >= 0:
+            bp[b] = rel[3 * slot:3 * slot + 3]
+    d = OracleData(om)
+    d.qpos[:] = ctx.read(e, "qpos"); d.qvel[:] = ctx.read(e, "qvel"); d.qacc_warmstart[:] = ctx.read(e, "warm")
+    d.mocap_pos[:] = ctx.read(e, "mocap"); d.mocap_quat[:] = [1, 0, 1, 0]; d.ctrl[:] = ctx.read(e, "ctrl")
+    return om, d
+
+
+@pytest.mark.parametrize("bench,n", CONFIGS)
+def test_fullsize_batch_matches_small_batches_and_oracle(gpulib, bench, n):
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    big = MetaWorldGpuVectorEnv(bench, num_envs=n, seed=42, use_one_hot=True, precision="fp64", lib=gpulib)
+    obs, _ = big.reset()
+    names = big.task_list
+    first = {name: big.env_task_names.index(name) for name in names}          # one env per task
+    acts = np.random.default_rng(5).uniform(-1, 1, (60, n, 4)).astype(np.float32)
+    NS = 12
+    rec = []
+    for t in range(NS):
+        o, r, te, tr, infos = big.step(acts[t])
+        rec.append((o.copy(), r.copy(), infos["success"].copy(), np.stack([infos[k] for k in
+                    ("near_object", "grasp_success", "grasp_reward", "in_place_reward", "obj_to_target", "unscaled_reward")], 1)))
+    assert big.status()["flags"] == 0
+    # (a) the same (task, goal, actions) in a small MT1 batch
+    worst = {}
+    for name, e in first.items():
+        small = MetaWorldGpuVectorEnv("MT1", name, num_envs=2, seed=42, precision="fp64", lib=gpulib)
+        o0 = small.ctx.reset(np.array([big._cur_goal[e]] * 2, dtype=np.int32)).copy()
+        assert np.abs(o0[0] - obs[e, :39]).max() < 1e-6, name            # (the big batch returns float32 one-hot observations)
+        eo = er = ei = 0.0
+        for t in range(NS):
+            o, r, te, tr, su, info = small.ctx.step(np.stack([acts[t, e]] * 2))
+            eo = max(eo, np.abs(o[0] - rec[t][0][e, :39]).max()); er = max(er, abs(r[0] - rec[t][1][e]))
+            ei = max(ei, np.abs(info[0] - rec[t][3][e]).max())
+            assert su[0] == rec[t][2][e], (name, t)
+        small.close()
+        worst[name] = (eo, er, ei)
+        # float32 observation dtype of the one-hot space (metaworld/wrappers.py:27-29) bounds the comparison at ~1e-7
+        assert eo < 2e-6 and er < 1e-7 and ei < 1e-5, (name, worst[name])
+    # (b) oracle one substep-batch from the synchronised device state, deep into contact-rich motion
+    for t in range(NS, 60):
+        big.ctx.step(acts[t], big._next_goal)
+    assert big.status()["flags"] == 0
+    synced = {name: _oracle_synced_to(big.ctx, e, name) for name, e in first.items()}
+    big.ctx.debug("substeps", 5)
+    for name, e in first.items():
+        om, d = synced[name]
+        d.step(5)
+        ic = big.ctx.read_int(e, "icount")
+        assert ic[0] == d.ncon and ic[1] == d.nefc, (name, ic[:2], d.ncon, d.nefc)
+        assert np.abs(big.ctx.read(e, "qpos") - d.qpos).max() < 1e-9, name
+        assert np.abs(big.ctx.read(e, "qvel") - d.qvel).max() < 1e-7, name
+    big.close()
+
+
+def test_fullsize_gather_and_status_through_the_abi(gpulib):
+    """MT50 @ 4096: the per-step bookkeeping record of the resident loop (world size 1: no communicator needed) and the status word"""
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    env = MetaWorldGpuVectorEnv("MT50", num_envs=4096, seed=1, use_one_hot=True, precision="fp32", lib=gpulib, max_episode_steps=25)
+    env.reset()
+    env.ctx.upload_actions(np.random.default_rng(0).uniform(-1, 1, (8, 4096, 4)).astype(np.float32))
+    env.ctx.step_resident_gather(25)
+    book = env.ctx.gather_bookkeeping()
+    assert book.shape == (1, 4096) and (book["done"] == 1).all() and (book["episode_length"] == 25).all()
+    ids = np.array([T.TASK_CONST[n]["id"] for n in env.env_task_names])
+    assert (book["task_id"][0] == ids).all() and np.isfinite(book["episode_return"]).all() and (book["episode_return"] >= 0).all()
+    assert env.status()["flags"] == 0
+    # an RCCL communicator of one rank works too (the driver's 1-GPU box): same records
+    env.ctx.comm_init(env.ctx.comm_unique_id(), 0, 1)
+    env.ctx.step_resident_gather(3)
+    b2 = env.ctx.gather_bookkeeping()
+    assert (b2["episode_length"] == 3).all() and (b2["done"] == 0).all()
+    env.close()
+
+
+def test_staggered_episode_phases(gpulib):
+    """mw_set_episode_phase: env i truncates after max_episode_steps - elapsed[i] steps (bench.py's whole-episode sampling)"""
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    env = MetaWorldGpuVectorEnv("MT1", "reach-v3", num_envs=64, seed=0, precision="fp32", lib=gpulib, max_episode_steps=16)
+    env.reset()
+    env.ctx.set_episode_phase(np.arange(64, dtype=np.int32) % 16)
+    a = np.zeros((64, 4), dtype=np.float32)
+    for t in range(1, 17):
+        o, r, te, tr, su, info = env.ctx.step(a)
+        assert (tr.astype(bool) == ((np.arange(64) % 16) == (16 - t) % 16)).all(), t
+    env.close()

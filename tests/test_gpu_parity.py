@@ -76,16 +76,21 @@ def test_gpu_task_matches_reference_trace(gpulib, task):
         G = {k: (v[:1] if getattr(v, "ndim", 0) >= 1 and len(v) == len(G["goal_idx"]) and k != "rand_vecs" else v) for k, v in G.items()}
     env = make_env(gpulib, task, n=len(G["goal_idx"]), precision="fp64")
     r = replay_trace(env, G, sync=True, steps=30)
+    st = env.status()
     env.close()
     tol_obs, tol_rew = TOL.get(task, (1e-5, 1e-5))
-    assert r["reset"] < 1e-4 and r["obs"] < tol_obs and r["reward"] < tol_rew and r["success_mismatch"] == 0, r
+    assert r["reset"] < 1e-9 and r["obs"] < tol_obs and r["reward"] < tol_rew and r["success_mismatch"] == 0, r
+    # info = near_object, grasp_success, grasp_reward, in_place_reward, obj_to_target, unscaled_reward (float32 at the ABI)
+    assert r["info"] < max(2e-5, tol_rew), r
+    assert st["flags"] == 0, st
 
 
 # (peg-unplug-side-v3 is excluded: the peg wedged in its hole is ill-conditioned -- the solver's converged point moves by
 # 1e-5 with the summation order, on the host harness with MW_NSUB=1 vs 8 just the same; it is a TOL exception already)
 @pytest.mark.parametrize("task", T.ALL_V3)
 def test_gpu_task_fp32_close_to_reference_trace(gpulib, task):
-    """The precision bench.py runs in: success flags exact, obs / reward within the fp32 contact-geometry floor."""
+    """The fp32 throughput mode (NOT the headline: bench.py's `value` is fp64): success flags exact, obs / reward within the fp32
+    contact-geometry floor (1e-5 on 28/50 tasks, 1e-2 on all)."""
     G = dict(golden(f"trace_{task}_seed42.npz"))
     if task == "basketball-v3":
         G = {k: (v[:1] if getattr(v, "ndim", 0) >= 1 and len(v) == len(G["goal_idx"]) and k != "rand_vecs" else v) for k, v in G.items()}

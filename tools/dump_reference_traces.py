@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""Pin the engine against the REAL reference stack: if `mujoco`, `gymnasium` and `metaworld` import --
+the genuine wheels, not the stand-ins of oracle/refshim.py -- record (seed, actions) -> (qpos, qvel, mocap, warmstart, obs,
+reward, success, info) traces of every v3 task in exactly the format of tests/golden/trace_*.npz (tools/gen_golden.py) into
+tests/golden_mujoco/.  tests/test_mujoco_pin.py replays them (one step from a synchronised state, like the golden-trace tests)
+on the host build and on the GPU, and skips while the directory is empty.
+
+This container and the GPU box have no mujoco wheel and no network, so the engine's parity with MuJoCo 3.3.0 is UNPINNED until
+someone runs this script where `pip install mujoco==3.3.0 gymnasium metaworld` works:
+
+    python tools/dump_reference_traces.py            # all 50 tasks, 4 episodes x 60 steps each, ~2 MB
+    python -m pytest tests/test_mujoco_pin.py -q     # then: does the engine reproduce MuJoCo?
+
+It also prints what the reference's own >= 0.8 scripted-policy gate
+(tests/metaworld/envs/mujoco/sawyer_xyz/test_scripted_policies.py:35) gives per task on the real engine -- the number this
+repo's engine must match (basketball-v3 in particular)."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def real_stack_available():
+    """True only for the genuine mujoco / gymnasium / metaworld (the stand-ins mark themselves)"""
+    try:
+        import gymnasium
+        import mujoco
+        import metaworld  # noqa: F401
+    except Exception as ex:          # ModuleNotFoundError here and on the GPU box
+        return False, f"{type(ex).__name__}: {ex}"
+    if "standin" in getattr(gymnasium, "__version__", "") or not hasattr(mujoco, "mj_versionString"):
+        return False, "the modules in sys.modules are the oracle/refshim.py stand-ins"
+    return True, f"mujoco {mujoco.mj_versionString()}, gymnasium {gymnasium.__version__}"
+
+
+def policy_gate(name, seed=42, goals=50):
+    """the reference's own test, verbatim logic: fraction of the 50 goals the scripted policy solves within 500 steps"""
+    import metaworld
+    from metaworld.policies import ENV_POLICY_MAP
+    mt1 = metaworld.MT1(name, seed=seed)
+    env = mt1.train_classes[name]()
+    env.seed(seed)
+    p = ENV_POLICY_MAP[name]()
+    done = 0
+    for task in mt1.train_tasks[:goals]:
+        env.set_task(task)
+        obs, _ = env.reset()
+        for _ in range(500):
+            obs, _, trunc, term, info = env.step(p.get_action(obs))
+            if int(info["success"]) == 1:
+                done += 1
+                break
+            if trunc or term:
+                break
+    return done / goals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tasks", nargs="*")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--episodes", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden_mujoco"))
+    ap.add_argument("--gate", action="store_true", help="also run the >= 0.8 scripted-policy gate per task (slow)")
+    args = ap.parse_args()
+    ok, why = real_stack_available()
+    if not ok:
+        print(f"dump_reference_traces: the real reference stack is not importable ({why}); nothing written.")
+        return 2
+    print("recording with", why)
+    from tools.gen_golden import run_task          # same recorder, real engine underneath
+    from metaworld_amd import tasks as T
+    os.makedirs(args.out, exist_ok=True)
+    for name in args.tasks or T.ALL_V3:
+        rng = np.random.default_rng(args.seed)
+        res = run_task(name, args.seed, args.episodes, args.steps, "mixed", rng)
+        path = os.path.join(args.out, f"trace_{name}_seed{args.seed}.npz")
+        np.savez_compressed(path, **res)
+        line = f"{name:32s} -> {path} success steps {int(res['success'].sum())}"
+        if args.gate:
+            line += f"  scripted-policy gate {policy_gate(name, args.seed):.2f}"
+        print(line, flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

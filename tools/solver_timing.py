@@ -16,9 +16,10 @@ lib = native.load("mw_", os.path.join(ROOT, "metaworld_amd", "libmwgpu_timing.so
 n = int(sys.argv[1])
 win = int(os.environ.get("MW_WIN", "50"))
 nwin = int(os.environ.get("MW_NWIN", "4"))
+prec = os.environ.get("MW_PREC", "fp32")
 names = ["warm", "Hasm", "chol", "MvJv", "lsrch", "update", "n_ls", "n_newt", "kin", "crb", "coll", "cons", "smooth", "solve"]
 for task in sys.argv[2:]:
-    env = MetaWorldGpuVectorEnv("MT1", task, num_envs=n, seed=0, precision="fp32", lib=lib)
+    env = MetaWorldGpuVectorEnv("MT1", task, num_envs=n, seed=0, precision=prec, lib=lib)
     env.reset()
     env.ctx.upload_actions(np.random.default_rng(0).uniform(-1, 1, (64, n, 4)).astype(np.float32))
     for w in range(nwin):
