@@ -84,7 +84,8 @@ def _full_step_port(task_names, seconds):
     lib = native.load("mwh_", so)
     n = 4 * (os.cpu_count() or 1)
     n = max(n, len(task_names))
-    os.environ.setdefault("MW_NSUB", "1")
+    old_nsub = os.environ.get("MW_NSUB")
+    os.environ["MW_NSUB"] = "1"          # (host harness knob: no emulated sub-lanes -- one plain lane program per env and core)
     # the task mix as a custom MT benchmark with 2 goals per task (every goal costs one faithful 500-substep reset on the host)
     env = MetaWorldGpuVectorEnv("custom-mt", envs_list=list(task_names), num_envs=n, seed=1, precision="fp64", lib=lib,
                                 use_one_hot=len(task_names) > 1, total_tasks_per_cls=2)
@@ -96,6 +97,10 @@ def _full_step_port(task_names, seconds):
         steps += 1
     dt = time.perf_counter() - t0
     env.close()
+    if old_nsub is None:
+        del os.environ["MW_NSUB"]
+    else:
+        os.environ["MW_NSUB"] = old_nsub
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": os.cpu_count() or 1,
             "sample": f"{n} envs x {steps} full steps (physics + obs + reward + wrappers, host build of the lane programs, OpenMP) in {dt:.1f}s"}
 

@@ -317,6 +317,7 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
         int best = 0;
         T bd = T(-1e30);
         if (s.hill) {
+            MW_COUNT(3)
             // steepest-ascent walk over the hull graph (MuJoCo's mesh-graph support): from the previous result on this
             // shape, else from the best of the fixed start candidates; strict improvement only.  An exhaustive scan
             // of the 884-vertex gripper hull cost ~20k cycles per call; the walk visits a few dozen vertices.
@@ -335,6 +336,7 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
                 }
             }
             for (int it = 0; it < s.nvert; it++) {
+                MW_COUNT(4)
                 int nxt = cur;
                 const int j0 = s.nbradr[cur], j1 = s.nbradr[cur + 1];
                 for (int jb = j0; jb < j1; jb += 8) {        // neighbours in batches of 8: ids, then coordinates, issued together
@@ -354,10 +356,18 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
             s.hint = cur;
             best = cur;
         } else {
-#pragma unroll 4
-            for (int i = 0; i < s.nvert; i++) {
-                const T dd = s.vert[3 * i] * dl.x + s.vert[3 * i + 1] * dl.y + s.vert[3 * i + 2] * dl.z;
-                if (dd > bd + tie) { bd = dd; best = i; }
+            // exhaustive scan of a small hull (<= 64 vertices) in batches of 16: the 48 coordinate loads of a batch are issued
+            // back to back and waited for once (a 4-vertex batch spent most of a support call in 16 dependent round trips)
+            for (int i0 = 0; i0 < s.nvert; i0 += 16) {
+                T dd[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int i = i0 + q < s.nvert ? i0 + q : s.nvert - 1;
+                    dd[q] = s.vert[3 * i] * dl.x + s.vert[3 * i + 1] * dl.y + s.vert[3 * i + 2] * dl.z;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    if (i0 + q < s.nvert && dd[q] > bd + tie) { bd = dd[q]; best = i0 + q; }
             }
         }
         pl = mv3(s.vert + 3 * best);
@@ -399,6 +409,7 @@ MW_HD void tri_closest_origin(V3<T> a, V3<T> b, V3<T> c, T* w) {
 template <typename T>
 MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V3<T>* v0_override = nullptr) {
     const T tol = sizeof(T) == 8 ? T(1e-10) : T(2e-6);
+    MW_COUNT(5)
     SV<T> v0, v1, v2, v3_, v4;
     v0.a = A.pos; v0.b = B.pos; v0.v = v0.b - v0.a;
     if (v0_override) v0.v = *v0_override;
@@ -433,6 +444,7 @@ MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V
         dir = normalized(cross(v2.v - v1.v, v3_.v - v1.v), &len);
         if (len == 0) break;
         if (dot(dir, v1.v) >= 0) hit = true;
+        MW_COUNT(6)
         v4 = msupport(A, B, dir);
         const T dv4 = dot(v4.v, dir);
         if (dv4 < 0 && !hit) return 0;
@@ -593,6 +605,7 @@ MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, H
     const Shape<T> ua = UNIFORM ? a_.uniform() : a_, ub = UNIFORM ? b_.uniform() : b_;
     if (UNIFORM) margin = mw_uniform(margin);
     const int t1 = ua.type, t2 = ub.type;
+    MW_COUNT(7)
     int n = -1;
     if (t1 == G_PLANE) n = plane_x(ua, ub, margin, h);
     else if (t1 == G_SPHERE) n = sphere_x(ua, ub, margin, h);
@@ -712,7 +725,7 @@ MW_STAGE_FN void collision(const Env<T> e_) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int npair = m.sz.npair, maxcon = m.sz.maxcon;
-    int ncon = 0, flags = 0;
+    int ncon = 0, flags = 0, want = 0;
     if (e.nsub == 1) {
         for (int p = 0; p < npair; p++) {
             if (!pair_near(e, p)) continue;
@@ -723,6 +736,7 @@ MW_STAGE_FN void collision(const Env<T> e_) {
             if (cnt <= 0) continue;
             append_contacts(e, p, cnt, h, ncon, maxcon);
             ncon += cnt;
+            want += cnt;
             if (ncon > maxcon) { ncon = maxcon; flags |= 2; }
         }
     } else {
@@ -759,10 +773,12 @@ MW_STAGE_FN void collision(const Env<T> e_) {
                 if (n[MW_SLOT(sub)] > 0) append_contacts(e, pp[MW_SLOT(sub)], n[MW_SLOT(sub)], h[MW_SLOT(sub)], ncon + off[MW_SLOT(sub)], maxcon);
             }
             ncon += total;
+            want += total;
             if (ncon > maxcon) { ncon = maxcon; flags |= 2; }
         }
     }
     e.I(L.icount) = ncon;
+    if (want > e.I(L.icount + IC_WANT_CON)) e.I(L.icount + IC_WANT_CON) = want;
     if (flags) e.I(L.icount + 3) |= flags;
     MW_SYNC();
 }

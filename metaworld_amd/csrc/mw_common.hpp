@@ -95,6 +95,8 @@ constexpr int CON_ISTRIDE = 4;   // ints per contact record
 constexpr int EFC_EXTRA = 11;    // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv, fri, info, state
 constexpr int SR_N = 8;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force, block list
 constexpr int IC_NBLK = 18;      // icount slot: number of constraint blocks (single rows / contact cones)
+constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 20 / 21 demand
+constexpr int IC_WANT_CON = 20, IC_WANT_EFC = 21;   // running maxima of the contacts / constraint rows a step WANTED (capacity planning)
 constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a non-zero Jacobian entry
 
 struct Sizes {
@@ -164,7 +166,7 @@ inline Layout make_layout(const Sizes& s) {
     L.efcX = take(EFC_EXTRA * s.maxefc);
     L.nreal = o;
     o = 0;
-    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(20); L.iwork = take(3 * s.maxefc); L.ipair = take(s.npair > 0 ? s.npair : 1);   // + 16 phase timers (MW_SOLVER_TIMING builds): 8 solver phases, 6 pipeline stages
+    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(IC_SIZE); L.iwork = take(3 * s.maxefc); L.ipair = take(s.npair > 0 ? s.npair : 1);   // + 16 phase timers (MW_SOLVER_TIMING builds): 8 solver phases, 6 pipeline stages
     L.nint = o;
     return L;
 }

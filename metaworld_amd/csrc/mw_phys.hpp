@@ -581,7 +581,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    int nefc = 0, nblk = 0, nwork = 0, flags = 0;
+    int nefc = 0, nblk = 0, nwork = 0, flags = 0, want = 0;
     const int maxefc = m.sz.maxefc;
     auto work = [&](int kind, int id, int r0) {
         e.I(L.iwork + 3 * nwork) = kind; e.I(L.iwork + 3 * nwork + 1) = id; e.I(L.iwork + 3 * nwork + 2) = r0;
@@ -589,6 +589,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
     };
     // ---- weld(mocap, hand): 3 translational + 3 rotational rows ----
     for (int q = 0; q < m.sz.neq; q++) {
+        want += 6;
         if (nefc + 6 > maxefc) { flags |= 1; continue; }
         work(C_EQUALITY, q, nefc);
         for (int k = 0; k < 6; k++) IEFC(e, nblk + k, 2) = nefc + k;
@@ -601,6 +602,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
         for (int side = -1; side <= 1; side += 2) {
             const T dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - q);
             if (dist < margin) {
+                want += 1;
                 if (nefc + 1 > maxefc) { flags |= 1; continue; }
                 work(C_LIMIT, 2 * j + (side > 0), nefc);
                 IEFC(e, nblk, 2) = nefc;
@@ -615,6 +617,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
         const int dim = ICON(e, c, 2);
         int adr = -1;
         if (dist < inc) {
+            want += dim;
             if (nefc + dim > maxefc) flags |= 1;
             else {
                 adr = nefc;
@@ -627,6 +630,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
     }
     e.I(L.icount + 1) = nefc;
     e.I(L.icount + IC_NBLK) = nblk;
+    if (want > e.I(L.icount + IC_WANT_EFC)) e.I(L.icount + IC_WANT_EFC) = want;
     if (flags) e.I(L.icount + 3) |= flags;
     MW_SYNC();
     MW_SUBS(e, sub) {

@@ -865,7 +865,7 @@ public:
             {"reloc", L.reloc, 3 * (s.nreloc > 0 ? s.nreloc : 1)}, {"time", L.time, 1}, {"task", L.task, TASK_NREAL}, {"state", 0, L.nstate},
             {"xpos", L.xpos, 3 * s.nbody}, {"xquat", L.xquat, 4 * s.nbody}, {"xmat", L.xmat, 9 * s.nbody}, {"xipos", L.xipos, 3 * s.nbody},
             {"geom_xpos", L.geom_xpos, 3 * s.ngeom}, {"geom_xmat", L.geom_xmat, 9 * s.ngeom}, {"cdof", L.cdof, 6 * s.nv},
-            {"qM", L.qM, s.nv * s.nv}, {"qL", L.qL, s.nv * s.nv}, {"bias", L.bias, s.nv}, {"smooth", L.smooth, s.nv},
+            {"qM", L.qM, s.nv * s.nv}, {"qL", L.qL, s.nv * s.nv}, {"qH", L.qH, s.nv * s.nv}, {"bias", L.bias, s.nv}, {"smooth", L.smooth, s.nv},
             {"qacc_smooth", L.qacc_smooth, s.nv}, {"qfrc_constraint", L.qfrc_c, s.nv}, {"qacc", L.qacc, s.nv},
             {"con", L.con, CON_STRIDE * s.maxcon}, {"efcJ", L.efcJ, s.nv * s.maxefc}, {"efcX", L.efcX, EFC_EXTRA * s.maxefc}};
         for (auto& e : tab) if (k == e.name) { *n = e.n; return e.off; }
@@ -874,7 +874,7 @@ public:
     static int ioffset_of(const Layout& L, const Sizes& s, const std::string& k, int* n) {
         if (k == "icon") { *n = CON_ISTRIDE * s.maxcon; return L.icon; }
         if (k == "iefc") { *n = EFC_ISTRIDE * s.maxefc; return L.iefc; }
-        if (k == "icount") { *n = 20; return L.icount; }
+        if (k == "icount") { *n = IC_SIZE; return L.icount; }
         throw std::runtime_error("unknown int column " + k);
     }
     int layout_size(int gid, const char* what) override {

@@ -190,7 +190,7 @@ def model_probes(model_name):
 
 
 with open(os.path.join(_HERE, "data", "model_caps.json")) as _f:
-    MODEL_CAPS = json.load(_f)     # per-model contact / constraint-row capacities (measured maxima x 1.5, tools/measure_caps)
+    MODEL_CAPS = json.load(_f)     # per-model contact / constraint-row capacities: 2 x the demand measured on the GPU over whole episodes of random actions at MT50 @ 4096 (tools/measure_caps_gpu.py)
 
 
 def packed_model(model_name, maxcon=None, maxefc=None, **kw):

@@ -76,7 +76,7 @@ class MetaWorldGpuVectorEnv:
     metadata = {"autoreset_mode": "SameStep", "render_modes": []}
 
     def __init__(self, benchmark="MT1", env_name=None, num_envs=None, seed=None, use_one_hot=False,
-                 max_episode_steps=None, terminate_on_success=False, precision="fp32", device_id=0,
+                 max_episode_steps=None, terminate_on_success=False, precision="fp64", device_id=0,
                  rank=0, world_size=1, goal_seed=42, task_names=None, lib=None, maxcon=None, maxefc=None,
                  partially_observable=None, task_select="random", meta_batch_size=None, total_tasks_per_cls=None,
                  recurrent_info_in_obs=False, normalize_reward_in_recurrent_info=True, reward_function_version="v2",
@@ -86,7 +86,10 @@ class MetaWorldGpuVectorEnv:
         `task_select` "random" = RandomTaskSelectWrapper, "pseudorandom" = PseudoRandomTaskSelectWrapper;
         `meta_batch_size` / `total_tasks_per_cls` = the ML split of each class's goals over sub-envs (`tasks[i::k]`);
         `recurrent_info_in_obs` = RNNBasedMetaRLWrapper; `reward_normalization_method` / `normalize_observations` = the
-        normalisation wrappers.  Only the v2 reward functions have device code."""
+        normalisation wrappers.  Only the v2 reward functions have device code.
+        `precision`: "fp64" (default) = the reference's own arithmetic (float64 state, solver, observations): the mode whose GPU
+        tests hold obs / reward <= 1e-5 against the reference traces; "fp32" is the opt-in throughput mode (success flags exact,
+        obs / reward within the single-precision contact-geometry floor)."""
         if reward_function_version != "v2":
             raise NotImplementedError("only reward_function_version='v2' has device code (SURVEY.md 8f item 4)")
         if task_select not in ("random", "pseudorandom"):

@@ -1,0 +1,57 @@
+"""The four tasks whose one-step tolerance is wider than 1e-5 (tests/test_tasks_parity.py::TOL) are not looser because the device
+code is less accurate there: at those states the REFERENCE ITSELF (its unmodified Python on the oracle engine) is ill-conditioned.
+Proof by perturbation: move the synchronised qpos by 1e-12 and the reference's own next observation moves by 1e-7 ... 2e-5 --
+an amplification of 1e5 ... 1e7 in ONE step (a contact at its activation margin / a face-on-face contact whose single contact
+point is not a continuous function of the poses), while the same experiment on reach-v3 returns the perturbation unamplified.
+No implementation that differs from the reference's arithmetic by one rounding can meet 1e-5 at such a state; the waived
+tolerances are set from this measured sensitivity."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import golden
+
+# (task, env index, step) of the largest device-vs-trace deviation of each waived task (host build, fp64); reach-v3 = control
+CASES = [("door-unlock-v3", 0, 35, 1e-7), ("peg-unplug-side-v3", 1, 0, 1e-7), ("door-close-v3", 0, 47, 1e-7), ("box-close-v3", 0, 28, 1e-7)]
+
+
+def _step_reference_from(task, G, e, t, eps):
+    import metaworld
+    mt1 = metaworld.MT1(task, seed=42)
+    env = mt1.train_classes[task]()
+    env.seed(42)
+    env.set_task(mt1.train_tasks[int(G["goal_idx"][e])])
+    env.reset()
+    d = env.data
+    if t > 0:
+        src = (G["qpos"][e, t - 1], G["qvel"][e, t - 1], G["mocap"][e, t - 1], G["warm"][e, t - 1], G["obs"][e, t - 1][:18])
+    else:
+        src = (G["reset_qpos"][e], G["reset_qvel"][e], G["reset_mocap"][e], G["reset_warm"][e], G["reset_obs"][e][:18])
+    d.qpos[:] = src[0] + eps; d.qvel[:] = src[1]; d.mocap_pos[0][:] = src[2]; d.qacc_warmstart[:] = src[3]
+    env.curr_path_length = t
+    env._prev_obs = src[4].copy()
+    return env.step(G["actions"][e, t])[0]
+
+
+@pytest.fixture(scope="module")
+def reference():
+    from oracle import refshim
+    if not os.path.isdir(refshim.REFERENCE_ROOT):
+        pytest.skip("reference sources not present (GPU box)")
+    refshim.install()
+
+
+@pytest.mark.parametrize("task,e,t,floor", CASES)
+def test_waived_state_amplifies_a_1e12_perturbation(reference, task, e, t, floor):
+    G = golden(f"trace_{task}_seed42.npz")
+    base = _step_reference_from(task, G, e, t, 0.0)
+    moved = max(np.abs(_step_reference_from(task, G, e, t, eps) - base).max() for eps in (1e-12, -1e-12))
+    assert moved > floor, (task, moved)          # >= 1e5-fold amplification of a 1e-12 perturbation in one step
+
+
+def test_control_state_does_not(reference):
+    G = golden("trace_reach-v3_seed42.npz")
+    base = _step_reference_from("reach-v3", G, 1, 33, 0.0)
+    moved = np.abs(_step_reference_from("reach-v3", G, 1, 33, 1e-12) - base).max()
+    assert moved < 1e-11, moved

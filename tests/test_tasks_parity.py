@@ -7,11 +7,13 @@ import pytest
 from metaworld_amd import tasks as T
 from tests.helpers import golden, make_env, replay_trace
 
-# Documented exceptions (DESIGN.md "parity"): contacts whose single MPR point is not unique (flat mesh faces of the
-# gripper palm, the plug seated in its socket), and basketball whose goal site drifts with the env's reset history.
-TOL = {"door-unlock-v3": (5e-4, 2e-2), "peg-unplug-side-v3": (1e-4, 1e-3), "door-close-v3": (1e-5, 1e-4),
-       "box-close-v3": (1e-4, 1e-3)}
-
+# Documented exceptions.  At the states where these four tasks exceed 1e-5 the reference itself amplifies a 1e-12 perturbation of
+# the synchronised state to 1e-7 ... 2e-5 in ONE step (tests/test_ill_conditioning.py proves it on the reference's own Python):
+# a contact sitting at its activation margin, or a face-on-face contact whose single contact point is not a continuous function
+# of the poses (the gripper palm's flat mesh faces, the plug seated in its socket).  The tolerances are ~3x the deviation measured
+# on the host build and on the GPU (16 sub-lanes, FMA contraction, single-precision Hessian factor change the rounding).
+TOL = {"door-unlock-v3": (3e-4, 1e-2), "peg-unplug-side-v3": (3e-5, 1e-4), "door-close-v3": (1e-5, 5e-5),
+       "box-close-v3": (5e-5, 2e-4)}
 
 @pytest.mark.parametrize("task", T.ALL_V3)
 def test_task_matches_reference_trace(hostsim, task):

@@ -1,14 +1,14 @@
 #!/bin/bash
 # rocprofv3 evidence for the bench workload (run on the GPU box through gpurun):
 #   kernel-trace stats (its own pass) + separate PMC passes, all CSV under gpurun_out/prof_<tag>/
-# usage: tools/profile_bench.sh <tag> [bench args...]
+# usage: tools/profile_bench.sh <tag> [bench args...]      (the bench runs with --no-cpu-baseline --no-extra-precision)
 set -u
-tag=${1:-r01}; shift || true
+tag=${1:-r02}; shift || true
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
-args="--no-cpu-baseline --no-parity-mode $*"     # bench.py defaults (1000 timed steps after 100) unless overridden
+args="--no-cpu-baseline --no-extra-precision $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python $root/bench.py $args > "$out/kt.log" 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" \
@@ -18,6 +18,21 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   rocprofv3 --pmc $set --output-format csv -d "$out/pmc_$name" -- python $root/bench.py $args > "$out/pmc_$name.log" 2>&1
 done
 cd $root
-# keep only the small CSVs
 find "$out" -name "*.db" -delete
+stats=$(find "$out/kt" -name "*kernel_stats.csv" | head -1)
+[ -n "$stats" ] && cp "$stats" "$out/kernel_stats.csv"
+kms=$(python - "$out/kernel_stats.csv" <<'PY'
+import csv, sys
+try:
+    for r in csv.DictReader(open(sys.argv[1])):
+        if "step_device_only" in r["Name"]:
+            print(float(r["AverageNs"]) / 1e6); break
+except Exception:
+    print(0)
+PY
+)
+prec=$(echo "$args" | grep -q "fp32" && echo fp32 || echo fp64)
+python tools/summarize_pmc.py "$out/pmc_*/**/*counter_collection.csv" --kernel step_device_only --json "$out/pmc.json" \
+  --workload "MT50 sync-vector, 4096 envs/GPU, $prec, random actions" --kernel-ms "$kms" > "$out/pmc_summary.txt" 2>&1
+grep -h '^{' "$out/kt.log" | tail -1 > "$out/bench_line_under_kernel_trace.json"
 du -sh "$out"

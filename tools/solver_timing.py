@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from metaworld_amd import native  # noqa: E402
 from metaworld_amd.vector_env import MetaWorldGpuVectorEnv  # noqa: E402
 
-lib = native.load("mw_", os.path.join(ROOT, "metaworld_amd", "libmwgpu_timing.so"))
+lib = native.load("mw_", os.path.join(ROOT, "metaworld_amd", os.environ.get("MW_LIB", "libmwgpu_timing.so")))
 n = int(sys.argv[1])
 win = int(os.environ.get("MW_WIN", "50"))
 nwin = int(os.environ.get("MW_NWIN", "4"))
@@ -31,4 +31,5 @@ for task in sys.argv[2:]:
         d = d * scale
         print(f"{task:18s} steps {w*win:3d}-{(w+1)*win:3d} {ms:6.2f} ms/step nefc<= {ic1[:,1].max():3d} | kcyc/step (max lane) " +
               " ".join(f"{k}:{v:.0f}" for k, v in zip(names, d.max(0))), flush=True)
+    print("   status", env.ctx.status(), flush=True)
     env.close()

@@ -1,31 +1,64 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc CSVs (gpurun_out/pmc_*/p_counter_collection.csv) for the step kernel:
-mean counter value per dispatch.  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide
-coalesced reads by 2x (MI355X_MICROARCH.md, HBM section) -- both raw and corrected values are printed."""
+"""Summarise rocprofv3 --pmc CSVs (one directory per counter group, tools/profile_bench.sh) for the step kernel: mean counter value
+per dispatch, printed as text; with --json OUT also the small JSON bench.py reads for `roofline.traffic` and `roofline.alu_issue`.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports WIDE coalesced reads by 2x (MI355X_MICROARCH.md, HBM section):
+the step kernel's requests are 4-32 bytes per lane group, so the raw value is used and the corrected one is printed beside it."""
+import argparse
 import collections
 import csv
 import glob
-import sys
+import json
 
-pat = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_*/p_counter_collection.csv"
-kernel = sys.argv[2] if len(sys.argv) > 2 else "step_device_only"
-print(f"# kernel filter: {kernel}")
-for f in sorted(glob.glob(pat)):
+ap = argparse.ArgumentParser()
+ap.add_argument("pattern", nargs="?", default="gpurun_out/pmc_*/**/*counter_collection.csv")
+ap.add_argument("--kernel", default="step_device_only")
+ap.add_argument("--json")
+ap.add_argument("--workload", default="")
+ap.add_argument("--envs", type=int, default=4096)
+ap.add_argument("--kernel-ms", type=float, default=0.0, help="average launch duration of the kernel trace of the same command")
+args = ap.parse_args()
+print(f"# kernel filter: {args.kernel}")
+mean = {}
+meta = None
+for f in sorted(glob.glob(args.pattern, recursive=True)):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    meta = None
     for r in csv.DictReader(open(f)):
-        if kernel not in r["Kernel_Name"]:
+        if args.kernel not in r["Kernel_Name"]:
             continue
         acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-        meta = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "LDS_Block_Size", "Workgroup_Size", "Grid_Size")}
+        meta = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "LDS_Block_Size", "Workgroup_Size", "Grid_Size") if k in r}
     for c, d in sorted(acc.items()):
         v = list(d.values())
         m = sum(v) / len(v)
+        mean[c] = m
         extra = ""
         if c == "FETCH_SIZE":
-            extra = f"  = {m / 1024:.1f} MiB raw, {2 * m / 1024:.1f} MiB with the gfx950 x2 correction"
+            extra = f"  = {m / 1024:.1f} MiB raw, {2 * m / 1024:.1f} MiB with the gfx950 x2 wide-read correction"
         if c == "WRITE_SIZE":
             extra = f"  = {m / 1024:.1f} MiB"
-        print(f"{c:24s} dispatches={len(v):3d} mean/dispatch={m:16.1f}{extra}")
-    if meta:
-        print("  launch:", meta)
+        print(f"{c:24s} dispatches={len(v):4d} mean/dispatch={m:16.1f}{extra}")
+if meta:
+    print("  launch:", meta)
+if args.json and mean:
+    waves = mean.get("SQ_WAVES", 0.0)
+    out = {"workload": args.workload, "kernel": args.kernel, "launch": meta,
+           "fetch_bytes_per_launch": mean.get("FETCH_SIZE", 0.0) * 1024, "write_bytes_per_launch": mean.get("WRITE_SIZE", 0.0) * 1024,
+           "valu_wave_instr_per_launch": mean.get("SQ_INSTS_VALU", 0.0), "salu_wave_instr_per_launch": mean.get("SQ_INSTS_SALU", 0.0),
+           "vmem_rd_wave_instr_per_launch": mean.get("SQ_INSTS_VMEM_RD", 0.0), "vmem_wr_wave_instr_per_launch": mean.get("SQ_INSTS_VMEM_WR", 0.0),
+           "lds_wave_instr_per_launch": mean.get("SQ_INSTS_LDS", 0.0), "waves_per_launch": waves,
+           "wait_frac": mean.get("SQ_WAIT_ANY", 0.0) / mean["SQ_WAVE_CYCLES"] if mean.get("SQ_WAVE_CYCLES") else None,
+           "tcc_hit_rate": mean.get("TCC_HIT_sum", 0.0) / (mean.get("TCC_HIT_sum", 0.0) + mean.get("TCC_MISS_sum", 1.0)) if mean.get("TCC_HIT_sum") else None,
+           # envs x sub-lanes all do useful (distinct or replicated-by-design) work only where the lanes hold an env: lanes / (waves x 64)
+           "lane_utilisation": None, "wave_slot_occupancy": None, "kernel_ms_per_launch": args.kernel_ms or None,
+           "note": "rocprofv3 --pmc, separate passes per counter group, mean over the step-kernel launches of `python bench.py --no-cpu-baseline "
+                   "--no-extra-precision`; FETCH_SIZE / WRITE_SIZE in KiB x 1024 (raw: narrow requests, no x2 correction)"}
+    if waves:
+        # distinct environments per lane slot: 1 = one env per lane; below that the other lanes are sub-lanes of the same env
+        # (they split the row / pair sweeps and replicate the serial parts)
+        out["lane_utilisation"] = args.envs / (64.0 * waves)
+    if mean.get("SQ_WAVE_CYCLES") and args.kernel_ms:
+        cycles = args.kernel_ms * 1e-3 * 2.4e9
+        out["wave_slot_occupancy"] = mean["SQ_WAVE_CYCLES"] * 4 / (1024 * cycles)      # SQ_WAVE_CYCLES counts quad-cycles
+    with open(args.json, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", args.json)
