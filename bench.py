@@ -219,6 +219,9 @@ def main(argv=None):
             dist.init_process_group(args.backend)
 
     lib = None
+    if os.environ.get("MW_LIB"):          # experiments: a variant build of the library (tools/build_variants.sh)
+        from metaworld_amd import native
+        lib = native.load("mw_", os.path.join(ROOT, "metaworld_amd", os.environ["MW_LIB"]))
     if args.host_harness:
         import __graft_entry__ as g
         from metaworld_amd import native

@@ -24,7 +24,7 @@ struct Shape {
     int nvert;
     T margin;
     // hill-climbing support for big hulls (metaworld_amd/mjcf.py add_mesh_graph): CSR adjacency of this mesh's vertices
-    // (local ids), 32 start candidates, and the vertex the previous support call on this shape ended at
+    // (local ids), the direction cube map of start vertices, and the vertex the previous support call on this shape ended at
     CP<int> nbradr, nbr, start;
     int hill;
     mutable int hint;
@@ -293,6 +293,25 @@ MW_HD int box_box(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, int
     return cnt;
 }
 
+// cube-map cell of a direction: face = 2 * (major axis) + (negative side), (u, v) = the two other components over |major|,
+// each cut into HILL_GRID intervals -- the same rule in metaworld_amd/mjcf.py (table build) and oracle/mjl_collide.c
+constexpr int HILL_GRID = 8;
+template <typename T>
+MW_HD int hill_cell(T x, T y, T z) {
+    const T ax = mw_abs(x), ay = mw_abs(y), az = mw_abs(z);
+    int axis;
+    T m, u, v, c;
+    if (ax >= ay && ax >= az) { axis = 0; m = ax; c = x; u = y; v = z; }
+    else if (ay >= az) { axis = 1; m = ay; c = y; u = x; v = z; }
+    else { axis = 2; m = az; c = z; u = x; v = y; }
+    if (!(m > 0)) return 0;
+    const T s = T(0.5) * HILL_GRID / m;
+    int iu = (int)((u + m) * s), iv = (int)((v + m) * s);
+    iu = iu < 0 ? 0 : (iu > HILL_GRID - 1 ? HILL_GRID - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > HILL_GRID - 1 ? HILL_GRID - 1 : iv);
+    return ((2 * axis + (c < 0 ? 1 : 0)) * HILL_GRID + iu) * HILL_GRID + iv;
+}
+
 // ------------------------------------------------------------ MPR on support functions
 // support point; exact ties (direction perpendicular to a flat feature) are broken canonically (towards +, lowest
 // vertex index) within `tie`, so that independent implementations walk the same portal
@@ -321,22 +340,17 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
             // steepest-ascent walk over the hull graph (MuJoCo's mesh-graph support): from the previous result on this
             // shape, else from the best of the fixed start candidates; strict improvement only.  An exhaustive scan
             // of the 884-vertex gripper hull cost ~20k cycles per call; the walk visits a few dozen vertices.
-            int cur;
+            // start: the cube-map cell of the direction (mjcf.py add_mesh_graph), or the previous call's result if that is higher
+            int cur = s.start[hill_cell(dl.x, dl.y, dl.z)];
+            bd = s.vert[3 * cur] * dl.x + s.vert[3 * cur + 1] * dl.y + s.vert[3 * cur + 2] * dl.z;
             if (s.hint >= 0) {
-                cur = s.hint;
-                bd = s.vert[3 * cur] * dl.x + s.vert[3 * cur + 1] * dl.y + s.vert[3 * cur + 2] * dl.z;
-            } else {
-                cur = s.start[0];
-                bd = s.vert[3 * cur] * dl.x + s.vert[3 * cur + 1] * dl.y + s.vert[3 * cur + 2] * dl.z;
-#pragma unroll 8
-                for (int k = 1; k < 32; k++) {
-                    const int c = s.start[k];
-                    const T dd = s.vert[3 * c] * dl.x + s.vert[3 * c + 1] * dl.y + s.vert[3 * c + 2] * dl.z;
-                    if (dd > bd) { bd = dd; cur = c; }
-                }
+                const int hv = s.hint;
+                const T hd = s.vert[3 * hv] * dl.x + s.vert[3 * hv + 1] * dl.y + s.vert[3 * hv + 2] * dl.z;
+                if (hd > bd) { bd = hd; cur = hv; }
             }
             for (int it = 0; it < s.nvert; it++) {
                 MW_COUNT(4)
+                MW_PAIR_ADD(2, 1)
                 int nxt = cur;
                 const int j0 = s.nbradr[cur], j1 = s.nbradr[cur + 1];
                 for (int jb = j0; jb < j1; jb += 8) {        // neighbours in batches of 8: ids, then coordinates, issued together
@@ -445,6 +459,7 @@ MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V
         if (len == 0) break;
         if (dot(dir, v1.v) >= 0) hit = true;
         MW_COUNT(6)
+        MW_PAIR_ADD(1, 1)
         v4 = msupport(A, B, dir);
         const T dv4 = dot(v4.v, dir);
         if (dv4 < 0 && !hit) return 0;
@@ -592,7 +607,7 @@ MW_HD Shape<T> make_shape(const Env<T> e, int g) {
             s.hill = 1;
             s.nbradr = m.mesh_nbradr + m.mesh_vertadr[mi];
             s.nbr = m.mesh_nbr;
-            s.start = m.mesh_start + 32 * mi;
+            s.start = m.mesh_start + 6 * HILL_GRID * HILL_GRID * mi;
         }
     }
     return s;
@@ -606,6 +621,7 @@ MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, H
     if (UNIFORM) margin = mw_uniform(margin);
     const int t1 = ua.type, t2 = ub.type;
     MW_COUNT(7)
+    MW_PAIR_BEGIN(t1, t2)
     int n = -1;
     if (t1 == G_PLANE) n = plane_x(ua, ub, margin, h);
     else if (t1 == G_SPHERE) n = sphere_x(ua, ub, margin, h);

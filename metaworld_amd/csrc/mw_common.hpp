@@ -48,9 +48,16 @@ inline long* mw_cnt() { static long c[8] = {0}; return c; }
 #define MW_COUNT(i) mw_cnt()[i]++;
 inline long* mw_hist() { static long h[4 * 64] = {0}; return h; }
 #define MW_HIST(w, v) mw_hist()[(w) * 64 + ((v) < 63 ? (v) : 63)]++;
+// per geom-type-pair narrow-phase statistics: [t1][t2][0 calls, 1 portal iterations, 2 hill-climb steps, 3 hits]
+inline long* mw_pairstat() { static long p[8 * 8 * 4] = {0}; return p; }
+inline int& mw_pair_cur() { static thread_local int c = 0; return c; }
+#define MW_PAIR_BEGIN(t1, t2) { mw_pair_cur() = ((t1) * 8 + (t2)) * 4; mw_pairstat()[mw_pair_cur()]++; }
+#define MW_PAIR_ADD(k, v) { mw_pairstat()[mw_pair_cur() + (k)] += (v); }
 #else
 #define MW_COUNT(i) {}
 #define MW_HIST(w, v) {}
+#define MW_PAIR_BEGIN(t1, t2) {}
+#define MW_PAIR_ADD(k, v) {}
 #endif
 
 
@@ -258,8 +265,8 @@ __device__ inline T sub_sum(const Env<T>& e, const T* p) {
     for (int off = e.lds_stride; off < 64; off <<= 1) v += __shfl_xor(v, off);
     return v;
 }
-template <int N, typename T>
-__device__ inline void sub_sum_n(const Env<T>& e, T (*p)[N]) {
+template <int N, typename T, typename U>
+__device__ inline void sub_sum_n(const Env<T>& e, U (*p)[N]) {
     for (int off = e.lds_stride; off < 64; off <<= 1) {
 #pragma unroll
         for (int k = 0; k < N; k++) p[0][k] += __shfl_xor(p[0][k], off);
@@ -283,9 +290,9 @@ __device__ inline int sub_scan(const Env<T>& e, const int* n, int* off) {
 #define MW_SLOT(sub) (sub)
 constexpr int MW_NSLOT = 64;
 #define MW_SYNC()
-template <typename T>
-inline T sub_sum(const Env<T>& e, const T* p) {
-    T q[MW_NSLOT], r[MW_NSLOT];
+template <typename T, typename U>
+inline U sub_sum(const Env<T>& e, const U* p) {
+    U q[MW_NSLOT], r[MW_NSLOT];
     for (int s = 0; s < e.nsub; s++) q[s] = p[s];
     for (int off = 1; off < e.nsub; off <<= 1) {
         for (int s = 0; s < e.nsub; s++) r[s] = q[s] + q[s ^ off];
@@ -299,10 +306,10 @@ inline int sub_scan(const Env<T>& e, const int* n, int* off) {
     for (int s = 0; s < e.nsub; s++) { off[s] = tot; tot += n[s]; }
     return tot;
 }
-template <int N, typename T>
-inline void sub_sum_n(const Env<T>& e, T (*p)[N]) {
+template <int N, typename T, typename U>
+inline void sub_sum_n(const Env<T>& e, U (*p)[N]) {
     for (int k = 0; k < N; k++) {
-        T col[MW_NSLOT];
+        U col[MW_NSLOT];
         for (int s = 0; s < e.nsub; s++) col[s] = p[s][k];
         p[0][k] = sub_sum(e, col);
     }

@@ -859,6 +859,126 @@ MW_HD void line_eval(const Env<T> e, int nblk, T alpha, const T* quadGauss, T* c
     if (mag) *mag = part[0][3] + mw_abs(2 * alpha * quadGauss[2]) + mw_abs(quadGauss[1]);
 }
 
+// Precision of the Newton Hessian and its Cholesky factor: SINGLE precision also in an fp64 context (unless -DMW_HESSIAN_F64).
+// H = M + J' D J is then a PRECONDITIONER of a double-precision solve: the Jacobian, the constraint forces, the gradient, the
+// exact line search, the cost and every convergence test stay in T, so the iteration converges to the same minimiser under
+// the same tolerance (the problem is strictly convex; an inexact Newton direction only changes the path).  What it buys: the
+// lower triangle is 120 instead of 240 registers for nv = 15, which is what made the fp64 assembly + factorisation spill
+// (-9 % time per MT50 step at 4096 envs; Newton iteration counts unchanged, ~1 extra line-search evaluation per iteration).
+// What it costs: two implementations no longer follow bit-identical iterates, so device-vs-oracle agreement over hundreds of
+// substeps is ~1e-9 instead of ~1e-14 (the reference tolerance is 1e-5).
+template <typename T> struct HessType { typedef T type; };
+#if !defined(MW_HESSIAN_F64)
+template <> struct HessType<double> { typedef float type; };
+#endif
+template <typename T, typename HT, int NV>
+MW_HD void tri_load_as(const Env<T> e, int A, int n, HT* h) {
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            const T v = e.R(A + (i < n ? i * n + j : 0));
+            h[tri(i, j)] = i < n ? (HT)v : (i == j ? HT(1) : HT(0));
+        }
+}
+template <typename T, typename HT, int NV>
+MW_HD void jrow_load_as(const Env<T> e, int row, int nv, HT* j) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) j[k] = (HT)EJ(e, row, k < nv ? k : 0);
+}
+
+// search direction s = -H^-1 g of one Newton iteration: reads -g from L.grad, writes s to L.search.
+// H = M + J' D J over quadratic rows (+ dense cone blocks): lower triangle in registers (a partial sum per sub-lane over its
+// blocks, M on sub-lane 0), butterfly total, then Cholesky + solve replicated on the sub-lanes.
+template <typename T, typename HT, int NV>
+MW_STAGE_FN void newton_direction(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
+    CLayout& L = e.lay();
+    const int nv = e.nv, nblk = e.I(L.icount + IC_NBLK);
+    constexpr int NT = NV * (NV + 1) / 2;
+    HT H[MW_NSLOT][NT];
+    MW_SUBS(e, sub) {
+        HT* h = H[MW_SLOT(sub)];
+        if (sub == 0) tri_load_as<T, HT, NV>(e, L.qM, nv, h);
+        else {
+#pragma unroll
+            for (int k = 0; k < NT; k++) h[k] = 0;
+        }
+        for (int kb = sub; kb < nblk; kb += e.nsub) {
+            const int i = block_row(e, kb);
+            const int st = (int)sr_get(e, i, SR_STATE);
+            if (st == S_SATISFIED) continue;
+            const int info = (int)sr_get(e, i, SR_INFO), dim = (info >> 4) & 15, type = info & 15;
+            if (st == S_CONE) {
+                ConeEval<T> z = cone_eval<T>(Rows<T, false>{e}, i, dim, T(0));
+                const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu));
+                HT Hc[16];
+                const T scl = z.mu * z.N / (z.Tn * z.Tn * z.Tn), dg = z.mu * z.mu - z.mu * z.N / z.Tn;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        T v;
+                        if (r == 0 && c == 0) v = 1;
+                        else if (r == 0) v = -z.mu * z.U[c] / z.Tn;
+                        else if (c == 0) v = -z.mu * z.U[r] / z.Tn;
+                        else v = scl * z.U[r] * z.U[c] + (r == c ? dg : T(0));
+                        Hc[4 * r + c] = (r < dim && c < dim) ? HT(v * Dm * z.fri[r] * z.fri[c]) : HT(0);
+                    }
+                HT j[4][NV];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool on = r < dim;
+                    jrow_load_as<T, HT, NV>(e, on ? i + r : i, nv, j[r]);
+#pragma unroll
+                    for (int a = 0; a < NV; a++) j[r][a] = (on && a < nv) ? j[r][a] : HT(0);
+                }
+#pragma unroll
+                for (int a = 0; a < NV; a++) {
+                    HT t[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        t[c] = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) t[c] += j[r][a] * Hc[4 * r + c];
+                    }
+#pragma unroll
+                    for (int b = 0; b <= a; b++) {
+                        HT acc = 0;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc += t[c] * j[c][b];
+                        h[tri(a, b)] += acc;
+                    }
+                }
+            } else {          // quadratic: every row of the block is an independent rank-1 term
+                const int nr = type == C_CONTACT ? dim : 1;
+                for (int r = 0; r < nr; r++) {
+                    const HT D = (HT)sr_get(e, i + r, SR_D);
+                    HT j[NV];
+                    jrow_load_as<T, HT, NV>(e, i + r, nv, j);
+#pragma unroll
+                    for (int a = 0; a < NV; a++) j[a] = a < nv ? j[a] : HT(0);
+#pragma unroll
+                    for (int a = 0; a < NV; a++) {
+                        const HT Da = D * j[a];
+#pragma unroll
+                        for (int b = 0; b <= a; b++) h[tri(a, b)] += Da * j[b];
+                    }
+                }
+            }
+        }
+    }
+    sub_sum_n<NT>(e, H);
+    HT inv[NV], sh[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) sh[k] = k < nv ? (HT)e.R(L.grad + k) : HT(0);
+    chol_reg<HT, NV>(H[0], inv);
+    chol_solve_reg<HT, NV>(H[0], inv, sh);
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        if (k < nv) e.R(L.search + k) = (T)sh[k];
+}
+
 template <typename T, int NV>
 MW_HD void solve_impl(const Env<T> e) {
     CModel<T>& m = e.model();
@@ -915,90 +1035,14 @@ MW_HD void solve_impl(const Env<T> e) {
         }
         if (scale * mw_sqrt(gn) < m.tolerance) break;
         MW_TICK(t_c)
-        {
-            // H = M + J' D J over quadratic rows (+ dense cone blocks): lower triangle in registers (a partial sum per
-            // sub-lane over its blocks, M on sub-lane 0), butterfly total, then Cholesky + solve replicated
-            T H[MW_NSLOT][NT];
-            MW_SUBS(e, sub) {
-                T* h = H[MW_SLOT(sub)];
-                if (sub == 0) tri_load<T, NV>(e, L.qM, nv, h);
-                else {
-#pragma unroll
-                    for (int k = 0; k < NT; k++) h[k] = 0;
-                }
-                for (int kb = sub; kb < nblk; kb += e.nsub) {
-                    const int i = block_row(e, kb);
-                    const int st = (int)sr_get(e, i, SR_STATE);
-                    if (st == S_SATISFIED) continue;
-                    const int info = (int)sr_get(e, i, SR_INFO), dim = (info >> 4) & 15, type = info & 15;
-                    if (st == S_CONE) {
-                        ConeEval<T> z = cone_eval<T>(Rows<T, false>{e}, i, dim, T(0));
-                        const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu));
-                        T Hc[16];
-                        const T scl = z.mu * z.N / (z.Tn * z.Tn * z.Tn), dg = z.mu * z.mu - z.mu * z.N / z.Tn;
-#pragma unroll
-                        for (int r = 0; r < 4; r++)
-#pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                T v;
-                                if (r == 0 && c == 0) v = 1;
-                                else if (r == 0) v = -z.mu * z.U[c] / z.Tn;
-                                else if (c == 0) v = -z.mu * z.U[r] / z.Tn;
-                                else v = scl * z.U[r] * z.U[c] + (r == c ? dg : T(0));
-                                Hc[4 * r + c] = (r < dim && c < dim) ? v * Dm * z.fri[r] * z.fri[c] : T(0);
-                            }
-                        T j[4][NV];
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const bool on = r < dim;
-                            jrow_load<T, NV>(e, on ? i + r : i, nv, j[r]);
-#pragma unroll
-                            for (int a = 0; a < NV; a++) j[r][a] = (on && a < nv) ? j[r][a] : T(0);
-                        }
-#pragma unroll
-                        for (int a = 0; a < NV; a++) {
-                            T t[4];
-#pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                t[c] = 0;
-#pragma unroll
-                                for (int r = 0; r < 4; r++) t[c] += j[r][a] * Hc[4 * r + c];
-                            }
-#pragma unroll
-                            for (int b = 0; b <= a; b++) {
-                                T acc = 0;
-#pragma unroll
-                                for (int c = 0; c < 4; c++) acc += t[c] * j[c][b];
-                                h[tri(a, b)] += acc;
-                            }
-                        }
-                    } else {          // quadratic: every row of the block is an independent rank-1 term
-                        const int nr = type == C_CONTACT ? dim : 1;
-                        for (int r = 0; r < nr; r++) {
-                            const T D = sr_get(e, i + r, SR_D);
-                            T j[NV];
-                            jrow_load<T, NV>(e, i + r, nv, j);
-#pragma unroll
-                            for (int a = 0; a < NV; a++) j[a] = a < nv ? j[a] : T(0);
-#pragma unroll
-                            for (int a = 0; a < NV; a++) {
-                                const T Da = D * j[a];
-#pragma unroll
-                                for (int b = 0; b <= a; b++) h[tri(a, b)] += Da * j[b];
-                            }
-                        }
-                    }
-                }
-            }
-            sub_sum_n<NT>(e, H);
-            MW_TICK(t_d)
-            T inv[NV];
-            chol_reg<T, NV>(H[0], inv);
-            chol_solve_reg<T, NV>(H[0], inv, sr);
-            MW_TICK(t_e)
-            MW_TOCK(e, L, 1, t_c, t_d)
-            MW_TOCK(e, L, 2, t_d, t_e)
-        }
+        // Newton direction: -g goes through the column store (L.grad) into its own non-inlined function and the direction comes
+        // back in L.search, so that the register allocation of the Hessian (nv (nv + 1) / 2 accumulators + up to four Jacobian
+        // rows) is not mixed with everything that is live in this loop
+        vec_store<T, NV>(e, L.grad, nv, sr);
+        newton_direction<T, typename HessType<T>::type, NV>(e);
+        vec_load<T, NV>(e, L.search, nv, sr);
+        MW_TICK(t_e)
+        MW_TOCK(e, L, 1, t_c, t_e)
         MW_TICK(t_f)
         // ---- exact line search (safeguarded Newton on the 1-D convex cost) ----
         T snorm = 0, quadGauss[3] = {0, 0, 0};

@@ -830,20 +830,48 @@ def save_model(m: Model, path):
 
 
 HILL_MIN_VERTS = 64     # meshes with more hull vertices use hill-climbing support (like MuJoCo's mesh graphs)
-HILL_NSTART = 32        # start candidates: the support vertices of 32 fixed directions
+HILL_GRID = 8           # start table: a cube map of directions, 6 faces x HILL_GRID x HILL_GRID cells
+HILL_NSTART = 6 * HILL_GRID * HILL_GRID     # entry = the support vertex of the cell-centre direction (csrc/mw_collide.hpp hill_cell)
+
+
+def _hill_dirs():
+    """cell-centre directions of the start cube map.  Cell (face, iu, iv): face = 2 * (major axis) + (negative side); u, v = the two
+    other components (in x, y, z order) divided by |major component|, each cut into HILL_GRID intervals over [-1, 1]"""
+    dirs = []
+    for face in range(6):
+        ax, sg = face // 2, -1.0 if face % 2 else 1.0
+        o = [c for c in range(3) if c != ax]
+        for iu in range(HILL_GRID):
+            for iv in range(HILL_GRID):
+                d = np.zeros(3)
+                d[ax] = sg; d[o[0]] = (iu + 0.5) * 2.0 / HILL_GRID - 1.0; d[o[1]] = (iv + 0.5) * 2.0 / HILL_GRID - 1.0
+                dirs.append(d)
+    return np.array(dirs)
+
+
+def add_mesh_starts(A):
+    """the direction cube map of start vertices (mesh_start[mesh][cell]) for the hill-climbing hulls"""
+    dirs = _hill_dirs()
+    start = []
+    for mi in range(len(A["mesh_vertnum"])):
+        a, n = int(A["mesh_vertadr"][mi]), int(A["mesh_vertnum"][mi])
+        v = A["mesh_vert"][a:a + n]
+        start += [int(i) for i in np.argmax(v @ dirs.T, axis=0)] if A["mesh_hill"][mi] else [0] * HILL_NSTART
+    A["mesh_start"] = np.array(start if start else [0], dtype=np.int32)
 
 
 def add_mesh_graph(A):
-    """Hull-vertex adjacency (CSR over the global vertex index) + start candidates for hill-climbing support functions.
+    """Hull-vertex adjacency (CSR over the global vertex index) + the direction cube map of start vertices for hill-climbing
+    support functions (a support call looks its direction's cell up and climbs from that vertex or from the previous call's
+    result, whichever is higher: 1-3 steps instead of ~10 from one of 32 coarse candidates).
     Derived from the stored hull vertices, so it is identical wherever the compiled model is loaded."""
     if "mesh_nbradr" in A:
+        if len(A["mesh_start"]) != HILL_NSTART * max(1, len(A["mesh_vertnum"])):          # a model file written with an older start table
+            add_mesh_starts(A)
         return
     from scipy.spatial import ConvexHull
     nmesh = len(A["mesh_vertnum"])
-    adr, nbr, start, hill = [0], [], [], []
-    k = np.arange(HILL_NSTART) + 0.5
-    phi, th = np.arccos(1 - 2 * k / HILL_NSTART), np.pi * (1 + 5 ** 0.5) * k
-    dirs = np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], 1)
+    adr, nbr, hill = [0], [], []
     for mi in range(nmesh):
         a, n = int(A["mesh_vertadr"][mi]), int(A["mesh_vertnum"][mi])
         v = A["mesh_vert"][a:a + n]
@@ -859,11 +887,10 @@ def add_mesh_graph(A):
         for sset in adj:
             nbr += sorted(sset) if use else []
             adr.append(len(nbr))
-        start += [int(np.argmax(v @ d)) for d in dirs] if use else [0] * HILL_NSTART
     A["mesh_nbradr"] = np.array(adr, dtype=np.int32)
     A["mesh_nbr"] = np.array(nbr if nbr else [0], dtype=np.int32)
-    A["mesh_start"] = np.array(start if start else [0], dtype=np.int32)
     A["mesh_hill"] = np.array(hill if hill else [0], dtype=np.int32)
+    add_mesh_starts(A)
 
 
 def load_model(path) -> Model:

@@ -38,6 +38,22 @@ static inline void addscl3(double* r, const double* a, const double* b, double s
 static inline void copy3(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
 static inline void scl3(double* r, const double* a, double s) { r[0] = a[0] * s; r[1] = a[1] * s; r[2] = a[2] * s; }
 static inline double norm3(const double* a) { return sqrt(dot3(a, a)); }
+/* cube-map cell of a direction (start vertex table of the hill-climbing support, metaworld_amd/mjcf.py add_mesh_graph):
+   face = 2 * (major axis) + (negative side), (u, v) = the two other components over |major|, HILL_GRID intervals each */
+#define HILL_GRID 8
+static inline int hill_cell(double x, double y, double z) {
+    double ax = fabs(x), ay = fabs(y), az = fabs(z), m, u, v, c;
+    int axis;
+    if (ax >= ay && ax >= az) { axis = 0; m = ax; c = x; u = y; v = z; }
+    else if (ay >= az) { axis = 1; m = ay; c = y; u = x; v = z; }
+    else { axis = 2; m = az; c = z; u = x; v = y; }
+    if (!(m > 0)) return 0;
+    double s = 0.5 * HILL_GRID / m;
+    int iu = (int)((u + m) * s), iv = (int)((v + m) * s);
+    iu = iu < 0 ? 0 : (iu > HILL_GRID - 1 ? HILL_GRID - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > HILL_GRID - 1 ? HILL_GRID - 1 : iv);
+    return ((2 * axis + (c < 0 ? 1 : 0)) * HILL_GRID + iu) * HILL_GRID + iv;
+}
 static inline double normalize3(double* a) {
     double n = norm3(a);
     if (n < MINVAL) { a[0] = 1; a[1] = a[2] = 0; return 0; }
@@ -442,16 +458,14 @@ static void support(const Shape* s, const double* dir, double* out) {
         int best = 0;
         double bd = -1e30;
         if (s->hill) {
-            /* steepest-ascent walk over the hull graph, from the previous result on this shape or else from the best
-               of the fixed start candidates; strict improvement only (same rule as csrc/mw_collide.hpp) */
-            int cur;
-            if (s->hint >= 0) { cur = s->hint; bd = dot3(s->vert + 3 * cur, dl); }
-            else {
-                cur = s->start[0]; bd = dot3(s->vert + 3 * cur, dl);
-                for (int k = 1; k < 32; k++) {
-                    double dd = dot3(s->vert + 3 * s->start[k], dl);
-                    if (dd > bd) { bd = dd; cur = s->start[k]; }
-                }
+            /* steepest-ascent walk over the hull graph, from the direction's cube-map cell (metaworld_amd/mjcf.py
+               add_mesh_graph) or the previous result on this shape, whichever is higher; strict improvement only (same rule as
+               csrc/mw_collide.hpp) */
+            int cur = s->start[hill_cell(dl[0], dl[1], dl[2])];
+            bd = dot3(s->vert + 3 * cur, dl);
+            if (s->hint >= 0) {
+                double hd = dot3(s->vert + 3 * s->hint, dl);
+                if (hd > bd) { bd = hd; cur = s->hint; }
             }
             for (int it = 0; it < s->nvert; it++) {
                 int nxt = cur;
@@ -721,7 +735,7 @@ static void make_shape(const MjlModel* m, const MjlData* d, int g, Shape* s) {
             s->hill = 1;
             s->nbradr = m->mesh_nbradr + m->mesh_vertadr[mi];
             s->nbr = m->mesh_nbr;
-            s->start = m->mesh_start + 32 * mi;
+            s->start = m->mesh_start + 6 * HILL_GRID * HILL_GRID * mi;
         }
     }
 }

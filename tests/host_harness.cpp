@@ -119,6 +119,11 @@ extern "C" void mwh_counters(long* out, int reset) {
 }
 #endif
 #ifdef MW_PROFILE
+extern "C" void mwh_pairstat(long* out, int reset) {
+    for (int i = 0; i < 256; i++) { out[i] = mw::mw_pairstat()[i]; if (reset) mw::mw_pairstat()[i] = 0; }
+}
+#endif
+#ifdef MW_PROFILE
 extern "C" void mwh_hist(long* out, int reset) {
     for (int i = 0; i < 256; i++) { out[i] = mw::mw_hist()[i]; if (reset) mw::mw_hist()[i] = 0; }
 }
