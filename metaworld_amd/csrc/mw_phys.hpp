@@ -227,6 +227,21 @@ MW_HD void mat_vec(const Env<T> e, int A, int n, const T* x, T* y) {
         y[k] = s;
     }
 }
+// column dst <- M x, the rows split over the environment's sub-lanes (each row's sum in the same order as mat_vec: identical
+// values), then visible to all of them.  Replicating the 225 loads of M on every sub-lane was the largest part of a solver
+// iteration's serial remainder.
+template <typename T, int NV>
+MW_HD void mat_vec_rows(const Env<T> e, int A, int n, const T* x, int dst) {
+    MW_SUBS(e, sub) {
+        for (int k = sub; k < n; k += e.nsub) {
+            T s = 0;
+#pragma unroll
+            for (int j = 0; j < NV; j++) s += e.R(A + (j < n ? k * n + j : 0)) * x[j];
+            e.R(dst + k) = s;
+        }
+    }
+    MW_SYNC();
+}
 // factor the n x n matrix at A in place / solve with the factor at A, through registers
 template <typename T, int NV>
 MW_HD void chol_factor_via_reg(const Env<T> e, int A, int Lout, int n) {
@@ -997,11 +1012,15 @@ MW_HD void solve_impl(const Env<T> e) {
         }
     }
     auto set_point = [&](int src) {   // qacc <- src ; Ma, jar
-        T x[NV], y[NV];
+        T x[NV];
         vec_load<T, NV>(e, src, nv, x);
-        mat_vec<T, NV>(e, L.qM, nv, x, y);
         vec_store<T, NV>(e, L.qacc, nv, x);
-        vec_store<T, NV>(e, L.Ma, nv, y);
+        if (e.nsub > 1) mat_vec_rows<T, NV>(e, L.qM, nv, x, L.Ma);
+        else {
+            T y[NV];
+            mat_vec<T, NV>(e, L.qM, nv, x, y);
+            vec_store<T, NV>(e, L.Ma, nv, y);
+        }
         MW_SUBS(e, sub) {
             for (int i = sub; i < nefc; i += e.nsub) {
                 T j[NV], s = -EX(e, i, 4);
@@ -1048,9 +1067,14 @@ MW_HD void solve_impl(const Env<T> e) {
         T snorm = 0, quadGauss[3] = {0, 0, 0};
         {
             T Mv[NV];
-            mat_vec<T, NV>(e, L.qM, nv, sr, Mv);
             vec_store<T, NV>(e, L.search, nv, sr);
-            vec_store<T, NV>(e, L.Mv, nv, Mv);
+            if (e.nsub > 1) {
+                mat_vec_rows<T, NV>(e, L.qM, nv, sr, L.Mv);
+                vec_load<T, NV>(e, L.Mv, nv, Mv);
+            } else {
+                mat_vec<T, NV>(e, L.qM, nv, sr, Mv);
+                vec_store<T, NV>(e, L.Mv, nv, Mv);
+            }
 #pragma unroll
             for (int k = 0; k < NV; k++) {
                 const int kk = k < nv ? k : 0;

@@ -123,7 +123,7 @@ def test_gpu_lanes_per_block_invariance(gpulib, task, monkeypatch):
         # identical while the trajectories are numerically the same; a contact that sits exactly at its margin may then flip
         # between configurations (summation order differs), after which a chaotic scene drifts apart
         assert (runs[lpb][1][:12] == runs["64"][1][:12]).all(), "contact / row counts differ"
-        assert np.abs(runs[lpb][0][:12] - runs["64"][0][:12]).max() < 1e-8
+        assert np.abs(runs[lpb][0][:12] - runs["64"][0][:12]).max() < 1e-7          # (inexact-Newton iterates depend on the summation order)
         assert (runs[lpb][1] != runs["64"][1]).mean() < 0.1
         assert np.abs(runs[lpb][0] - runs["64"][0]).max() < 1e-2
 
