@@ -31,6 +31,9 @@ typedef struct mw_config {
     int32_t terminate_on_success;  /* AutoTerminateOnSuccessWrapper, metaworld/wrappers.py:207-230 */
     int32_t one_hot;               /* OneHotWrapper, metaworld/wrappers.py:14-32 */
     int32_t num_tasks;             /* one-hot width */
+    int32_t full_forward;          /* 0 (product): the final mj_forward of a step (sawyer_xyz_env.py:620) stops after the kinematics unless the
+                                    * task's reward reads contact forces (touching_object, :401-440) -- same observations, rewards and state;
+                                    * 1: always complete, for callers that read ncon / nefc / efc_force after a step (engine-level tests) */
 } mw_config;
 
 /* Per-task constants: what the reference keeps in each SawyerXYZEnv subclass

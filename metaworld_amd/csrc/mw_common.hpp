@@ -102,7 +102,8 @@ constexpr int CON_ISTRIDE = 4;   // ints per contact record
 constexpr int EFC_EXTRA = 11;    // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv, fri, info, state
 constexpr int SR_N = 8;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force, block list
 constexpr int IC_NBLK = 18;      // icount slot: number of constraint blocks (single rows / contact cones)
-constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 20 / 21 demand
+constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand
+constexpr int IC_DYN_VALID = 19;  // icount slot: 1 = contacts / constraint rows / solver output belong to the CURRENT qpos (see env_step)
 constexpr int IC_WANT_CON = 20, IC_WANT_EFC = 21;   // running maxima of the contacts / constraint rows a step WANTED (capacity planning)
 constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a non-zero Jacobian entry
 

@@ -148,7 +148,7 @@ struct World {
     const long long* snap_off;  // per task: element offset of goal 0
     const int* snap_stride;   // per task: elements per snapshot (= nstate + 39)
     const int* snap_ngoal;    // per task: number of goals (snapshots)
-    int max_episode_steps, terminate_on_success, one_hot, num_tasks;
+    int max_episode_steps, terminate_on_success, one_hot, num_tasks, full_forward;
     IOPtrs io;
 };
 
@@ -246,7 +246,7 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     Info info;
     for (int k = 0; k < 4; k++) act[k] = (T)w.io.act[(size_t)gid * 4 + k];
     e.I(e.lay().icount + 3) = 0;
-    env_step(e, td, act, obs, &reward, &success, &info);
+    env_step(e, td, act, obs, &reward, &success, &info, w.full_forward != 0);
     // Instability guard (the intent of the reference's dead `_did_see_sim_exception` branch, sawyer_xyz_env.py:603-619, and
     // of MuJoCo's own reset on a bad QACC): a non-finite step returns the last stable observation with reward 0, ends the
     // episode as truncated (so the SAME_STEP auto-reset below restores a valid state) and raises ST_UNSTABLE.
@@ -330,6 +330,7 @@ struct Config {
     int precision;   // 0 = fp32, 1 = fp64
     int device_id, rank, world_size;
     int max_episode_steps, terminate_on_success, one_hot, num_tasks;
+    int full_forward;   // 1 = complete final mj_forward for every task (see env_step)
 };
 
 struct TaskSpec {      // precision-independent TaskDesc
@@ -422,7 +423,7 @@ class Context : public ContextBase {
         w.groups = d_groups_; w.ngroups = (int)groups_.size(); w.tasks = d_tasks_;
         w.snap = d_snap_; w.snap_off = d_snap_off_; w.snap_stride = d_snap_stride_; w.snap_ngoal = d_snap_ngoal_;
         w.max_episode_steps = cfg.max_episode_steps; w.terminate_on_success = cfg.terminate_on_success;
-        w.one_hot = cfg.one_hot; w.num_tasks = cfg.num_tasks;
+        w.one_hot = cfg.one_hot; w.num_tasks = cfg.num_tasks; w.full_forward = cfg.full_forward;
         if (with_io) {
             w.io.act = d_act_; w.io.next_goal = d_next_goal_; w.io.obs = d_obs_; w.io.reward = d_reward_;
             w.io.terminated = d_flags_; w.io.truncated = d_flags_ + N_; w.io.success = d_flags_ + 2 * N_; w.io.done = d_flags_ + 3 * N_;

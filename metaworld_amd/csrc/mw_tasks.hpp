@@ -186,6 +186,7 @@ enum { G_OBJ = 0, G_LPAD = 1, G_RPAD = 2 };
 // Faithful to the reference's `efc_force[contact.efc_address]` including efc_address == -1 reading the LAST row.
 template <typename T>
 MW_HD bool touching_object(const Env<T> e, const TaskDesc<T>& td, int objgeom) {
+    if (!e.I(e.lay().icount + IC_DYN_VALID)) forward_dynamics(e);   // env_step stopped its final mj_forward after the kinematics
     const int ncon = e.I(e.lay().icount), nefc = e.I(e.lay().icount + 1);
     T fl = 0, fr = 0;
     for (int c = 0; c < ncon; c++) {
@@ -1266,8 +1267,13 @@ MW_HD void env_reset(const Env<T> e, const TaskDesc<T>& td, T* obs39) {
 }
 
 // SawyerXYZEnv.step (:579-642) up to (obs, reward, success, info); wrappers are applied by the caller
+// The final mj_forward is run LAZILY: the observation and every reward read only frames (kinematics); the collision ->
+// constraint -> solver half runs when (and only when) the task's reward asks for contact forces (touching_object does it on
+// demand), or always with `full_forward` (mw_config.full_forward: engine-level comparisons that read ncon / nefc / efc_force
+// after a step).  Same values either way: the two halves do not feed back into each other, and the next step's first
+// mj_step recomputes everything from (qpos, qvel, mocap, ctrl).  tests/test_lazy_forward.py holds the equivalence.
 template <typename T>
-MW_HD void env_step(const Env<T> e, const TaskDesc<T>& td, const T* act, T* obs39, T* reward, T* success, Info* info) {
+MW_HD void env_step(const Env<T> e, const TaskDesc<T>& td, const T* act, T* obs39, T* reward, T* success, Info* info, bool full_forward) {
     // set_xyz_action: mocap += clip(a,-1,1)*0.01, clipped to the mocap box
     // (the reference multiplies the float32 action by action_scale in float32: numpy keeps float32 * python-float in float32)
     for (int k = 0; k < 3; k++) {
@@ -1278,7 +1284,9 @@ MW_HD void env_step(const Env<T> e, const TaskDesc<T>& td, const T* act, T* obs3
     e.R(e.lay().ctrl) = act[3]; e.R(e.lay().ctrl + 1) = -act[3];
     for (int k = 0; k < 5; k++) substep(e);
     TK(e, TK_PATHLEN) += 1;
-    forward(e);
+    kinematics(e);
+    e.I(e.lay().icount + IC_DYN_VALID) = 0;
+    if (full_forward) forward_dynamics(e);
     get_obs(e, td, obs39);
     clip_obs(td, obs39);
     task_evaluate(e, td, obs39, act, reward, success, info);

@@ -18,7 +18,7 @@ NPROBE = 16
 
 class MwConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("precision", "device_id", "rank", "world_size", "max_episode_steps",
-                                         "terminate_on_success", "one_hot", "num_tasks")]
+                                         "terminate_on_success", "one_hot", "num_tasks", "full_forward")]
 
 
 class MwTask(C.Structure):
@@ -121,10 +121,10 @@ class Context:
     """Thin object wrapper over mw_ctx."""
 
     def __init__(self, lib: Lib, precision=0, device_id=0, rank=0, world_size=1, max_episode_steps=500,
-                 terminate_on_success=False, one_hot=False, num_tasks=1):
+                 terminate_on_success=False, one_hot=False, num_tasks=1, full_forward=False):
         self.lib = lib
         cfg = MwConfig(int(precision), device_id, rank, world_size, max_episode_steps, int(terminate_on_success),
-                       int(one_hot), num_tasks)
+                       int(one_hot), num_tasks, int(full_forward))
         self.ptr = C.c_void_p()
         rc = lib.create(C.byref(cfg), C.byref(self.ptr))
         self._check(rc)

@@ -81,7 +81,7 @@ class MetaWorldGpuVectorEnv:
                  partially_observable=None, task_select="random", meta_batch_size=None, total_tasks_per_cls=None,
                  recurrent_info_in_obs=False, normalize_reward_in_recurrent_info=True, reward_function_version="v2",
                  reward_normalization_method=None, reward_alpha=0.001, normalize_observations=False, envs_list=None,
-                 lanes_per_block=None, raise_on_status=False):
+                 lanes_per_block=None, raise_on_status=False, full_forward=False):
         """The keyword set of the reference's `_init_each_env` / `make_ml_envs` (metaworld/__init__.py:398-460, :516-618):
         `task_select` "random" = RandomTaskSelectWrapper, "pseudorandom" = PseudoRandomTaskSelectWrapper;
         `meta_batch_size` / `total_tasks_per_cls` = the ML split of each class's goals over sub-envs (`tasks[i::k]`);
@@ -89,7 +89,9 @@ class MetaWorldGpuVectorEnv:
         normalisation wrappers.  Only the v2 reward functions have device code.
         `precision`: "fp64" (default) = the reference's own arithmetic (float64 state, solver, observations): the mode whose GPU
         tests hold obs / reward <= 1e-5 against the reference traces; "fp32" is the opt-in throughput mode (success flags exact,
-        obs / reward within the single-precision contact-geometry floor)."""
+        obs / reward within the single-precision contact-geometry floor).
+        `full_forward`: True = every step ends with the complete mj_forward (callers that read ncon / nefc / contact forces
+        of the final state through `ctx.read*`); the default stops after the kinematics where no reward reads them."""
         if reward_function_version != "v2":
             raise NotImplementedError("only reward_function_version='v2' has device code (SURVEY.md 8f item 4)")
         if task_select not in ("random", "pseudorandom"):
@@ -128,7 +130,8 @@ class MetaWorldGpuVectorEnv:
         self._lib = lib or native.load()
         self.ctx = native.Context(self._lib, precision=1 if precision in ("fp64", 1) else 0, device_id=device_id,
                                   rank=rank, world_size=world_size, max_episode_steps=max_episode_steps or 500,
-                                  terminate_on_success=terminate_on_success, one_hot=use_one_hot, num_tasks=ntask)
+                                  terminate_on_success=terminate_on_success, one_hot=use_one_hot, num_tasks=ntask,
+                                  full_forward=full_forward)
         # env -> task (task-major contiguous blocks, like the reference's enumerate order)
         per, rem = divmod(self.num_envs, ntask)
         env_task_names = []

@@ -110,7 +110,7 @@ def test_gpu_lanes_per_block_invariance(gpulib, task, monkeypatch):
     runs = {}
     for lpb in ("64", "16", "8", "2", "1"):
         monkeypatch.setenv("MW_LANES_PER_BLOCK", lpb)
-        env = MetaWorldGpuVectorEnv("MT1", task, num_envs=6, seed=3, precision="fp64", lib=gpulib)
+        env = MetaWorldGpuVectorEnv("MT1", task, num_envs=6, seed=3, precision="fp64", lib=gpulib, full_forward=True)
         env.reset()
         qp, nc = [], []
         for t in range(40):

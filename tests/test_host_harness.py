@@ -84,7 +84,7 @@ def test_sub_lane_and_scratchpad_invariance(hostsim, task, monkeypatch):
     runs = {}
     for nsub, rows in (("1", "0"), ("1", "300"), ("4", "24"), ("8", "24"), ("8", "300"), ("32", "24"), ("64", "24")):
         monkeypatch.setenv("MW_NSUB", nsub); monkeypatch.setenv("MW_LDS_ROWS", rows)
-        env = MetaWorldGpuVectorEnv("MT1", task, num_envs=4, seed=3, precision="fp64", lib=hostsim)
+        env = MetaWorldGpuVectorEnv("MT1", task, num_envs=4, seed=3, precision="fp64", lib=hostsim, full_forward=True)
         env.reset()
         qp, nc = [], []
         for t in range(25):

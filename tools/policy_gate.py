@@ -13,8 +13,9 @@ import metaworld
 from metaworld.policies import ENV_POLICY_MAP
 from metaworld.env_dict import ALL_V3_ENVIRONMENTS
 names = list(ALL_V3_ENVIRONMENTS.keys())
+import os
 sel = sys.argv[1:] or names
-NE = 5
+NE = int(os.environ.get('MW_GATE_GOALS', '5'))        # the reference's own test walks all 50 (MW_GATE_GOALS=50)
 res = {}
 for name in sel:
     t=time.time()
@@ -22,7 +23,7 @@ for name in sel:
         mt1 = metaworld.MT1(name, seed=42)
         env = mt1.train_classes[name]()
         policy = ENV_POLICY_MAP[name]()
-        succ=0; ov=0
+        succ=0; ov=0; fails=[]
         for k,task in enumerate(mt1.train_tasks[:NE]):
             env.set_task(task)
             obs,info = env.reset()
@@ -31,10 +32,12 @@ for name in sel:
                 obs, r, te, tr, info = env.step(a)
                 if int(info['success'])==1:
                     succ+=1; break
+            else:
+                fails.append(k)
             ov = max(ov, env.data._od.info()['overflow'])
         res[name]=succ
-        print(f"{name:32s} succ {succ}/{NE}  nv={env.model.nv} overflow={ov} t={time.time()-t:.1f}s", flush=True)
+        print(f"{name:32s} succ {succ}/{NE}  nv={env.model.nv} overflow={ov} t={time.time()-t:.1f}s failed goals {fails}", flush=True)
     except Exception as e:
         print(f"{name:32s} ERROR {type(e).__name__}: {str(e)[:150]}", flush=True)
         res[name]=-1
-print('total ok tasks (>=4/5):', sum(1 for v in res.values() if v>=4), 'of', len(res))
+print(f'tasks passing the 80 % gate ({NE} goals):', sum(1 for v in res.values() if v >= 0.8 * NE), 'of', len(res))
