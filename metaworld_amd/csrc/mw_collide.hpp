@@ -491,23 +491,28 @@ MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V
     return 1;
 }
 
-// MPR's penetration direction depends on the interior ray (centre to centre): re-shoot the ray along the
-// normal just found until the depth stops decreasing (local minimum-translation direction).
+// MPR's penetration direction depends on the interior ray (centre to centre): re-shoot the ray along the normal just found
+// while the depth still decreases, at most MPR_RESHOOT_MAX times (the direction error shrinks by ~depth/radius per round; for
+// polytope pairs the first re-shot run confirms the face).  The cap is 2 because a wave waits for the slowest of its 64 lanes:
+// with 10 rounds the narrow phase of a late-episode MT50 step cost 3-4x what it costs without any (5.3-7.8 M vs 1.3-2.3 M
+// cycles per step, fp64), while the reference's scripted-policy gate gives identical per-task success counts for 2, 3 and 10.
+constexpr int MPR_RESHOOT_MAX = 2;
 template <typename T>
 MW_HD int mpr_refined(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h) {
     if (!mpr(A, B, margin, h)) return 0;
     const T rel = sizeof(T) == 8 ? T(1e-10) : T(1e-6);
-    for (int it = 0; it < 10; it++) {
+    for (int it = 0; it < MPR_RESHOOT_MAX; it++) {
         const T depth = margin - h->dist;
         if (depth <= T(1e-9)) break;
         const V3<T> v0 = h->normal * (T(0.02) * depth);
         Hit<T> h2;
+        MW_PAIR_ADD(3, 1)
         if (!mpr(A, B, margin, &h2, &v0)) break;
         const T d2 = margin - h2.dist;
         if (d2 > depth) break;
         *h = h2;
         if (depth - d2 <= rel * depth) { MW_HIST(3, it) break; }
-        if (it == 9) MW_HIST(3, 10)
+        if (it == MPR_RESHOOT_MAX - 1) MW_HIST(3, MPR_RESHOOT_MAX)
     }
     return 1;
 }

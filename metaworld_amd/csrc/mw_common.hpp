@@ -48,7 +48,7 @@ inline long* mw_cnt() { static long c[8] = {0}; return c; }
 #define MW_COUNT(i) mw_cnt()[i]++;
 inline long* mw_hist() { static long h[4 * 64] = {0}; return h; }
 #define MW_HIST(w, v) mw_hist()[(w) * 64 + ((v) < 63 ? (v) : 63)]++;
-// per geom-type-pair narrow-phase statistics: [t1][t2][0 calls, 1 portal iterations, 2 hill-climb steps, 3 hits]
+// per geom-type-pair narrow-phase statistics: [t1][t2][0 calls, 1 portal iterations, 2 hill-climb steps, 3 re-shot mpr() runs]
 inline long* mw_pairstat() { static long p[8 * 8 * 4] = {0}; return p; }
 inline int& mw_pair_cur() { static thread_local int c = 0; return c; }
 #define MW_PAIR_BEGIN(t1, t2) { mw_pair_cur() = ((t1) * 8 + (t2)) * 4; mw_pairstat()[mw_pair_cur()]++; }

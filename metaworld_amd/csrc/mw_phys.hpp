@@ -216,20 +216,9 @@ MW_HD void chol_solve_reg(const T* h, const T* inv, T* x) {
         x[i] = s * inv[i];
     }
 }
-// y = M x with M the full row-major n x n matrix at A (loads only)
-template <typename T, int NV>
-MW_HD void mat_vec(const Env<T> e, int A, int n, const T* x, T* y) {
-#pragma unroll
-    for (int k = 0; k < NV; k++) {      // x is zero beyond n; rows beyond n give unused values
-        T s = 0;
-#pragma unroll
-        for (int j = 0; j < NV; j++) s += e.R(A + ((k < n && j < n) ? k * n + j : 0)) * x[j];
-        y[k] = s;
-    }
-}
-// column dst <- M x, the rows split over the environment's sub-lanes (each row's sum in the same order as mat_vec: identical
-// values), then visible to all of them.  Replicating the 225 loads of M on every sub-lane was the largest part of a solver
-// iteration's serial remainder.
+// column dst <- M x (M the full row-major n x n matrix at A, x zero beyond n), the rows split over the environment's sub-lanes
+// (each row's sum in index order: identical values for any split), then visible to all of them.  The fully unrolled register form (mat_vec: nv^2 loads at nv^2 hoisted 64-bit addresses,
+// which the compiler kept in AGPRs / scratch and fetched one load per wait) cost 880 of the 970 kcycles of this phase per step.
 template <typename T, int NV>
 MW_HD void mat_vec_rows(const Env<T> e, int A, int n, const T* x, int dst) {
     MW_SUBS(e, sub) {
@@ -1015,12 +1004,7 @@ MW_HD void solve_impl(const Env<T> e) {
         T x[NV];
         vec_load<T, NV>(e, src, nv, x);
         vec_store<T, NV>(e, L.qacc, nv, x);
-        if (e.nsub > 1) mat_vec_rows<T, NV>(e, L.qM, nv, x, L.Ma);
-        else {
-            T y[NV];
-            mat_vec<T, NV>(e, L.qM, nv, x, y);
-            vec_store<T, NV>(e, L.Ma, nv, y);
-        }
+        mat_vec_rows<T, NV>(e, L.qM, nv, x, L.Ma);
         MW_SUBS(e, sub) {
             for (int i = sub; i < nefc; i += e.nsub) {
                 T j[NV], s = -EX(e, i, 4);
@@ -1068,13 +1052,8 @@ MW_HD void solve_impl(const Env<T> e) {
         {
             T Mv[NV];
             vec_store<T, NV>(e, L.search, nv, sr);
-            if (e.nsub > 1) {
-                mat_vec_rows<T, NV>(e, L.qM, nv, sr, L.Mv);
-                vec_load<T, NV>(e, L.Mv, nv, Mv);
-            } else {
-                mat_vec<T, NV>(e, L.qM, nv, sr, Mv);
-                vec_store<T, NV>(e, L.Mv, nv, Mv);
-            }
+            mat_vec_rows<T, NV>(e, L.qM, nv, sr, L.Mv);
+            vec_load<T, NV>(e, L.Mv, nv, Mv);
 #pragma unroll
             for (int k = 0; k < NV; k++) {
                 const int kk = k < nv ? k : 0;

@@ -605,10 +605,14 @@ static int mpr(const Shape* A, const Shape* B, double margin, Hit* h, const doub
 }
 
 /* MPR's penetration direction depends on the interior ray (centre to centre).  Re-shoot the ray along the
-   normal just found until the depth stops decreasing: converges to a local minimum-translation direction. */
+   normal just found while the depth still decreases, at most MPR_RESHOOT_MAX times: the error of the direction shrinks
+   by ~depth/radius per round towards a local minimum-translation direction (polytope pairs: the first re-shot run
+   confirms the face).  Two rounds: the reference's scripted-policy gate gives the same per-task success counts on all
+   contact-rich tasks as with 3 or 10 rounds, and on the GPU a wave waits for its slowest lane's rounds. */
+#define MPR_RESHOOT_MAX 2
 static int mpr_refined(const Shape* A, const Shape* B, double margin, Hit* h) {
     if (!mpr(A, B, margin, h, NULL)) return 0;
-    for (int it = 0; it < 10; it++) {
+    for (int it = 0; it < MPR_RESHOOT_MAX; it++) {
         double depth = margin - h->dist, v0[3];
         if (depth <= 1e-9) break;
         scl3(v0, h->normal, 0.02 * depth);

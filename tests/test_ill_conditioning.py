@@ -1,7 +1,7 @@
-"""The four tasks whose one-step tolerance is wider than 1e-5 (tests/test_tasks_parity.py::TOL) are not looser because the device
+"""The three tasks whose one-step tolerance is wider than 1e-5 (tests/test_tasks_parity.py::TOL) are not looser because the device
 code is less accurate there: at those states the REFERENCE ITSELF (its unmodified Python on the oracle engine) is ill-conditioned.
-Proof by perturbation: move the synchronised qpos by 1e-12 and the reference's own next observation moves by 1e-7 ... 2e-5 --
-an amplification of 1e5 ... 1e7 in ONE step (a contact at its activation margin / a face-on-face contact whose single contact
+Proof by perturbation: move the synchronised qpos by 1e-12 and the reference's own next observation moves by 2e-6 ... 8e-4 --
+an amplification of 1e6 ... 1e9 in ONE step (a contact at its activation margin / a face-on-face contact whose single contact
 point is not a continuous function of the poses), while the same experiment on reach-v3 returns the perturbation unamplified.
 No implementation that differs from the reference's arithmetic by one rounding can meet 1e-5 at such a state; the waived
 tolerances are set from this measured sensitivity."""
@@ -13,7 +13,7 @@ import pytest
 from tests.helpers import golden
 
 # (task, env index, step) of the largest device-vs-trace deviation of each waived task (host build, fp64); reach-v3 = control
-CASES = [("door-unlock-v3", 0, 35, 1e-7), ("peg-unplug-side-v3", 1, 0, 1e-7), ("door-close-v3", 0, 47, 1e-7), ("box-close-v3", 0, 28, 1e-7)]
+CASES = [("door-unlock-v3", 0, 41, 1e-5), ("peg-unplug-side-v3", 0, 4, 1e-5), ("door-close-v3", 0, 47, 1e-7)]
 
 
 def _step_reference_from(task, G, e, t, eps):
