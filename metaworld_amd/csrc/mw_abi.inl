@@ -28,6 +28,7 @@ int MW_API(model_set_option)(mw_model* m, const char* name, double v) {
     if (k == "timestep") m->d.timestep = v; else if (k == "tolerance") m->d.tolerance = v;
     else if (k == "reset_tolerance") m->d.reset_tolerance = v;
     else if (k == "lanes_per_block") m->d.lanes_per_block = (int)v;
+    else if (k == "step_ms_lpb4") m->d.step_ms_lpb4 = v; else if (k == "step_ms_lpb8") m->d.step_ms_lpb8 = v;
     else if (k == "meaninertia") m->d.meaninertia = v; else if (k == "gravity_z") m->d.gravity[2] = v;
     else if (k == "iterations") m->d.sz.iterations = (int)v; else if (k == "ls_iterations") m->d.sz.ls_iterations = (int)v;
     else if (k == "maxcon") m->d.sz.maxcon = (int)v; else if (k == "maxefc") m->d.sz.maxefc = (int)v;

@@ -25,7 +25,8 @@ struct Shape {
     T margin;
     // hill-climbing support for big hulls (metaworld_amd/mjcf.py add_mesh_graph): CSR adjacency of this mesh's vertices
     // (local ids), the direction cube map of start vertices, and the vertex the previous support call on this shape ended at
-    CP<int> nbradr, nbr, start;
+    CP<int> nbradr, nbr, start, nb8;
+    CP<T> nb8xyz, startxyz;   // first 8 neighbours of every vertex (ids / coordinates), coordinates of the start vertices
     int hill;
     mutable int hint;
     // everything except pos / mat is a model constant of the (wave-uniform) geom pair being tested
@@ -35,6 +36,8 @@ struct Shape {
         u.vert = (CP<T>)mw_uniform((unsigned long long)vert);
         u.nbradr = (CP<int>)mw_uniform((unsigned long long)nbradr); u.nbr = (CP<int>)mw_uniform((unsigned long long)nbr);
         u.start = (CP<int>)mw_uniform((unsigned long long)start); u.hill = mw_uniform(hill);
+        u.nb8 = (CP<int>)mw_uniform((unsigned long long)nb8); u.nb8xyz = (CP<T>)mw_uniform((unsigned long long)nb8xyz);
+        u.startxyz = (CP<T>)mw_uniform((unsigned long long)startxyz);
         for (int k = 0; k < 3; k++) u.size[k] = mw_uniform(size[k]);
         return u;
     }
@@ -341,8 +344,12 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
             // shape, else from the best of the fixed start candidates; strict improvement only.  An exhaustive scan
             // of the 884-vertex gripper hull cost ~20k cycles per call; the walk visits a few dozen vertices.
             // start: the cube-map cell of the direction (mjcf.py add_mesh_graph), or the previous call's result if that is higher
-            int cur = s.start[hill_cell(dl.x, dl.y, dl.z)];
-            bd = s.vert[3 * cur] * dl.x + s.vert[3 * cur + 1] * dl.y + s.vert[3 * cur + 2] * dl.z;
+            // One round trip per step: the start vertex comes with its coordinates (startxyz), and a vertex's first 8 neighbours
+            // with theirs (nb8 / nb8xyz, built at upload from the adjacency); only the ~7 % of vertices with more than 8
+            // neighbours go on through the adjacency lists.  Same comparisons in the same order as a walk over the lists.
+            const int cell = hill_cell(dl.x, dl.y, dl.z);
+            int cur = s.start[cell];
+            bd = s.startxyz[3 * cell] * dl.x + s.startxyz[3 * cell + 1] * dl.y + s.startxyz[3 * cell + 2] * dl.z;
             if (s.hint >= 0) {
                 const int hv = s.hint;
                 const T hd = s.vert[3 * hv] * dl.x + s.vert[3 * hv + 1] * dl.y + s.vert[3 * hv + 2] * dl.z;
@@ -353,7 +360,18 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
                 MW_PAIR_ADD(2, 1)
                 int nxt = cur;
                 const int j0 = s.nbradr[cur], j1 = s.nbradr[cur + 1];
-                for (int jb = j0; jb < j1; jb += 8) {        // neighbours in batches of 8: ids, then coordinates, issued together
+                {
+                    int id[8];
+                    T dd[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) id[q] = s.nb8[8 * cur + q];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) dd[q] = s.nb8xyz[24 * cur + 3 * q] * dl.x + s.nb8xyz[24 * cur + 3 * q + 1] * dl.y + s.nb8xyz[24 * cur + 3 * q + 2] * dl.z;
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                        if (j0 + q < j1 && dd[q] > bd) { bd = dd[q]; nxt = id[q]; }
+                }
+                for (int jb = j0 + 8; jb < j1; jb += 8) {        // further neighbours in batches of 8: ids, then coordinates, issued together
                     int id[8];
                     T dd[8];
 #pragma unroll
@@ -539,7 +557,7 @@ MW_HD int face_upgrade(const Shape<T>& c, const Shape<T>& box, Hit<T>* h, T marg
     pl.mat.m[3] = fy.y; pl.mat.m[4] = fz.y; pl.mat.m[5] = nf.y;
     pl.mat.m[6] = fy.z; pl.mat.m[7] = fz.z; pl.mat.m[8] = nf.z;
     pl.size[0] = pl.size[1] = pl.size[2] = 0; pl.vert = nullptr; pl.nvert = 0; pl.margin = 0;
-    pl.nbradr = nullptr; pl.nbr = nullptr; pl.start = nullptr; pl.hill = 0; pl.hint = -1;
+    pl.nbradr = nullptr; pl.nbr = nullptr; pl.start = nullptr; pl.nb8 = nullptr; pl.nb8xyz = nullptr; pl.startxyz = nullptr; pl.hill = 0; pl.hint = -1;
     Hit<T> t[8];
     int cnt = 0;
     V3<T> cax = col(c.mat, 2);
@@ -603,7 +621,7 @@ MW_HD Shape<T> make_shape(const Env<T> e, int g) {
     s.mat = ld9(e, e.lay().geom_xmat + 9 * g);
     for (int k = 0; k < 3; k++) s.size[k] = m.geom_size[3 * g + k];
     s.margin = 0; s.vert = nullptr; s.nvert = 0;
-    s.nbradr = nullptr; s.nbr = nullptr; s.start = nullptr; s.hill = 0; s.hint = -1;
+    s.nbradr = nullptr; s.nbr = nullptr; s.start = nullptr; s.nb8 = nullptr; s.nb8xyz = nullptr; s.startxyz = nullptr; s.hill = 0; s.hint = -1;
     if (s.type == G_MESH) {
         const int mi = m.geom_meshid[g];
         s.vert = m.mesh_vert + 3 * m.mesh_vertadr[mi];
@@ -613,6 +631,9 @@ MW_HD Shape<T> make_shape(const Env<T> e, int g) {
             s.nbradr = m.mesh_nbradr + m.mesh_vertadr[mi];
             s.nbr = m.mesh_nbr;
             s.start = m.mesh_start + 6 * HILL_GRID * HILL_GRID * mi;
+            s.startxyz = m.mesh_startxyz + 3 * 6 * HILL_GRID * HILL_GRID * mi;
+            s.nb8 = m.mesh_nb8 + 8 * m.mesh_vertadr[mi];
+            s.nb8xyz = m.mesh_nb8xyz + 24 * m.mesh_vertadr[mi];
         }
     }
     return s;
@@ -762,6 +783,7 @@ MW_STAGE_FN void collision(const Env<T> e_) {
         }
     } else {
         int ncand = 0;
+        MW_CTICK(tc0)
         for (int p0 = 0; p0 < npair; p0 += e.nsub) {
             int f[MW_NSLOT], foff[MW_NSLOT];
             MW_SUBS(e, sub) {
@@ -775,7 +797,11 @@ MW_STAGE_FN void collision(const Env<T> e_) {
             ncand += tot;
         }
         MW_SYNC();
+        MW_CTICK(tc1)
+        MW_CTOCK(e, L, 0, tc0, tc1)
+        MW_CADD(e, L, 2, ncand)
         for (int c0 = 0; c0 < ncand; c0 += e.nsub) {
+            MW_CADD(e, L, 3, 1)
             Hit<T> h[MW_NSLOT][16];
             int n[MW_NSLOT], off[MW_NSLOT], pp[MW_NSLOT];
             MW_SUBS(e, sub) {
@@ -797,6 +823,8 @@ MW_STAGE_FN void collision(const Env<T> e_) {
             want += total;
             if (ncon > maxcon) { ncon = maxcon; flags |= 2; }
         }
+        MW_CTICK(tc2)
+        MW_CTOCK(e, L, 1, tc1, tc2)
     }
     e.I(L.icount) = ncon;
     if (want > e.I(L.icount + IC_WANT_CON)) e.I(L.icount + IC_WANT_CON) = want;

@@ -34,14 +34,30 @@ namespace mw {
 // solver phase timers (shader clock), only in -DMW_SOLVER_TIMING device builds: accumulated in icount[4..11]
 #if defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 #define MW_TICK(var) const long long var = (long long)__builtin_amdgcn_s_memtime();
+#if defined(MW_COLL_TIMING)
+#define MW_TOCK(e, L, slot, t0, t1) if ((slot) >= 8) e.I(L.icount + 4 + (slot)) += (int)(((t1) - (t0)) >> 4);
+#define MW_TADD(e, L, slot, v)
+#else
 #define MW_TOCK(e, L, slot, t0, t1) e.I(L.icount + 4 + (slot)) += (int)(((t1) - (t0)) >> 4);
 #define MW_TADD(e, L, slot, v) e.I(L.icount + 4 + (slot)) += (v);
+#endif
 #else
 #define MW_TADD(e, L, slot, v)
 #define MW_TICK(var)
 #define MW_TOCK(e, L, slot, t0, t1)
 #endif
 
+// -DMW_COLL_TIMING (with -DMW_SOLVER_TIMING): the eight solver-phase slots are given to the collision stage instead
+// (0 mid phase, 1 narrow phase [cycles / 16]; 2 candidate pairs, 3 narrow-phase rounds [counts]); tools/experiments/coll_timing.py
+#if defined(MW_COLL_TIMING) && defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define MW_CTICK(var) const long long var = (long long)__builtin_amdgcn_s_memtime();
+#define MW_CTOCK(e, L, slot, t0, t1) e.I(L.icount + 4 + (slot)) += (int)(((t1) - (t0)) >> 4);
+#define MW_CADD(e, L, slot, v) e.I(L.icount + 4 + (slot)) += (v);
+#else
+#define MW_CTICK(var)
+#define MW_CTOCK(e, L, slot, t0, t1)
+#define MW_CADD(e, L, slot, v)
+#endif
 // iteration counters / histograms of the host profile build (tests/host_harness.cpp with -DMW_PROFILE)
 #if defined(MW_PROFILE) && !defined(__HIPCC__)
 inline long* mw_cnt() { static long c[8] = {0}; return c; }
@@ -150,6 +166,10 @@ struct Model {
     CP<T> geom_margin, geom_gap, geom_rbound, geom_invweight0, geom_aabb;
     CP<T> mesh_vert, act_kp, act_ctrlrange, eq_solref, eq_solimp, eq_data, eq_invweight0;
     CP<T> probe_pos, probe_quat;
+    // derived at upload (DeviceModel): per hull vertex its first 8 neighbours (ids, coordinates) and the coordinates of the
+    // cube-map start vertices, so that one hill-climbing step is ONE round trip instead of three (adjacency -> ids -> coordinates)
+    CP<int> mesh_nb8;
+    CP<T> mesh_nb8xyz, mesh_startxyz;
     Layout L;        // make_layout(sz)
 };
 

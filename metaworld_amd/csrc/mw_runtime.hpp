@@ -8,9 +8,11 @@
 //   template <class F> static void launch(int nblocks, F lane_program);   // F(block, thread, Scratchpad) for 64 threads / block
 //   static void sync();
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <map>
+#include <set>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -35,6 +37,7 @@ struct ModelData {
     double timestep = 0.0025, tolerance = 1e-10, meaninertia = 1, gravity[3] = {0, 0, -9.81};
     double reset_tolerance = 0;   // solver tolerance of the (double precision) reset-snapshot build; 0 = same as tolerance
     int lanes_per_block = 0;      // environments per workgroup for this model's group; 0 = the runtime's own choice (finalize)
+    double step_ms_lpb4 = 0, step_ms_lpb8 = 0;   // measured late-episode step time of this scene at 4 / 8 lanes per workgroup (0 = unknown)
     const std::vector<int>& I(const std::string& k) const {
         auto it = ints.find(k);
         if (it == ints.end()) throw std::runtime_error("model is missing int field " + k);
@@ -92,6 +95,35 @@ struct DeviceModel {
         std::vector<size_t> ioff, roff;
         for (auto& f : ifs) { ioff.push_back(ib.size()); const auto& v = d.I(f.name); ib.insert(ib.end(), v.begin(), v.end()); ib.push_back(0); }
         for (auto& f : rfs) { roff.push_back(rb.size()); const auto& v = d.Rr(f.name); for (double x : v) rb.push_back((T)x); rb.push_back(0); }
+        // derived hull tables (see Model::mesh_nb8): neighbour q < 8 of vertex v, padded with the last neighbour exactly like the
+        // batched walk in support() pads a short batch, so the walk compares the same values in the same order
+        size_t o_nb8, o_nb8xyz, o_startxyz;
+        {
+            const auto &vadr = d.I("mesh_vertadr"), &vnum = d.I("mesh_vertnum"), &nadr = d.I("mesh_nbradr"), &nbr = d.I("mesh_nbr"),
+                       &hill = d.I("mesh_hill"), &start = d.I("mesh_start");
+            const auto& vert = d.Rr("mesh_vert");
+            const size_t V = vert.size() / 3, nmesh = hill.size();
+            const size_t ncell = nmesh ? start.size() / nmesh : 0;
+            std::vector<int> nb8(V * 8 + 1, 0);
+            std::vector<T> nb8xyz(V * 24 + 1, T(0)), sxyz(nmesh * ncell * 3 + 1, T(0));
+            for (size_t mi = 0; mi < nmesh && mi < vadr.size(); mi++) {
+                if (!hill[mi]) continue;
+                const int va = vadr[mi];
+                for (int v = 0; v < vnum[mi]; v++) {
+                    const int j0 = nadr[va + v], j1 = nadr[va + v + 1];
+                    for (int q = 0; q < 8; q++) {
+                        const int id = j1 > j0 ? nbr[j0 + q < j1 ? j0 + q : j1 - 1] : v;
+                        nb8[(size_t)(va + v) * 8 + q] = id;
+                        for (int k = 0; k < 3; k++) nb8xyz[((size_t)(va + v) * 8 + q) * 3 + k] = (T)vert[3 * (size_t)(va + id) + k];
+                    }
+                }
+                for (size_t c = 0; c < ncell; c++)
+                    for (int k = 0; k < 3; k++) sxyz[(mi * ncell + c) * 3 + k] = (T)vert[3 * (size_t)(va + start[mi * ncell + c]) + k];
+            }
+            o_nb8 = ib.size(); ib.insert(ib.end(), nb8.begin(), nb8.end());
+            o_nb8xyz = rb.size(); rb.insert(rb.end(), nb8xyz.begin(), nb8xyz.end());
+            o_startxyz = rb.size(); rb.insert(rb.end(), sxyz.begin(), sxyz.end());
+        }
         iblob = (int*)Backend::alloc(ib.size() * sizeof(int));
         rblob = (T*)Backend::alloc(rb.size() * sizeof(T));
         Backend::h2d(iblob, ib.data(), ib.size() * sizeof(int));
@@ -100,6 +132,9 @@ struct DeviceModel {
         for (auto& f : ifs) { const int* q = iblob + ioff[k++]; ::memcpy(&(m.*(f.p)), &q, sizeof(q)); }
         k = 0;
         for (auto& f : rfs) { const T* q = rblob + roff[k++]; ::memcpy(&(m.*(f.p)), &q, sizeof(q)); }
+        { const int* q = iblob + o_nb8; ::memcpy(&m.mesh_nb8, &q, sizeof(q)); }
+        { const T* q = rblob + o_nb8xyz; ::memcpy(&m.mesh_nb8xyz, &q, sizeof(q)); }
+        { const T* q = rblob + o_startxyz; ::memcpy(&m.mesh_startxyz, &q, sizeof(q)); }
         m.sz = d.sz;
         m.L = make_layout(d.sz);
         m.timestep = (T)d.timestep; m.tolerance = (T)d.tolerance; m.meaninertia = (T)d.meaninertia;
@@ -491,26 +526,48 @@ public:
         groups_.resize(by_model.size());
         // Lanes per workgroup, per group.  The lane programs are latency-bound and a wave runs as long as its slowest lane,
         // so while the batch does not fill the chip (one wave per SIMD: the lane programs use all 512 VGPRs) the groups
-        // are spread over MORE, emptier waves whose idle threads become sub-lanes.  Greedy: halve the lanes-per-workgroup
-        // of the group with the largest (row capacity x lanes per workgroup) -- the heaviest wave -- while the grid still
-        // fits.  MW_LANES_PER_BLOCK forces one value for every group.
+        // are spread over MORE, emptier waves whose idle threads become sub-lanes.  The launch lasts as long as its slowest
+        // wave, so the waves go where they shorten the slowest group: each model carries the measured time of one late-episode
+        // step of its scene at 4 and at 8 lanes per workgroup (model options step_ms_lpb4 / step_ms_lpb8, shipped in
+        // metaworld_amd/data/model_caps.json; measured with tools/per_task_timing.py); between and beyond those two points the
+        // time is close to linear in the lanes (box-close 3.1 / 3.6 / 5.5 / 8.9 ms at 2 / 4 / 8 / 16, reach 1.45 / 1.49 /
+        // 1.67 / 2.0).  Greedy: halve the lanes of the group with the largest predicted time while the grid still fits the
+        // one-wave-per-SIMD budget; a group that no longer fits is frozen and the next one is tried.  A model without
+        // measurements is ranked by its row capacity.  MW_LANES_PER_BLOCK forces one value for every group.
         std::map<int, int> lpb_of;
         {
             const char* ov = getenv("MW_LANES_PER_BLOCK");
             const int budget = 4 * Backend::compute_units();
             auto blocks = [&]() { int nb = 0; for (auto& kv : by_model) nb += ((int)kv.second.size() + lpb_of[kv.first] - 1) / lpb_of[kv.first]; return nb; };
-            for (auto& kv : by_model) lpb_of[kv.first] = BLOCK;
+            auto predicted = [&](int model, int l) {
+                const ModelData& md = *models[model];
+                double t4 = md.step_ms_lpb4, t8 = md.step_ms_lpb8;
+                if (!(t4 > 0 && t8 >= t4)) { t4 = 1.0 + md.sz.maxefc / 150.0; t8 = 1.3 * t4; }
+                return t4 + (t8 - t4) * (l - 4) / 4.0;
+            };
+            // upper end of the search: the smallest uniform value that fits the budget (MT50 @ 4096: 8).  Going further (light scenes
+            // at 16+ lanes to give more heavy ones 2) looks better on the per-scene measurements and is worse on the whole
+            // batch: MT50 @ 4096 fp64 runs at 873 k env-steps/s with {2, 4, 8}, 864 k with 4 everywhere, 722 k once 16 is
+            // allowed (late in an episode EVERY scene has environments with expensive mesh contacts, tools/mix_timing.py)
+            int start = 1;
+            for (;; start *= 2) {
+                for (auto& kv : by_model) lpb_of[kv.first] = start;
+                if (start >= BLOCK || blocks() <= budget) break;
+            }
+            if (const char* mx = getenv("MW_LPB_MAX")) start = atoi(mx);
+            for (auto& kv : by_model) lpb_of[kv.first] = start;
+            std::set<int> frozen;
             for (;;) {
                 int best = -1; double bw = -1;
                 for (auto& kv : by_model) {
                     const int l = lpb_of[kv.first];
-                    if (l <= 4) continue;      // (2 and 1 lanes help the heaviest scene alone but cost the others more: measured)
-                    const double wgt = (double)models[kv.first]->sz.maxefc * l;
+                    if (l <= 2 || frozen.count(kv.first)) continue;      // (1 lane = 64 sub-lanes: the butterflies outgrow the sweeps)
+                    const double wgt = predicted(kv.first, l);
                     if (wgt > bw) { bw = wgt; best = kv.first; }
                 }
                 if (best < 0) break;
                 lpb_of[best] /= 2;
-                if (blocks() > budget) { lpb_of[best] *= 2; break; }
+                if (blocks() > budget) { lpb_of[best] *= 2; frozen.insert(best); }
             }
             for (auto& kv : by_model) {          // an explicit per-model choice (model option "lanes_per_block") wins over the proxy
                 const int l = models[kv.first]->lanes_per_block;
@@ -523,6 +580,13 @@ public:
                 if (l != 1 && l != 2 && l != 4 && l != 8 && l != 16 && l != 32 && l != 64) throw std::runtime_error("lanes per block must be a power of two <= 64");
                 for (auto& kv : by_model) lpb_of[kv.first] = l;
             }
+        }
+        if (getenv("MW_VERBOSE")) {
+            std::map<int, int> hist;
+            for (auto& kv : by_model) hist[lpb_of[kv.first]]++;
+            fprintf(stderr, "[mwgpu] lanes per workgroup -> number of scenes:");
+            for (auto& kv : hist) fprintf(stderr, " %d:%d", kv.first, kv.second);
+            fprintf(stderr, "\n");
         }
         int gi = 0, blk = 0;
         for (auto& kv : by_model) {

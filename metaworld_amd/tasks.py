@@ -190,7 +190,7 @@ def model_probes(model_name):
 
 
 with open(os.path.join(_HERE, "data", "model_caps.json")) as _f:
-    MODEL_CAPS = json.load(_f)     # per-model contact / constraint-row capacities: 2 x the demand measured on the GPU over whole episodes of random actions at MT50 @ 4096 (tools/measure_caps_gpu.py)
+    MODEL_CAPS = json.load(_f)     # per model: contact / constraint-row capacities = 2 x the demand measured on the GPU over whole episodes of random actions at MT50 @ 4096 (tools/measure_caps_gpu.py); step_ms_lpb4 / 8 = ms per late-episode step of the scene alone (82 envs, fp64, steps 250-350 of random actions; tools/per_task_timing.py, max over the tasks sharing the scene)
 
 
 def packed_model(model_name, maxcon=None, maxefc=None, **kw):
@@ -204,7 +204,11 @@ def packed_model(model_name, maxcon=None, maxefc=None, **kw):
             for b in d.get("reloc", []):
                 if b not in reloc:
                     reloc.append(b)
-    return pack_model(compiled_model(model_name), probes, reloc_bodies=reloc, maxcon=maxcon, maxefc=maxefc, **kw), roles, reloc
+    pk = pack_model(compiled_model(model_name), probes, reloc_bodies=reloc, maxcon=maxcon, maxefc=maxefc, **kw)
+    for k in ("step_ms_lpb4", "step_ms_lpb8"):          # measured step time of the scene at 4 / 8 lanes per workgroup: the runtime's
+        if k in caps:                                     # lanes-per-workgroup assignment ranks the groups by it (mw_runtime.hpp finalize)
+            pk["options"][k] = caps[k]
+    return pk, roles, reloc
 
 
 def task_struct(task, model_index, roles, reloc, onehot_id, partially_observable=False) -> native.MwTask:
