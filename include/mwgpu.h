@@ -58,7 +58,8 @@ typedef struct mw_task {
  * Options: timestep, tolerance (solver tolerance of the context's precision), reset_tolerance (tolerance of the
  * double-precision reset-snapshot build; default = tolerance), meaninertia, gravity_z, iterations, ls_iterations,
  * maxcon, maxefc (contact / constraint-row capacities per environment), nreloc, lanes_per_block (environments per
- * 64-thread workgroup of this model's group, a power of two; 0 = the runtime's choice). */
+ * 64-thread workgroup of this model's group, a power of two; 0 = the runtime's choice), step_ms_lpb4 / step_ms_lpb8 (measured
+ * time of one late-episode step of this scene at 4 / 8 environments per workgroup: ranks the groups when the runtime chooses). */
 mw_model* mw_model_new(void);
 int mw_model_set_int(mw_model* m, const char* field, const int32_t* v, int n);
 int mw_model_set_real(mw_model* m, const char* field, const double* v, int n);
