@@ -170,6 +170,7 @@ struct Model {
     // cube-map start vertices, so that one hill-climbing step is ONE round trip instead of three (adjacency -> ids -> coordinates)
     CP<int> mesh_nb8;
     CP<T> mesh_nb8xyz, mesh_startxyz;
+    CP<int> body_dofmask;   // derived at upload: bit i = dof i lies on the chain from body b to the root (nv <= 31)
     Layout L;        // make_layout(sz)
 };
 

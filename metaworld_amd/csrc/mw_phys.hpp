@@ -456,23 +456,14 @@ MW_HD void row_range(const Env<T> e, int row, int first, int last) {
     if (first < IEFC(e, row, 3)) IEFC(e, row, 3) = first;
     if (last > IEFC(e, row, 4)) IEFC(e, row, 4) = last;
 }
-// J rows (translational/rotational) of a world point on body b: accumulate sign * axis . jac into row
-template <typename T>
-MW_HD void add_jac_row(const Env<T> e, int row, int body, V3<T> point, V3<T> axis, bool rotational, T sign) {
-    CModel<T>& m = e.model();
-    const int last = m.body_lastdof[body];
-    int first = last;
-    for (int i = last; i >= 0; i = m.dof_parentid[i]) {
-        V3<T> w = ld3(e, e.lay().cdof + 6 * i);
-        T val;
-        if (rotational) val = dot(axis, w);
-        else val = dot(axis, ld3(e, e.lay().cdof + 6 * i + 3) + cross(w, point));
-        EJ(e, row, i) += sign * val;
-        first = i;
-    }
-    if (last >= 0) row_range(e, row, first, last);
-}
-
+// Jacobian rows are filled DOF BY DOF: body_dofmask[b] (derived at upload) says which dofs lie on body b's chain, so the motion
+// axes cdof[i] are loaded once per dof at an address that does not depend on a previous load, and every entry
+// J[row][i] = sign_a * (axis . jac_a) + sign_b * (axis . jac_b) is stored once.  (The row-by-row form walked dof_parentid for
+// every row and body: ~2 dependent round trips per entry, and a read-modify-write of the row in the column store.)  The two
+// terms are added in the order the reference-style accumulation used (first body of the call order first), so the values
+// are the same.
+MW_HD int mask_first(int mask) { int i = 0; while (!((mask >> i) & 1)) i++; return i; }
+MW_HD int mask_last(int mask) { int i = 31; while (!((mask >> i) & 1)) i--; return i; }
 // initialise rows r0 .. r0+n-1 of one constraint (type, id): empty Jacobian rows, descriptor, friction scale
 template <typename T>
 MW_HD void init_rows(const Env<T> e, int r0, int n, int type, int id) {
@@ -501,26 +492,26 @@ MW_HD void weld_rows(const Env<T> e, int q, int r0) {
     Q4<T> q2n = qconj(ld4(e, L.xquat + 4 * b2));
     Q4<T> qr = qmul(q2n, qa);
     init_rows(e, r0, 6, C_EQUALITY, q);
-    for (int k = 0; k < 3; k++) {
-        V3<T> ax{T(k == 0), T(k == 1), T(k == 2)};
-        add_jac_row(e, r0 + k, b1, p1, ax, false, T(1));
-        add_jac_row(e, r0 + k, b2, p2, ax, false, T(-1));
-    }
+    // translational rows k: + axis_k . (v + w x p1) of body 1, - axis_k . (v + w x p2) of body 2
     // rotational rows: 0.5 * imag( conj(q2) * (w1 - w2) * q1 * rel ) * torquescale
-    for (int pass = 0; pass < 2; pass++) {
-        const int b = pass ? b2 : b1;
-        const T sg = pass ? T(-1) : T(1);
-        int first = m.body_lastdof[b];
-        for (int i = m.body_lastdof[b]; i >= 0; i = m.dof_parentid[i]) {
-            V3<T> w = ld3(e, L.cdof + 6 * i);
-            Q4<T> q4 = qmul(qmul(q2n, Q4<T>{0, w.x, w.y, w.z}), qa);
-            EJ(e, r0 + 3, i) += sg * T(0.5) * q4.x * ts;
-            EJ(e, r0 + 4, i) += sg * T(0.5) * q4.y * ts;
-            EJ(e, r0 + 5, i) += sg * T(0.5) * q4.z * ts;
-            first = i;
+    const int m1 = m.body_dofmask[b1], m2 = m.body_dofmask[b2], both = m1 | m2;
+    for (int i = 0; i < e.nv; i++) {
+        if (!((both >> i) & 1)) continue;
+        const V3<T> w = ld3(e, L.cdof + 6 * i), v = ld3(e, L.cdof + 6 * i + 3);
+        const bool in1 = (m1 >> i) & 1, in2 = (m2 >> i) & 1;
+        const V3<T> l1 = v + cross(w, p1), l2 = v + cross(w, p2);
+        const Q4<T> q4 = qmul(qmul(q2n, Q4<T>{0, w.x, w.y, w.z}), qa);
+        const T rot[3] = {q4.x, q4.y, q4.z};
+        for (int k = 0; k < 3; k++) {
+            V3<T> ax{T(k == 0), T(k == 1), T(k == 2)};
+            T acc = 0, acr = 0;
+            if (in1) { acc += T(1) * dot(ax, l1); acr += T(1) * T(0.5) * rot[k] * ts; }
+            if (in2) { acc += T(-1) * dot(ax, l2); acr += T(-1) * T(0.5) * rot[k] * ts; }
+            EJ(e, r0 + k, i) = acc;
+            EJ(e, r0 + 3 + k, i) = acr;
         }
-        if (m.body_lastdof[b] >= 0) for (int k = 3; k < 6; k++) row_range(e, r0 + k, first, m.body_lastdof[b]);
     }
+    if (both) for (int k = 0; k < 6; k++) { IEFC(e, r0 + k, 3) = mask_first(both); IEFC(e, r0 + k, 4) = mask_last(both); }
     const T res[6] = {cp.x, cp.y, cp.z, ts * qr.x, ts * qr.y, ts * qr.z};
     for (int k = 0; k < 6; k++) {
         EX(e, r0 + k, 0) = res[k];
@@ -551,12 +542,22 @@ MW_HD void contact_rows(const Env<T> e, int c, int r0) {
     init_rows(e, r0, dim, C_CONTACT, c);
     const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
     V3<T> pos{CON(e, c, 1), CON(e, c, 2), CON(e, c, 3)};
-    for (int k = 0; k < dim; k++) {
-        const int a = k < 3 ? k : k - 3;
-        V3<T> ax{CON(e, c, 4 + 3 * a), CON(e, c, 5 + 3 * a), CON(e, c, 6 + 3 * a)};
-        add_jac_row(e, r0 + k, b2, pos, ax, k >= 3, T(1));
-        add_jac_row(e, r0 + k, b1, pos, ax, k >= 3, T(-1));
+    const int m1 = m.body_dofmask[b1], m2 = m.body_dofmask[b2], both = m1 | m2;
+    V3<T> ax[3];
+    for (int a = 0; a < 3; a++) ax[a] = V3<T>{CON(e, c, 4 + 3 * a), CON(e, c, 5 + 3 * a), CON(e, c, 6 + 3 * a)};
+    for (int i = 0; i < e.nv; i++) {
+        if (!((both >> i) & 1)) continue;
+        const V3<T> w = ld3(e, L.cdof + 6 * i), lin = ld3(e, L.cdof + 6 * i + 3) + cross(w, pos);
+        const bool in1 = (m1 >> i) & 1, in2 = (m2 >> i) & 1;
+        for (int k = 0; k < dim; k++) {
+            const T val = k >= 3 ? dot(ax[k - 3], w) : dot(ax[k], lin);
+            T acc = 0;
+            if (in2) acc += T(1) * val;            // body 2 first, then body 1 (the order of the row-by-row accumulation)
+            if (in1) acc += T(-1) * val;
+            EJ(e, r0 + k, i) = acc;
+        }
     }
+    if (both) for (int k = 0; k < dim; k++) { IEFC(e, r0 + k, 3) = mask_first(both); IEFC(e, r0 + k, 4) = mask_last(both); }
     EX(e, r0, 0) = dist; EX(e, r0, 1) = inc;
     T solref[2] = {CON(e, c, 17), CON(e, c, 18)}, solimp[5];
     for (int k = 0; k < 5; k++) solimp[k] = CON(e, c, 19 + k);

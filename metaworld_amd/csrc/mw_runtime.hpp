@@ -97,7 +97,7 @@ struct DeviceModel {
         for (auto& f : rfs) { roff.push_back(rb.size()); const auto& v = d.Rr(f.name); for (double x : v) rb.push_back((T)x); rb.push_back(0); }
         // derived hull tables (see Model::mesh_nb8): neighbour q < 8 of vertex v, padded with the last neighbour exactly like the
         // batched walk in support() pads a short batch, so the walk compares the same values in the same order
-        size_t o_nb8, o_nb8xyz, o_startxyz;
+        size_t o_nb8, o_nb8xyz, o_startxyz, o_dofmask;
         {
             const auto &vadr = d.I("mesh_vertadr"), &vnum = d.I("mesh_vertnum"), &nadr = d.I("mesh_nbradr"), &nbr = d.I("mesh_nbr"),
                        &hill = d.I("mesh_hill"), &start = d.I("mesh_start");
@@ -121,6 +121,14 @@ struct DeviceModel {
                     for (int k = 0; k < 3; k++) sxyz[(mi * ncell + c) * 3 + k] = (T)vert[3 * (size_t)(va + start[mi * ncell + c]) + k];
             }
             o_nb8 = ib.size(); ib.insert(ib.end(), nb8.begin(), nb8.end());
+            // chain mask of every body (see Model::body_dofmask): the Jacobian rows are then filled dof by dof without walking
+            // dof_parentid (a chain of dependent loads per row and body)
+            const auto &lastdof = d.I("body_lastdof"), &dpar = d.I("dof_parentid");
+            if (d.sz.nv > 31) throw std::runtime_error("body_dofmask: more than 31 dofs");
+            std::vector<int> dm(lastdof.size() + 1, 0);
+            for (size_t b = 0; b < lastdof.size(); b++)
+                for (int i = lastdof[b]; i >= 0; i = dpar[i]) dm[b] |= 1 << i;
+            o_dofmask = ib.size(); ib.insert(ib.end(), dm.begin(), dm.end());
             o_nb8xyz = rb.size(); rb.insert(rb.end(), nb8xyz.begin(), nb8xyz.end());
             o_startxyz = rb.size(); rb.insert(rb.end(), sxyz.begin(), sxyz.end());
         }
@@ -133,6 +141,7 @@ struct DeviceModel {
         k = 0;
         for (auto& f : rfs) { const T* q = rblob + roff[k++]; ::memcpy(&(m.*(f.p)), &q, sizeof(q)); }
         { const int* q = iblob + o_nb8; ::memcpy(&m.mesh_nb8, &q, sizeof(q)); }
+        { const int* q = iblob + o_dofmask; ::memcpy(&m.body_dofmask, &q, sizeof(q)); }
         { const T* q = rblob + o_nb8xyz; ::memcpy(&m.mesh_nb8xyz, &q, sizeof(q)); }
         { const T* q = rblob + o_startxyz; ::memcpy(&m.mesh_startxyz, &q, sizeof(q)); }
         m.sz = d.sz;
