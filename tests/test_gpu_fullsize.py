@@ -38,6 +38,7 @@ def _oracle_synced_to(ctx, e, task):
 @pytest.mark.parametrize("bench,n", CONFIGS)
 def test_fullsize_batch_matches_small_batches_and_oracle(gpulib, bench, n):
     from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    from tests.test_tasks_parity import TOL
     big = MetaWorldGpuVectorEnv(bench, num_envs=n, seed=42, use_one_hot=True, precision="fp64", lib=gpulib)
     obs, _ = big.reset()
     names = big.task_list
@@ -65,8 +66,12 @@ def test_fullsize_batch_matches_small_batches_and_oracle(gpulib, bench, n):
             assert su[0] == rec[t][2][e], (name, t)
         small.close()
         worst[name] = (eo, er, ei)
-        # float32 observation dtype of the one-hot space (metaworld/wrappers.py:27-29) bounds the comparison at ~1e-7
-        assert eo < 2e-6 and er < 1e-7 and ei < 1e-5, (name, worst[name])
+        # float32 observation dtype of the one-hot space (metaworld/wrappers.py:27-29) bounds the comparison at ~1e-7.
+        # The big batch and the 2-env batch run this task with different numbers of cooperating sub-lanes (different
+        # summation order, ~1e-16); the three tasks whose states amplify 1e-12 to 1e-5 ... 1e-3 in ONE step
+        # (tests/test_ill_conditioning.py) carry that through 12 open-loop steps (measured: peg-unplug 1.8e-4 / 1.7e-3)
+        lim = (2e-3, 2e-2, 2e-2) if name in TOL else (2e-6, 1e-7, 1e-5)
+        assert eo < lim[0] and er < lim[1] and ei < lim[2], (name, worst[name])
     # (b) oracle one substep-batch from the synchronised device state, deep into contact-rich motion
     for t in range(NS, 60):
         big.ctx.step(acts[t], big._next_goal)

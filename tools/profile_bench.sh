@@ -35,4 +35,6 @@ prec=$(echo "$args" | grep -q "fp32" && echo fp32 || echo fp64)
 python tools/summarize_pmc.py "$out/pmc_*/**/*counter_collection.csv" --kernel step_device_only --json "$out/pmc.json" \
   --workload "MT50 sync-vector, 4096 envs/GPU, $prec, random actions" --kernel-ms "$kms" > "$out/pmc_summary.txt" 2>&1
 grep -h '^{' "$out/kt.log" | tail -1 > "$out/bench_line_under_kernel_trace.json"
+# keep the summaries only (gpurun copies at most 64 MiB back; the raw kernel trace + counter CSVs are ~40 MB per run)
+rm -rf "$out/kt" "$out"/pmc_*/
 du -sh "$out"
