@@ -973,7 +973,9 @@ MW_STAGE_FN void newton_direction(const Env<T> e_) {
             }
         }
     }
+    MW_TICK(t_rows)
     sub_sum_n<NT>(e, H);
+    MW_TICK(t_bfly)
     HT inv[NV], sh[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) sh[k] = k < nv ? (HT)e.R(L.grad + k) : HT(0);
@@ -982,6 +984,9 @@ MW_STAGE_FN void newton_direction(const Env<T> e_) {
 #pragma unroll
     for (int k = 0; k < NV; k++)
         if (k < nv) e.R(L.search + k) = (T)sh[k];
+    MW_TICK(t_end)
+    MW_TOCK(e, L, 2, t_rows, t_bfly)      // timing builds: slot 2 ("chol") = butterfly of the partial Hessians + factorisation + solve
+    MW_TOCK(e, L, 2, t_bfly, t_end)
 }
 
 template <typename T, int NV>

@@ -100,8 +100,10 @@ def test_gpu_task_fp32_close_to_reference_trace(gpulib, task):
     assert r["reset"] < 1e-2 and r["obs"] < 1e-2 and r["reward"] < 5e-2 and r["success_mismatch"] == 0, r
 
 
-@pytest.mark.parametrize("task", ["box-close-v3", "door-unlock-v3", "shelf-place-v3", "sweep-into-v3"])
-def test_gpu_lanes_per_block_invariance(gpulib, task, monkeypatch):
+@pytest.mark.parametrize("task,precision", [(t, "fp64") for t in ("box-close-v3", "door-unlock-v3", "shelf-place-v3", "sweep-into-v3", "hammer-v3",
+                                                               "plate-slide-v3", "stick-pull-v3", "reach-v3")]
+                         + [(t, "fp32") for t in ("box-close-v3", "hammer-v3", "stick-pull-v3")])
+def test_gpu_lanes_per_block_invariance(gpulib, task, precision, monkeypatch):
     """The mapping of environments to lanes (64 per wave, no sub-lanes ... 8 per wave, 8 cooperating sub-lanes each) must
     not change the physics: contact lists identical, states equal up to summation order.  Guards the wave-uniformity
     assumptions and the cross-sub-lane synchronisation, which the host harness cannot exercise."""
@@ -110,7 +112,7 @@ def test_gpu_lanes_per_block_invariance(gpulib, task, monkeypatch):
     runs = {}
     for lpb in ("64", "16", "8", "2", "1"):
         monkeypatch.setenv("MW_LANES_PER_BLOCK", lpb)
-        env = MetaWorldGpuVectorEnv("MT1", task, num_envs=6, seed=3, precision="fp64", lib=gpulib, full_forward=True)
+        env = MetaWorldGpuVectorEnv("MT1", task, num_envs=6, seed=3, precision=precision, lib=gpulib, full_forward=True)
         env.reset()
         qp, nc = [], []
         for t in range(40):
@@ -123,7 +125,8 @@ def test_gpu_lanes_per_block_invariance(gpulib, task, monkeypatch):
         # identical while the trajectories are numerically the same; a contact that sits exactly at its margin may then flip
         # between configurations (summation order differs), after which a chaotic scene drifts apart
         assert (runs[lpb][1][:12] == runs["64"][1][:12]).all(), "contact / row counts differ"
-        assert np.abs(runs[lpb][0][:12] - runs["64"][0][:12]).max() < 1e-7          # (inexact-Newton iterates depend on the summation order)
+        # (inexact-Newton iterates depend on the summation order; single precision: 1.6e-6 over 40 steps on the host build)
+        assert np.abs(runs[lpb][0][:12] - runs["64"][0][:12]).max() < (1e-7 if precision == "fp64" else 1e-5)
         assert (runs[lpb][1] != runs["64"][1]).mean() < 0.1
         assert np.abs(runs[lpb][0] - runs["64"][0]).max() < 1e-2
 
