@@ -536,13 +536,12 @@ public:
         // Lanes per workgroup, per group.  The lane programs are latency-bound and a wave runs as long as its slowest lane,
         // so while the batch does not fill the chip (one wave per SIMD: the lane programs use all 512 VGPRs) the groups
         // are spread over MORE, emptier waves whose idle threads become sub-lanes.  The launch lasts as long as its slowest
-        // wave, so the waves go where they shorten the slowest group: each model carries the measured time of one late-episode
-        // step of its scene at 4 and at 8 lanes per workgroup (model options step_ms_lpb4 / step_ms_lpb8, shipped in
-        // metaworld_amd/data/model_caps.json; measured with tools/per_task_timing.py); between and beyond those two points the
-        // time is close to linear in the lanes (box-close 3.1 / 3.6 / 5.5 / 8.9 ms at 2 / 4 / 8 / 16, reach 1.45 / 1.49 /
-        // 1.67 / 2.0).  Greedy: halve the lanes of the group with the largest predicted time while the grid still fits the
-        // one-wave-per-SIMD budget; a group that no longer fits is frozen and the next one is tried.  A model without
-        // measurements is ranked by its row capacity.  MW_LANES_PER_BLOCK forces one value for every group.
+        // wave, so the waves go where they shorten the slowest group: each model carries two measured numbers (model options
+        // step_ms_lpb4 / step_ms_lpb8, shipped in metaworld_amd/data/model_caps.json): its critical-path weight at 4 lanes per
+        // workgroup inside the MT50 @ 4096 workload (tools/mix_timing.py) and the same scaled by its 8-lane / 4-lane step-time
+        // ratio (tools/per_task_timing.py).  Greedy: halve the lanes of the group with the largest predicted time while the grid
+        // still fits the one-wave-per-SIMD budget; a group that no longer fits is frozen and the next one is tried.  A model
+        // without measurements is ranked by its row capacity.  MW_LANES_PER_BLOCK forces one value for every group.
         std::map<int, int> lpb_of;
         {
             const char* ov = getenv("MW_LANES_PER_BLOCK");
@@ -552,11 +551,14 @@ public:
                 const ModelData& md = *models[model];
                 double t4 = md.step_ms_lpb4, t8 = md.step_ms_lpb8;
                 if (!(t4 > 0 && t8 >= t4)) { t4 = 1.0 + md.sz.maxefc / 150.0; t8 = 1.3 * t4; }
-                return t4 + (t8 - t4) * (l - 4) / 4.0;
+                // measured shape of t(lanes) relative to the step t8 - t4 (box-close 2.7 / 3.1 / 3.6 / 5.5 / 8.9 ms at 1 / 2 / 4 / 8 / 16
+                // lanes, reach 1.45 / 1.49 / 1.67 / 2.0 at 2 / 4 / 8 / 16): linear above 4, flattening below (more butterfly stages)
+                const double f = l >= 4 ? (l - 4) / 4.0 * (l > 8 ? 0.93 : 1.0) : (l == 2 ? -0.4 : -0.55);
+                return t4 + (t8 - t4) * f;
             };
             // upper end of the search: the smallest uniform value that fits the budget (MT50 @ 4096: 8).  Going further (light scenes
             // at 16+ lanes to give more heavy ones 2) looks better on the per-scene measurements and is worse on the whole
-            // batch: MT50 @ 4096 fp64 runs at 873 k env-steps/s with {2, 4, 8}, 864 k with 4 everywhere, 722 k once 16 is
+            // batch: MT50 @ 4096 fp64 ran at 873 k env-steps/s with {2, 4, 8}, 864 k with 4 everywhere, 722 k once 16 was
             // allowed (late in an episode EVERY scene has environments with expensive mesh contacts, tools/mix_timing.py)
             int start = 1;
             for (;; start *= 2) {
@@ -570,7 +572,7 @@ public:
                 int best = -1; double bw = -1;
                 for (auto& kv : by_model) {
                     const int l = lpb_of[kv.first];
-                    if (l <= 2 || frozen.count(kv.first)) continue;      // (1 lane = 64 sub-lanes: the butterflies outgrow the sweeps)
+                    if (l <= 1 || frozen.count(kv.first)) continue;
                     const double wgt = predicted(kv.first, l);
                     if (wgt > bw) { bw = wgt; best = kv.first; }
                 }

@@ -190,7 +190,7 @@ def model_probes(model_name):
 
 
 with open(os.path.join(_HERE, "data", "model_caps.json")) as _f:
-    MODEL_CAPS = json.load(_f)     # per model: contact / constraint-row capacities = 2 x the demand measured on the GPU over whole episodes of random actions at MT50 @ 4096 (tools/measure_caps_gpu.py); step_ms_lpb4 / 8 = ms per late-episode step of the scene alone (82 envs, fp64, steps 250-350 of random actions; tools/per_task_timing.py, max over the tasks sharing the scene)
+    MODEL_CAPS = json.load(_f)     # per model: contact / constraint-row capacities = 2 x the demand measured on the GPU over whole episodes of random actions at MT50 @ 4096 (tools/measure_caps_gpu.py); step_ms_lpb4 = critical-path weight of the scene inside the MT50 @ 4096 bench workload at 4 lanes per workgroup (largest per-env cycle count of a step / 2.4e6, tools/mix_timing.py, max over the tasks sharing the scene), step_ms_lpb8 = the same scaled by the scene's isolated 8-lane / 4-lane step-time ratio (tools/per_task_timing.py)
 
 
 def packed_model(model_name, maxcon=None, maxefc=None, **kw):
