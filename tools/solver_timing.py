@@ -21,7 +21,10 @@ names = ["warm", "Hasm", "chol", "MvJv", "lsrch", "update", "n_ls", "n_newt", "k
 for task in sys.argv[2:]:
     env = MetaWorldGpuVectorEnv("MT1", task, num_envs=n, seed=0, precision=prec, lib=lib)
     env.reset()
-    env.ctx.upload_actions(np.random.default_rng(0).uniform(-1, 1, (64, n, 4)).astype(np.float32))
+    acts = np.random.default_rng(0).uniform(-1, 1, (64, n, 4)).astype(np.float32)
+    if os.environ.get("MW_SAME_ACTIONS"):          # every env identical (same goal stream, same actions): no divergence between lanes
+        acts[:] = acts[:, :1]
+    env.ctx.upload_actions(acts)
     for w in range(nwin):
         ic0 = np.array([env.ctx.read_int(e, "icount") for e in range(n)])
         ms = env.ctx.step_resident(win) / win
