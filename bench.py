@@ -179,7 +179,10 @@ def prepare(env, args, rank):
         env.ctx.set_episode_phase((np.arange(N, dtype=np.int64) * 7919 % HORIZON).astype(np.int32))
         env.ctx.step_resident(HORIZON)
     env.ctx.step_resident(args.warmup)
-    env.ctx.status(clear=True)
+    st = env.ctx.status(clear=True)
+    if st["flags"] and not args.allow_status:          # the timed region continues from this state: an overflow here counts too
+        raise RuntimeError(f"bench: the step kernel raised status flags {st} during the untimed pre-roll / warm-up (1/2 = constraint-row / "
+                           "contact capacity exceeded, 4 = non-finite state)")
 
 
 def check_outputs(env, allow):

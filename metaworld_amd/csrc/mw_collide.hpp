@@ -827,7 +827,11 @@ MW_STAGE_FN void collision(const Env<T> e_) {
         MW_CTOCK(e, L, 1, tc1, tc2)
     }
     e.I(L.icount) = ncon;
-    if (want > e.I(L.icount + IC_WANT_CON)) e.I(L.icount + IC_WANT_CON) = want;
+    // demand statistic (capacity planning only): taken from sub-lane 0, which is active in every narrow-phase round.  On the GPU
+    // the copies of `want` in sub-lanes that sat out a round's (divergent, non-inlined) collide_pair call came back as garbage
+    // in long MT50 runs -- `ncon`, which is consumed inside the loop, never did; see DESIGN.md 5 "compiler sensitivity"
+    want = sub_first(e, want);
+    if (e.sub == 0 && want > e.I(L.icount + IC_WANT_CON)) e.I(L.icount + IC_WANT_CON) = want;
     if (flags) e.I(L.icount + 3) |= flags;
     MW_SYNC();
 }

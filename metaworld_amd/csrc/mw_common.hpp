@@ -294,6 +294,9 @@ __device__ inline void sub_sum_n(const Env<T>& e, U (*p)[N]) {
         for (int k = 0; k < N; k++) p[0][k] += __shfl_xor(p[0][k], off);
     }
 }
+// the value sub-lane 0 of the environment holds
+template <typename T>
+__device__ inline int sub_first(const Env<T>& e, int v) { return __shfl(v, e.thr % e.lds_stride); }
 // exclusive prefix of one int per sub-lane (in sub-lane order) and the total
 template <typename T>
 __device__ inline int sub_scan(const Env<T>& e, const int* n, int* off) {
@@ -322,6 +325,8 @@ inline U sub_sum(const Env<T>& e, const U* p) {
     }
     return q[0];
 }
+template <typename T>
+inline int sub_first(const Env<T>&, int v) { return v; }
 template <typename T>
 inline int sub_scan(const Env<T>& e, const int* n, int* off) {
     int tot = 0;

@@ -18,22 +18,28 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
 out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "model_caps_measured.json")
 demand = {}
-for seed in (1, 2):
-    env = MetaWorldGpuVectorEnv("MT50", num_envs=n, seed=seed, use_one_hot=True, precision="fp32", maxcon=192, maxefc=768)
+# two generic seeds + the bench workload itself (bench.py: seed 42, action stream rng(0) of length 64, staggered episode phases), fp32 and fp64
+RUNS = [(1, 1, 97, False, "fp32"), (42, 0, 64, True, "fp32"), (42, 0, 64, True, "fp64")]
+for seed, aseed, alen, stagger, prec in RUNS:
+    env = MetaWorldGpuVectorEnv("MT50", num_envs=n, seed=seed, use_one_hot=True, precision=prec, maxcon=192, maxefc=768)
     env.reset()
-    env.ctx.upload_actions(np.random.default_rng(seed).uniform(-1, 1, (97, n, 4)).astype(np.float32))
+    env.ctx.upload_actions(np.random.default_rng(aseed).uniform(-1, 1, (alen, n, 4)).astype(np.float32))
+    if stagger:
+        env.ctx.set_episode_phase((np.arange(n, dtype=np.int64) * 7919 % 500).astype(np.int32))
     env.ctx.step_resident(steps)
-    print("seed", seed, "status", env.ctx.status(), flush=True)
+    print("seed", seed, prec, "status", env.ctx.status(), flush=True)
+    ic = env.ctx.read_int_all("icount", 24) if hasattr(env.ctx, "read_int_all") else np.array([env.ctx.read_int(e, "icount", 24) for e in range(n)])
     for e, name in enumerate(env.env_task_names):
-        ic = env.ctx.read_int(e, "icount", 24)
         m = T.TASK_CONST[name]["model"]
         d = demand.setdefault(m, [0, 0])
-        d[0] = max(d[0], int(ic[20])); d[1] = max(d[1], int(ic[21]))
+        d[0] = max(d[0], int(ic[e][20])); d[1] = max(d[1], int(ic[e][21]))
     env.close()
+cur = T.MODEL_CAPS
 caps = {m: {"maxcon": int(-(-d[0] * 3 // 2) // 8 * 8 + 8), "maxefc": int(-(-d[1] * 3 // 2) // 8 * 8 + 8), "measured_ncon": d[0], "measured_nefc": d[1]}
         for m, d in sorted(demand.items())}
 os.makedirs(os.path.dirname(out), exist_ok=True)
 with open(out, "w") as f:
     json.dump(caps, f, indent=1)
 for m, c in caps.items():
-    print(f"{m:36s} wanted ncon {c['measured_ncon']:3d} nefc {c['measured_nefc']:3d} -> maxcon {c['maxcon']:3d} maxefc {c['maxefc']:3d}")
+    tight = "  <-- current capacity below 2x demand" if (cur[m]["maxcon"] < 2 * c["measured_ncon"] or cur[m]["maxefc"] < 2 * c["measured_nefc"]) else ""
+    print(f"{m:36s} wanted ncon {c['measured_ncon']:3d} nefc {c['measured_nefc']:3d}  (shipped maxcon {cur[m]['maxcon']:3d} maxefc {cur[m]['maxefc']:3d}){tight}")
