@@ -38,3 +38,10 @@ def test_bench_cpu_baseline_leg_runs_on_the_oracle():
     assert r["kind"] == "port" and r["cores"] == (os.cpu_count() or 1) and r["unit"] == "env-steps/s" and 1e2 < r["value"] < 1e7
     assert 1e2 < r["single_core_value"] < 1e6 and "2 tasks in equal shares" in r["sample"]
     assert r["full_step_port"]["value"] > 0          # physics + obs + reward on the host cores (host build of the lane programs)
+
+
+def test_every_entry_point_is_mapped_to_the_reference_in_integration_md():
+    hdr = open(os.path.join(ROOT, "include", "mwgpu.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = set(re.findall(r"\b(mw_[a-z_]+)\s*\(", hdr))
+    assert not [s for s in sorted(declared) if s not in doc]
