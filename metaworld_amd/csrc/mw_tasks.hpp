@@ -1249,6 +1249,12 @@ MW_HD void task_after_reset(const Env<T> e, const TaskDesc<T>& td, V3<T> persist
     if (!td.partially_observable) { obs39[36] = s.x; obs39[37] = s.y; obs39[38] = s.z; }
 }
 
+#if defined(MW_REWARD_V1)
+}  // namespace mw
+#include "mw_tasks_v1.hpp"   // reward_function_version = "v1": a separate build of the library (libmwgpu_v1.so), see the header
+namespace mw {
+#endif
+
 // =========================================================================== env-level reset / step
 // SawyerXYZEnv.reset (:664-682) second pass semantics: mj_resetData -> reset_model -> obs with prev := curr.
 // (The first reset_model pass only leaves model writes behind; they are functions of rand_vec and are
@@ -1261,6 +1267,9 @@ MW_HD void env_reset(const Env<T> e, const TaskDesc<T>& td, T* obs39) {
     const V3<T> persist = tk3(e, TK_PERSIST0);
     task_model_writes(e, td);
     task_reset_model(e, td);
+#if defined(MW_REWARD_V1)
+    task_reset_v1(e, td);
+#endif
     get_obs(e, td, obs39);
     for (int k = 0; k < 18; k++) { obs39[18 + k] = obs39[k]; TK(e, TK_PREVOBS + k) = obs39[k]; }
     task_after_reset(e, td, persist, obs39);
@@ -1289,7 +1298,11 @@ MW_HD void env_step(const Env<T> e, const TaskDesc<T>& td, const T* act, T* obs3
     if (full_forward) forward_dynamics(e);
     get_obs(e, td, obs39);
     clip_obs(td, obs39);
+#if defined(MW_REWARD_V1)
+    task_evaluate_v1(e, td, obs39, act, reward, success, info);
+#else
     task_evaluate(e, td, obs39, act, reward, success, info);
+#endif
 }
 
 }  // namespace mw

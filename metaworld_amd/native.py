@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmwgpu.so")
+LIB_PATH_V1 = os.path.join(os.path.dirname(LIB_PATH), "libmwgpu_v1.so")          # reward_function_version="v1" (csrc/mw_tasks_v1.hpp)
 NPROBE = 16
 
 
@@ -56,6 +57,7 @@ class Lib:
             except Exception:
                 pass
         self.dll = C.CDLL(path)
+        self.path = path
         self.prefix = prefix
         f = self._f
         f("model_new", C.c_void_p)

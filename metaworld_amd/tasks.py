@@ -66,23 +66,29 @@ TASK_DEFS = {
     "faucet-close-v3": dict(objs=[_obj((S, "handleStartClose"), (B, "faucetBase"), QUAT_MUJOCO, (0, 0, -0.01))], reloc=["faucetBase"]),
     "handle-press-side-v3": dict(objs=[_obj((S, "handleStart"), None, QUAT_ZERO)], extra=[(S, "goalPress")], reloc=["box"]),
     "handle-press-v3": dict(objs=[_obj((S, "handleStart"), None, QUAT_ZERO)], extra=[(S, "goalPress")], reloc=["box"]),
-    "handle-pull-side-v3": dict(objs=[_obj((S, "handleCenter"), None, QUAT_ZERO)], extra=[(S, "goalPull")], reloc=["box"]),
-    "handle-pull-v3": dict(objs=[_obj((S, "handleRight"), None, QUAT_ZERO)], extra=[(S, "goalPull")], reloc=["box"]),
+    "handle-pull-side-v3": dict(objs=[_obj((S, "handleCenter"), None, QUAT_ZERO)], extra=[(S, "goalPull")], reloc=["box"],
+                                extra_v1=[(S, "handleStart")]),
+    "handle-pull-v3": dict(objs=[_obj((S, "handleRight"), None, QUAT_ZERO)], extra=[(S, "goalPull")], reloc=["box"],
+                           c_model_v1=[("site_pos", "handleStart", 2)]),
     "lever-pull-v3": dict(objs=[_obj((S, "leverStart"), (G, "objGeom"), QUAT_SCIPY)], reloc=["lever"], joints=["LeverAxis"]),
     "window-open-v3": dict(objs=[_obj((S, "handleOpenStart"), None, QUAT_ZERO)], reloc=["window"], joints=["window_slide"]),
     "window-close-v3": dict(objs=[_obj((S, "handleCloseStart"), None, QUAT_ZERO)], reloc=["window"], joints=["window_slide"]),
     "plate-slide-v3": dict(objs=[_obj((G, "puck"), (G, "puck"), QUAT_SCIPY)], reloc=["puck_goal"], geom="puck"),
     "plate-slide-side-v3": dict(objs=[_obj((G, "puck"), (G, "puck"), QUAT_SCIPY)], geom="puck"),
-    "plate-slide-back-v3": dict(objs=[_obj((G, "puck"), (G, "puck"), QUAT_SCIPY)], reloc=["puck_goal"], geom="puck"),
+    # (-side and -back only write data.body("puck_goal").xpos, which the next mj_forward overwrites: the goal body stays where the
+    #  XML puts it; they must NOT share a relocatable-body slot with the variant that moves it, see model_key)
+    "plate-slide-back-v3": dict(objs=[_obj((G, "puck"), (G, "puck"), QUAT_SCIPY)], geom="puck"),
     "plate-slide-back-side-v3": dict(objs=[_obj((G, "puck"), (G, "puck"), QUAT_SCIPY)], reloc=["puck_goal"], geom="puck"),
     "assembly-v3": dict(objs=[_obj((S, "RoundNut-8"), (B, "RoundNut"), QUAT_MUJOCO)], extra=[(S, "RoundNut")], reloc=["peg"], geom="WrenchHandle"),
     "disassemble-v3": dict(objs=[_obj((S, "RoundNut-8"), (B, "RoundNut"), QUAT_MUJOCO)], extra=[(S, "RoundNut")], reloc=["peg"], geom="WrenchHandle"),
     "hammer-v3": dict(objs=[_obj((B, "hammer"), (B, "hammer"), QUAT_MUJOCO), _obj((B, "nail_link"), (B, "nail_link"), QUAT_MUJOCO)],
-                      extra=[(S, "goal")], reloc=["box"], joints=["NailSlideJoint"], geom="HammerHandle"),
-    "basketball-v3": dict(objs=[_obj((B, "bsktball"), (B, "bsktball"), QUAT_MUJOCO)], extra=[(S, "goal")], reloc=["basket_goal"]),
+                      extra=[(S, "goal")], reloc=["box"], joints=["NailSlideJoint"], geom="HammerHandle",
+                      extra_v1=[(G, "HammerHead"), (S, "nailHead")]),
+    "basketball-v3": dict(objs=[_obj((B, "bsktball"), (B, "bsktball"), QUAT_MUJOCO)], extra=[(S, "goal")], reloc=["basket_goal"],
+                          extra_v1=[(G, "objGeom")]),
     "box-close-v3": dict(objs=[_obj((B, "top_link"), (B, "top_link"), QUAT_MUJOCO)], reloc=["boxbody"], geom="BoxHandleGeom",
-                         c_model=[("body_pos", "boxbody", 2)]),
-    "pick-out-of-hole-v3": dict(objs=[_obj((B, "obj"), (B, "obj"), QUAT_MUJOCO)]),
+                         c_model=[("body_pos", "boxbody", 2)], extra_v1=[(G, "BoxHandleGeom")]),
+    "pick-out-of-hole-v3": dict(objs=[_obj((B, "obj"), (B, "obj"), QUAT_MUJOCO)], extra_v1=[(G, "objGeom")]),
     "shelf-place-v3": dict(objs=[_obj((B, "obj"), (G, "objGeom"), QUAT_SCIPY)], reloc=["shelf"], c_model=[("site_pos", "goal", None)]),
     "peg-insert-side-v3": dict(objs=[_obj((S, "pegGrasp"), (S, "pegGrasp"), QUAT_SCIPY)], reloc=["box"],
                                extra=[(S, "pegHead"), (S, "bottom_right_corner_collision_box_1"), (S, "top_left_corner_collision_box_1"),
@@ -99,6 +105,20 @@ with open(os.path.join(_HERE, "data", "task_constants.json")) as _f:
 ALL_V3 = _CONST["all_v3"]          # index = MT50 one-hot id (metaworld/env_dict.py:217-270)
 MT10 = _CONST["mt10"]              # MT10 order (metaworld/env_dict.py:278-291)
 TASK_CONST = _CONST["tasks"]
+
+
+# tasks whose `reward_function_version="v1"` branch is restated on the device (csrc/mw_tasks_v1.hpp), by MT50 id there
+V1_TASKS = ["reach-v3", "reach-wall-v3",
+            "button-press-topdown-v3", "button-press-topdown-wall-v3", "button-press-v3", "button-press-wall-v3", "coffee-button-v3",
+            "dial-turn-v3", "door-close-v3", "door-lock-v3", "door-open-v3", "door-unlock-v3", "drawer-close-v3", "drawer-open-v3",
+            "faucet-open-v3", "faucet-close-v3", "handle-press-side-v3", "handle-press-v3", "handle-pull-side-v3", "handle-pull-v3",
+            "lever-pull-v3", "plate-slide-v3", "plate-slide-side-v3", "plate-slide-back-v3", "plate-slide-back-side-v3",
+            "window-open-v3", "window-close-v3",
+            "push-v3", "push-back-v3", "push-wall-v3", "coffee-push-v3", "coffee-pull-v3", "soccer-v3", "sweep-v3", "sweep-into-v3",
+            "hand-insert-v3",
+            "pick-place-v3", "pick-place-wall-v3", "shelf-place-v3", "pick-out-of-hole-v3", "basketball-v3", "box-close-v3",
+            "peg-insert-side-v3", "bin-picking-v3", "peg-unplug-side-v3", "assembly-v3", "disassemble-v3", "hammer-v3",
+            "stick-push-v3", "stick-pull-v3"]
 
 
 def supported_tasks():
@@ -161,8 +181,9 @@ def compiled_model(name):
     return _model_cache[name]
 
 
-def model_probes(model_name):
-    """union of the probes of every task that uses this model -> (list, {task: [probe ids by role]})"""
+def model_probes(model_name, v1=False):
+    """union of the probes of every task that uses this model -> (list, {task: [probe ids by role]}); v1: + the frames only the
+    v1 reward functions read (`extra_v1`)"""
     probes = list(COMMON_PROBES)
     roles = {}
     for task, d in TASK_DEFS.items():
@@ -179,7 +200,7 @@ def model_probes(model_name):
                 ids.append(probes.index(p))
         while len(ids) < 7 + 4:
             ids.append(-1)
-        for p in d.get("extra", []):
+        for p in d.get("extra", []) + (d.get("extra_v1", []) if v1 else []):
             if p not in probes:
                 probes.append(p)
             ids.append(probes.index(p))
@@ -193,17 +214,25 @@ with open(os.path.join(_HERE, "data", "model_caps.json")) as _f:
     MODEL_CAPS = json.load(_f)     # per model: contact / constraint-row capacities = 2 x the demand measured on the GPU over whole episodes of random actions at MT50 @ 4096 (tools/measure_caps_gpu.py); step_ms_lpb4 = critical-path weight of the scene inside the MT50 @ 4096 bench workload at 4 lanes per workgroup (largest per-env cycle count of a step / 2.4e6, tools/mix_timing.py, max over the tasks sharing the scene), step_ms_lpb8 = the same scaled by the scene's isolated 8-lane / 4-lane step-time ratio (tools/per_task_timing.py)
 
 
-def packed_model(model_name, maxcon=None, maxefc=None, **kw):
+def model_key(task):
+    """Tasks share one packed model (= one group of the runtime) when they use the same scene AND relocate the same bodies: a body
+    that is relocatable in the tables reads its position from a per-env slot, which only the tasks that write
+    `model.body(X).pos` at reset fill in (plate-slide-side / -back never do: their goal body must keep its XML position)."""
+    return TASK_CONST[task]["model"], tuple(TASK_DEFS[task].get("reloc", []))
+
+
+def packed_model(model_name, maxcon=None, maxefc=None, v1=False, reloc_bodies=None, **kw):
     caps = MODEL_CAPS.get(model_name, dict(maxcon=64, maxefc=256))
     maxcon = maxcon or caps["maxcon"]
     maxefc = maxefc or caps["maxefc"]
-    probes, roles = model_probes(model_name)
-    reloc = []
-    for task, d in TASK_DEFS.items():
-        if TASK_CONST[task]["model"] == model_name:
-            for b in d.get("reloc", []):
-                if b not in reloc:
-                    reloc.append(b)
+    probes, roles = model_probes(model_name, v1=v1)
+    reloc = list(reloc_bodies) if reloc_bodies is not None else []
+    if reloc_bodies is None:          # (union over the scene's tasks: only right when they all relocate the same bodies, see model_key)
+        for task, d in TASK_DEFS.items():
+            if TASK_CONST[task]["model"] == model_name:
+                for b in d.get("reloc", []):
+                    if b not in reloc:
+                        reloc.append(b)
     pk = pack_model(compiled_model(model_name), probes, reloc_bodies=reloc, maxcon=maxcon, maxefc=maxefc, **kw)
     for k in ("step_ms_lpb4", "step_ms_lpb8"):          # measured step time of the scene at 4 / 8 lanes per workgroup: the runtime's
         if k in caps:                                     # lanes-per-workgroup assignment ranks the groups by it (mw_runtime.hpp finalize)
@@ -211,7 +240,7 @@ def packed_model(model_name, maxcon=None, maxefc=None, **kw):
     return pk, roles, reloc
 
 
-def task_struct(task, model_index, roles, reloc, onehot_id, partially_observable=False) -> native.MwTask:
+def task_struct(task, model_index, roles, reloc, onehot_id, partially_observable=False, v1=False) -> native.MwTask:
     c, d = TASK_CONST[task], TASK_DEFS[task]
     t = native.MwTask()
     t.kind, t.model, t.onehot_id = c["id"], model_index, onehot_id
@@ -251,7 +280,7 @@ def task_struct(task, model_index, roles, reloc, onehot_id, partially_observable
     for v in d.get("c", []):
         t.c[k] = v
         k += 1
-    for arr, name, comp in d.get("c_model", []):      # constants read from the compiled model (XML values)
+    for arr, name, comp in d.get("c_model", []) + (d.get("c_model_v1", []) if v1 else []):      # constants read from the compiled model (XML values)
         kind = "body" if arr == "body_pos" else "site"
         vals = m.arrays[arr][m.names[kind][name]]
         for v in ([vals[comp]] if comp is not None else vals):

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import time
 
+import os
+
 import numpy as np
 
 from . import native, tasks as T
@@ -92,8 +94,9 @@ class MetaWorldGpuVectorEnv:
         obs / reward within the single-precision contact-geometry floor).
         `full_forward`: True = every step ends with the complete mj_forward (callers that read ncon / nefc / contact forces
         of the final state through `ctx.read*`); the default stops after the kinematics where no reward reads them."""
-        if reward_function_version != "v2":
-            raise NotImplementedError("only reward_function_version='v2' has device code (SURVEY.md 8f item 4)")
+        if reward_function_version not in ("v1", "v2"):
+            raise ValueError(f"reward_function_version must be 'v1' or 'v2', got {reward_function_version!r}")
+        v1 = reward_function_version == "v1"
         if task_select not in ("random", "pseudorandom"):
             raise ValueError(f"task_select must be 'random' or 'pseudorandom', got {task_select!r}")
         if reward_normalization_method not in (None, "gymnasium", "exponential"):
@@ -127,7 +130,17 @@ class MetaWorldGpuVectorEnv:
         # makes it visible for ML too (tests/metaworld/test_evaluation.py:70-82) -> overridable
         self.partially_observable = benchmark.startswith("ML") if partially_observable is None else bool(partially_observable)
         self.seed_value = seed
-        self._lib = lib or native.load()
+        if v1:
+            # the v1 reward functions live in their own build of the library (csrc/mw_tasks_v1.hpp, -DMW_REWARD_V1); tasks whose
+            # v1 branch has no device restatement yet are refused here rather than silently evaluated with v2
+            missing_v1 = [n for n in names if n not in T.V1_TASKS]
+            if missing_v1:
+                raise NotImplementedError(f"reward_function_version='v1' has no device code yet for: {missing_v1}")
+        self.reward_function_version = reward_function_version
+        self._lib = lib or (native.load("mw_", native.LIB_PATH_V1) if v1 else native.load())
+        if v1 != ("_v1" in os.path.basename(getattr(self._lib, "path", ""))):          # a library of the other flavour was handed in
+            raise ValueError(f"reward_function_version={reward_function_version!r} needs the {'v1' if v1 else 'v2'} build of the library "
+                             f"(got {getattr(self._lib, 'path', self._lib)})")
         self.ctx = native.Context(self._lib, precision=1 if precision in ("fp64", 1) else 0, device_id=device_id,
                                   rank=rank, world_size=world_size, max_episode_steps=max_episode_steps or 500,
                                   terminate_on_success=terminate_on_success, one_hot=use_one_hot, num_tasks=ntask,
@@ -145,14 +158,15 @@ class MetaWorldGpuVectorEnv:
         self._task_index = {}
         self.goal_tables = {}
         for oh, name in enumerate(names):
-            mname = T.TASK_CONST[name]["model"]
-            if mname not in model_index:
-                pk, roles, reloc = T.packed_model(mname, maxcon=maxcon, maxefc=maxefc,
+            mkey = T.model_key(name)          # (scene, relocated bodies): tasks share a group only if both agree
+            mname = mkey[0]
+            if mkey not in model_index:
+                pk, roles, reloc = T.packed_model(mname, maxcon=maxcon, maxefc=maxefc, v1=v1, reloc_bodies=mkey[1],
                                                   tolerance=None if precision in ("fp64", 1) else 1e-6)
                 if mname in self.lanes_per_block:
                     pk["options"]["lanes_per_block"] = self.lanes_per_block[mname]
-                model_index[mname] = self.ctx.add_model(pk)
-                roles_of[mname], reloc_of[mname] = roles, reloc
+                model_index[mkey] = self.ctx.add_model(pk)
+                roles_of[mkey], reloc_of[mkey] = roles, reloc
             if benchmark == "custom-mt":          # env idx is built as MT1(name, seed + idx)
                 goals = T.custom_goal_tables((name,), goal_seed + oh)[name]
             elif benchmark == "custom-ml":        # one `_make_tasks` stream over the class list
@@ -162,7 +176,7 @@ class MetaWorldGpuVectorEnv:
             if total_tasks_per_cls is not None:          # only the first total_tasks_per_cls goals of a class are ever selected
                 goals = goals[:max(1, int(total_tasks_per_cls))]
             self.goal_tables[name] = goals
-            ts = T.task_struct(name, model_index[mname], roles_of[mname], reloc_of[mname], onehot_id=oh,
+            ts = T.task_struct(name, model_index[mkey], roles_of[mkey], reloc_of[mkey], onehot_id=oh, v1=v1,
                                partially_observable=self.partially_observable)
             self._task_index[name] = self.ctx.add_task(ts, goals)
         self.model_index = model_index

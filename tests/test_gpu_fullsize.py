@@ -21,7 +21,7 @@ CONFIGS = [("MT50", 4096), ("MT10", 10240)]
 def _oracle_synced_to(ctx, e, task):
     from oracle.mjlite import OracleData, OracleModel
     mname = T.TASK_CONST[task]["model"]
-    pk, roles, reloc = T.packed_model(mname)
+    pk, roles, reloc = T.packed_model(mname, reloc_bodies=T.model_key(task)[1])
     cm = T.compiled_model(mname)
     om = OracleModel(cm)
     om.view("eq_data")[:] = WELD

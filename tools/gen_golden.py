@@ -27,11 +27,11 @@ warnings.filterwarnings("ignore")
 INFO_KEYS = ["near_object", "grasp_success", "grasp_reward", "in_place_reward", "obj_to_target", "unscaled_reward"]
 
 
-def run_task(name, seed, episodes, steps, mode, rng):
+def run_task(name, seed, episodes, steps, mode, rng, reward_version="v2"):
     import metaworld
     from metaworld.policies import ENV_POLICY_MAP
     mt1 = metaworld.MT1(name, seed=seed)
-    env = mt1.train_classes[name]()
+    env = mt1.train_classes[name](reward_function_version=reward_version)
     env.seed(seed)
     policy = ENV_POLICY_MAP[name]()
     import pickle
@@ -78,14 +78,16 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--mode", default="mixed", choices=["random", "policy", "mixed"])
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--reward-version", default="v2", choices=["v1", "v2"], help="v1: files are named trace_v1_<task>_seed<seed>.npz")
     args = ap.parse_args()
     from oracle import refshim
     refshim.install()
     os.makedirs(args.out, exist_ok=True)
     for name in args.tasks:
         rng = np.random.default_rng(args.seed)
-        res = run_task(name, args.seed, args.episodes, args.steps, args.mode, rng)
-        path = os.path.join(args.out, f"trace_{name}_seed{args.seed}.npz")
+        res = run_task(name, args.seed, args.episodes, args.steps, args.mode, rng, args.reward_version)
+        tag = "v1_" if args.reward_version == "v1" else ""
+        path = os.path.join(args.out, f"trace_{tag}{name}_seed{args.seed}.npz")
         np.savez_compressed(path, **res)
         print(name, "->", path, f"({os.path.getsize(path) / 1024:.0f} KiB)", "success steps:", int(res["success"].sum()))
 
