@@ -10,7 +10,10 @@ from tests.helpers import oracle_for
 MODELS = ["sawyer_reach_v3", "sawyer_door_pull", "sawyer_stick_obj", "sawyer_coffee", "sawyer_window_horizontal"]
 
 
-@pytest.mark.parametrize("name", MODELS)
+ALL_MODELS = sorted({T.TASK_CONST[t]["model"] for t in T.supported_tasks()})
+
+
+@pytest.mark.parametrize("name", ALL_MODELS)
 def test_fk_and_mass_matrix_match_numpy(name):
     m = T.compiled_model(name)
     om, d = oracle_for(name)
@@ -149,3 +152,176 @@ def test_solver_output_is_physically_consistent(hostsim, task):
             rows += nefc
     env.close()
     assert rows > 0
+
+
+def _integrate(A, q, v, eps):
+    """q (+) eps v on the configuration manifold (free joint: world-frame translation, body-frame rotation)"""
+    from metaworld_amd.mjcf import J_FREE, qmul
+    q = q.copy()
+    for j in range(len(A["jnt_type"])):
+        qa, da = A["jnt_qposadr"][j], A["jnt_dofadr"][j]
+        if A["jnt_type"][j] == J_FREE:
+            q[qa:qa + 3] += eps * v[da:da + 3]
+            w = v[da + 3:da + 6] * eps
+            th = np.linalg.norm(w)
+            dq = np.concatenate([[np.cos(th / 2)], np.sin(th / 2) * w / th]) if th > 0 else np.array([1.0, 0, 0, 0])
+            q[qa + 3:qa + 7] = qmul(q[qa + 3:qa + 7], dq)
+        else:
+            q[qa] += eps * v[da]
+    return q
+
+
+@pytest.mark.parametrize("name", MODELS + ["sawyer_hammer"])
+def test_bias_forces_match_the_lagrangian(name):
+    """qfrc_bias (recursive Newton-Euler in the oracle: Coriolis + centrifugal + gravity) against Lagrange's equations evaluated by
+    central differences of the model compiler's numpy mass matrix and potential energy:
+    c = Mdot v - 1/2 d(v'Mv)/dq + dU/dq   (free bodies at rest: their rotational velocities are quasi-velocities)"""
+    from metaworld_amd.mjcf import J_FREE
+    m = T.compiled_model(name)
+    A = m.arrays
+    om, d = oracle_for(name)
+    rng = np.random.default_rng(0)
+    nv = om.nv
+    q, v = A["qpos0"].copy(), np.zeros(nv)
+    for j in range(len(A["jnt_type"])):
+        qa, da = A["jnt_qposadr"][j], A["jnt_dofadr"][j]
+        if A["jnt_type"][j] == J_FREE:
+            q[qa:qa + 3] += rng.uniform(-0.1, 0.1, 3)
+            qq = rng.normal(size=4)
+            q[qa + 3:qa + 7] = qq / np.linalg.norm(qq)
+        else:
+            lo, hi = A["jnt_range"][j] if A["jnt_limited"][j] else (-1, 1)
+            q[qa], v[da] = rng.uniform(lo, hi), rng.normal()
+    mass, grav = A["body_mass"], np.array(m.gravity)
+
+    def potential(qq):
+        return -sum(mass[b] * grav @ fk_numpy(m, qq)[2][b] for b in range(len(mass)))
+    eps = 1e-5
+    dM, dU = np.zeros((nv, nv, nv)), np.zeros(nv)
+    for k in range(nv):
+        ek = np.zeros(nv)
+        ek[k] = 1
+        qp, qm = _integrate(A, q, ek, eps), _integrate(A, q, ek, -eps)
+        dM[k] = (mass_matrix_numpy(m, qp)[0] - mass_matrix_numpy(m, qm)[0]) / (2 * eps)
+        dU[k] = (potential(qp) - potential(qm)) / (2 * eps)
+    c = np.einsum("kij,k,j->i", dM, v, v) - 0.5 * np.einsum("kij,i,j->k", dM, v, v) + dU
+    d.qpos[:] = q; d.qvel[:] = v
+    d.mocap_pos[:] = [0, 0.6, 0.2]; d.mocap_quat[:] = [1, 0, 1, 0]
+    d.forward()
+    assert np.abs(c).max() > 5 and np.abs(d.qfrc_bias - c).max() < 2e-6 * np.abs(c).max()          # measured 1.2e-7 on |c| = 33
+
+
+JAC_TASKS = ["hammer-v3", "box-close-v3", "basketball-v3", "assembly-v3", "stick-pull-v3", "peg-insert-side-v3", "door-lock-v3", "soccer-v3",
+             "drawer-open-v3", "coffee-push-v3", "sweep-into-v3", "pick-place-wall-v3"]
+
+
+@pytest.mark.parametrize("task", JAC_TASKS)
+def test_constraint_jacobian_is_the_relative_motion_at_the_contact(hostsim, task):
+    """every contact row of efc_J (normal, two tangents, torsional, two rolling) applied to a random velocity v must equal the
+    relative linear / angular velocity of the two bodies at the contact point, expressed in the contact frame -- obtained here
+    without any Jacobian code: central differences of the numpy forward kinematics at q (+) eps v, the contact point carried along
+    rigidly by each body.  Weld and joint-limit rows: J v = d(efc_pos)/dt by central differences of the oracle's own residual."""
+    import copy
+    import ctypes as C
+
+    from metaworld_amd import policies as P
+    from metaworld_amd.mjcf import q2mat
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    from oracle.mjlite import OracleData, OracleModel, lib
+    from tests.helpers import WELD
+    env = MetaWorldGpuVectorEnv("MT1", task, num_envs=2, seed=3, precision="fp64", lib=hostsim)
+    obs, _ = env.reset()
+    mname = T.TASK_CONST[task]["model"]
+    _, _, reloc = T.packed_model(mname, reloc_bodies=T.model_key(task)[1])
+    cm0 = T.compiled_model(mname)
+    om = OracleModel(cm0)
+    om.view("eq_data")[:] = WELD
+    d = OracleData(om)
+    body_pos = om.view("body_pos").reshape(-1, 3)
+    nv = om.nv
+    J, efc_pos = d.view("efc_J").reshape(-1, nv), d.view("efc_pos")
+    rng = np.random.default_rng(0)
+    rows, eps, quat = 0, 1e-6, [1, 0, 1, 0]
+    for t in range(160):
+        obs = env.step(P.batched_actions([task] * 2, obs.astype(np.float64)).astype(np.float32))[0]
+        if t % 32 != 31:
+            continue
+        for e in range(2):
+            cm = copy.copy(cm0)
+            cm.arrays = dict(cm0.arrays)
+            cm.arrays["body_pos"] = cm0.arrays["body_pos"].copy()
+            rel = env.ctx.read(e, "reloc")
+            for slot, name in enumerate(reloc):          # the per-goal model.body(X).pos, in the oracle model and in the numpy model
+                body_pos[cm.names["body"][name]] = cm.arrays["body_pos"][cm.names["body"][name]] = rel[3 * slot:3 * slot + 3]
+            A = cm.arrays
+            q, mp = env.ctx.read(e, "qpos").copy(), env.ctx.read(e, "mocap").copy()
+            d.qpos[:] = q; d.qvel[:] = 0
+            d.mocap_pos[:] = mp + [0.004, -0.003, 0.002]; d.mocap_quat[:] = quat          # (a visible weld error)
+            d.forward()
+            nefc = d.nefc
+            Jn, contacts = J[:nefc].copy(), d.contacts()
+            ty, idd, st = (C.c_int * 1024)(), (C.c_int * 1024)(), (C.c_int * 1024)()
+            lib().mjl_data_efc_int(d.ptr, ty, idd, st)
+            nel = int(np.isin(np.array(ty[:nefc]), (0, 3)).sum())          # equality + limit rows come first
+            v = rng.normal(size=nv)
+            x0, xq0 = fk_numpy(cm, q, mp, quat)[:2]
+            fk = [fk_numpy(cm, _integrate(A, q, v, s * eps), mp, quat) for s in (1, -1)]
+
+            def motion(b, p):
+                loc = q2mat(xq0[b]).T @ (p - x0[b])
+                pp = [fk[s][0][b] + q2mat(fk[s][1][b]) @ loc for s in (0, 1)]
+                Rd = q2mat(fk[0][1][b]) @ q2mat(fk[1][1][b]).T          # R(+eps) R(-eps)' = I + 2 eps [w]x
+                return (pp[0] - pp[1]) / (2 * eps), np.array([Rd[2, 1] - Rd[1, 2], Rd[0, 2] - Rd[2, 0], Rd[1, 0] - Rd[0, 1]]) / (4 * eps)
+            for c in contacts:
+                a, dim = c["efc_address"], c["dim"]
+                if a < 0:
+                    continue
+                F = c["frame"].reshape(3, 3)
+                l1, w1 = motion(A["geom_bodyid"][c["geom1"]], c["pos"])
+                l2, w2 = motion(A["geom_bodyid"][c["geom2"]], c["pos"])
+                want = np.concatenate([F @ (l2 - l1), F @ (w2 - w1)])[:dim]
+                assert np.abs(Jn[a:a + dim] @ v - want).max() < 1e-7, (task, t, e, dim)          # measured 4e-10
+                rows += dim
+            res = []
+            for s in (1, -1):
+                d.qpos[:] = _integrate(A, q, v, s * eps)
+                d.forward()
+                res.append(efc_pos[:nel].copy())
+            assert nel >= 6 and np.abs(Jn[:nel] @ v - (res[0] - res[1]) / (2 * eps)).max() < 1e-7, (task, t, e)
+    env.close()
+    assert rows > 0
+
+
+def test_tumbling_body_conserves_momentum_to_first_order_in_the_time_step():
+    """gyroscopic terms + quaternion integration: the hammer (composite of several bodies, centre of mass off the joint frame)
+    tumbling without gravity or contact.  Linear momentum and angular momentum about the world origin are constants of the
+    continuous motion; semi-implicit Euler keeps them to O(h): the drift over 0.5 s is ~1.7 % at the model's h = 2.5 ms and must
+    shrink in proportion to h (a wrong sign or frame in the bias force or in the integrator would not converge)."""
+    import ctypes as C
+
+    from metaworld_amd.mjcf import J_FREE, q2mat
+    from oracle.mjlite import lib
+
+    def drift(h):
+        A = T.compiled_model("sawyer_hammer").arrays
+        om, d = oracle_for("sawyer_hammer")
+        for key, val in ((b"gravity", np.zeros(3)), (b"opt_timestep", np.array([h]))):
+            lib().mjl_model_set_real(om.ptr, key, val.ctypes.data, val.size)
+        j = [j for j in range(len(A["jnt_type"])) if A["jnt_type"][j] == J_FREE][0]
+        qa, da, b = A["jnt_qposadr"][j], A["jnt_dofadr"][j], A["jnt_bodyid"][j]
+        d.mocap_pos[:] = [0, 0.6, 0.3]; d.mocap_quat[:] = [1, 0, 1, 0]
+        d.qpos[qa:qa + 3] = [0.3, 0.2, 1.0]
+        d.qvel[da:da + 6] = [0.1, -0.2, 0.05, 3.0, 1.0, 2.0]
+
+        def momentum():          # generalized momentum of the free joint: linear in the world frame, angular about the body origin in the body frame
+            hm = d.qM[da:da + 6, da:da + 6] @ d.qvel[da:da + 6]
+            return np.concatenate([hm[:3], q2mat(d.xquat[b]) @ hm[3:6] + np.cross(d.qpos[qa:qa + 3], hm[:3])])
+        d.forward()
+        m0, worst = momentum(), 0.0
+        for _ in range(int(round(0.5 / h / 10))):
+            d.step(10)
+            assert d.ncon == 0
+            worst = max(worst, np.linalg.norm(momentum() - m0) / np.linalg.norm(m0))
+        return worst
+    e1, e4 = drift(0.0025), drift(0.000625)
+    assert e1 < 2.5e-2 and 0.2 < e4 / e1 < 0.3, (e1, e4)
