@@ -830,8 +830,12 @@ MW_STAGE_FN void collision(const Env<T> e_) {
     // demand statistic (capacity planning only): taken from sub-lane 0, which is active in every narrow-phase round.  On the GPU
     // the copies of `want` in sub-lanes that sat out a round's (divergent, non-inlined) collide_pair call came back as garbage
     // in long MT50 runs -- `ncon`, which is consumed inside the loop, never did; see DESIGN.md 5 "compiler sensitivity"
+#if defined(MW_WANT_RAW)          // diagnostic build only (tools/experiments/want_probe.py): the form that exposed it, every sub-lane stores its own copy
+    if (want > e.I(L.icount + IC_WANT_CON)) e.I(L.icount + IC_WANT_CON) = want;
+#else
     want = sub_first(e, want);
     if (e.sub == 0 && want > e.I(L.icount + IC_WANT_CON)) e.I(L.icount + IC_WANT_CON) = want;
+#endif
     if (flags) e.I(L.icount + 3) |= flags;
     MW_SYNC();
 }
