@@ -153,8 +153,14 @@ int mw_gather_bookkeeping(mw_ctx* c, mw_bookkeeping* out, int out_on_device);
 /* ---- run-time status (SURVEY.md 5 "failure detection"): status[0] = OR of the per-env flags since the last clear
  *      (1 = constraint-row capacity exceeded, 2 = contact capacity exceeded -- rows / contacts were DROPPED, the step differs
  *      from the reference's; 4 = non-finite state, the env was reset: the intent of sawyer_xyz_env.py:603-619),
- *      status[1..3] = number of env-steps that raised each flag. ---- */
-int mw_status(mw_ctx* c, int32_t* status /*[4]*/, int clear);
+ *      8 = CANARY: the copies of a redundantly computed value held by the threads that share one environment disagreed -- the
+ *      step kernel's own check against silent register corruption; must always be 0),
+ *      status[1..4] = number of env-steps that raised flag 1 / 2 / 4 / 8,
+ *      status[5] = Newton directions recomputed with a full-precision factor because the single-precision factor's direction
+ *      was not a descent direction, status[6] = line searches abandoned on a non-descent direction (both informational: no
+ *      flag bit; MuJoCo's solver stops the same way), status[7] reserved. ---- */
+#define MW_STATUS_WORDS 8
+int mw_status(mw_ctx* c, int32_t* status /*[MW_STATUS_WORDS]*/, int clear);
 
 /* ---- state access for parity tests (mujoco data.qpos / qvel / mocap_pos, MujocoEnv.set_state) ---- */
 int mw_column_size(mw_ctx* c, int env, const char* what);

@@ -641,8 +641,11 @@ MW_HD Shape<T> make_shape(const Env<T> e, int g) {
 
 // UNIFORM: every active lane of the wave tests the same geom pair (no sub-lanes), so the shapes' model constants can
 // live in scalar registers; with sub-lanes each sub-lane group has its own pair and nothing is wave-uniform.
+// `active`: the call itself is made by EVERY live lane of the wave (see collision()); lanes without a pair to test pass false
+// and leave through a branch inside this function.
 template <typename T, bool UNIFORM>
-MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h) {
+MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h, bool active) {
+    if (!active) return 0;
     const Shape<T> ua = UNIFORM ? a_.uniform() : a_, ub = UNIFORM ? b_.uniform() : b_;
     if (UNIFORM) margin = mw_uniform(margin);
     const int t1 = ua.type, t2 = ub.type;
@@ -761,6 +764,10 @@ MW_HD void append_contacts(const Env<T> e, int p, int cnt, const Hit<T>* hh, int
 //    which most were culled); each sub-lane has its own pair, nothing is wave-uniform (collide_pair<T, false>).
 // Hits are appended in pair order (exclusive prefix of the hit counts over the sub-lanes): the contact list is identical
 // to a serial sweep whatever nsub is.
+// CONVERGENT CALLS.  collide_pair is a 170 KB non-inlined function that uses every register; it is entered by ALL live lanes
+// of the wave or by none: the loop / skip conditions are wave-uniform (mw_any), lanes without work pass active = false and
+// branch inside the callee.  Rounds 1-2 made the call from inside the per-lane `if (near)` / `if (c0 + sub < ncand)`: values
+// kept in registers across that partially-masked call came back as garbage in lanes that had sat it out.
 template <typename T>
 MW_STAGE_FN void collision(const Env<T> e_) {
     const Env<T> e = e_.uniform();
@@ -770,16 +777,17 @@ MW_STAGE_FN void collision(const Env<T> e_) {
     int ncon = 0, flags = 0, want = 0;
     if (e.nsub == 1) {
         for (int p = 0; p < npair; p++) {
-            if (!pair_near(e, p)) continue;
+            const bool near = pair_near(e, p);
+            if (!mw_any(near)) continue;                       // wave-uniform: no lane of the wave is near this pair
             const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
             const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
             Hit<T> h[16];
-            int cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h);
+            const int cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h, near);
             if (cnt <= 0) continue;
             append_contacts(e, p, cnt, h, ncon, maxcon);
             ncon += cnt;
             want += cnt;
-            if (ncon > maxcon) { ncon = maxcon; flags |= 2; }
+            if (ncon > maxcon) { ncon = maxcon; flags |= ST_CON_OVERFLOW; }
         }
     } else {
         int ncand = 0;
@@ -800,19 +808,17 @@ MW_STAGE_FN void collision(const Env<T> e_) {
         MW_CTICK(tc1)
         MW_CTOCK(e, L, 0, tc0, tc1)
         MW_CADD(e, L, 2, ncand)
-        for (int c0 = 0; c0 < ncand; c0 += e.nsub) {
+        for (int c0 = 0; mw_any(c0 < ncand); c0 += e.nsub) {   // wave-uniform trip count: the longest candidate list of the wave
             MW_CADD(e, L, 3, 1)
             Hit<T> h[MW_NSLOT][16];
             int n[MW_NSLOT], off[MW_NSLOT], pp[MW_NSLOT];
             MW_SUBS(e, sub) {
-                int cnt = 0, p = -1;
-                if (c0 + sub < ncand) {
-                    p = e.I(L.ipair + c0 + sub);
-                    const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
-                    const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
-                    cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)]);
-                    if (cnt < 0) cnt = 0;
-                }
+                const bool act = c0 + sub < ncand;
+                const int p = act ? e.I(L.ipair + c0 + sub) : 0;           // (an idle sub-lane builds the shapes of pair 0 and discards them)
+                const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+                const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
+                int cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)], act);
+                if (cnt < 0) cnt = 0;
                 n[MW_SLOT(sub)] = cnt; pp[MW_SLOT(sub)] = p;
             }
             const int total = sub_scan(e, n, off);
@@ -821,21 +827,15 @@ MW_STAGE_FN void collision(const Env<T> e_) {
             }
             ncon += total;
             want += total;
-            if (ncon > maxcon) { ncon = maxcon; flags |= 2; }
+            if (ncon > maxcon) { ncon = maxcon; flags |= ST_CON_OVERFLOW; }
         }
         MW_CTICK(tc2)
         MW_CTOCK(e, L, 1, tc1, tc2)
     }
+    // canary: ncon / want / flags are computed redundantly by every sub-lane of the environment and must agree
+    if (sub_disagree(e, ncon) || sub_disagree(e, want) || sub_disagree(e, flags)) flags |= ST_DIVERGED;
     e.I(L.icount) = ncon;
-    // demand statistic (capacity planning only): taken from sub-lane 0, which is active in every narrow-phase round.  On the GPU
-    // the copies of `want` in sub-lanes that sat out a round's (divergent, non-inlined) collide_pair call came back as garbage
-    // in long MT50 runs -- `ncon`, which is consumed inside the loop, never did; see DESIGN.md 5 "compiler sensitivity"
-#if defined(MW_WANT_RAW)          // diagnostic build only (tools/experiments/want_probe.py): the form that exposed it, every sub-lane stores its own copy
-    if (want > e.I(L.icount + IC_WANT_CON)) e.I(L.icount + IC_WANT_CON) = want;
-#else
-    want = sub_first(e, want);
-    if (e.sub == 0 && want > e.I(L.icount + IC_WANT_CON)) e.I(L.icount + IC_WANT_CON) = want;
-#endif
+    if (want > e.I(L.icount + IC_WANT_CON)) e.I(L.icount + IC_WANT_CON) = want;   // demand statistic (capacity planning)
     if (flags) e.I(L.icount + 3) |= flags;
     MW_SYNC();
 }

@@ -118,10 +118,17 @@ constexpr int CON_ISTRIDE = 4;   // ints per contact record
 constexpr int EFC_EXTRA = 11;    // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv, fri, info, state
 constexpr int SR_N = 8;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force, block list
 constexpr int IC_NBLK = 18;      // icount slot: number of constraint blocks (single rows / contact cones)
-constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand
+constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand, 22 / 23 solver retries / stalls
 constexpr int IC_DYN_VALID = 19;  // icount slot: 1 = contacts / constraint rows / solver output belong to the CURRENT qpos (see env_step)
 constexpr int IC_WANT_CON = 20, IC_WANT_EFC = 21;   // running maxima of the contacts / constraint rows a step WANTED (capacity planning)
 constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a non-zero Jacobian entry
+// per-env status bits of one step (icount[3]); OR-ed into the context status word (mw_status) by lane_step:
+//   1 / 2  constraint-row / contact capacity exceeded (rows / contacts were dropped)
+//   4      non-finite state, the env was truncated and reset
+//   8      CANARY: the copies of a redundantly computed value held by the sub-lanes of one environment disagreed (sub_disagree)
+//  16      (MW_BOUNDS debug builds) a column-store / scratchpad index was out of range
+enum { ST_ROW_OVERFLOW = 1, ST_CON_OVERFLOW = 2, ST_UNSTABLE = 4, ST_DIVERGED = 8, ST_OOB = 16 };
+constexpr int IC_SOLVER_RETRY = 22, IC_SOLVER_STALL = 23;   // icount slots: Newton directions recomputed with a T-precision factor / searches abandoned on a non-descent direction (this step)
 
 struct Sizes {
     int nq, nv, nbody, njnt, ngeom, nsite, nmesh, nmeshvert, npair, nu, neq, nprobe, nreloc;
@@ -224,10 +231,10 @@ struct Env {
     int lds_rows;      // constraint rows whose solver scalars fit in the scratchpad (the rest stay in the column store)
 #if defined(MW_BOUNDS)   // debug build: every column-store access is range-checked; a violation is recorded and redirected to element 0
     unsigned nreal_b, nint_b;
-    int* oob;          // context status word: [0] |= 8, [1] = kind (1 real, 2 int, 3 scratchpad), [2] = index, [3] = limit
+    int* oob;          // context status word: [0] |= ST_OOB, [1] = kind (1 real, 2 int, 3 scratchpad), [2] = index, [3] = limit
     MW_HD unsigned chk(int i, unsigned lim, int kind) const {
         if ((unsigned)i < lim) return (unsigned)i;
-        if (oob) { oob[0] |= 8; oob[1] = kind; oob[2] = i; oob[3] = (int)lim; }
+        if (oob) { oob[0] |= 16; oob[1] = kind; oob[2] = i; oob[3] = (int)lim; }
         return 0u;
     }
 #endif
@@ -297,6 +304,21 @@ __device__ inline void sub_sum_n(const Env<T>& e, U (*p)[N]) {
 // the value sub-lane 0 of the environment holds
 template <typename T>
 __device__ inline int sub_first(const Env<T>& e, int v) { return __shfl(v, e.thr % e.lds_stride); }
+// true if the predicate holds in ANY live lane of the wave (wave-uniform result): loop / call conditions built from it keep
+// every live lane of the wave inside the loop / the call, so that a non-inlined function is never entered under a partial
+// EXEC mask (the lanes with nothing to do pass `active = false` and branch inside the callee) -- see collision()
+__device__ inline bool mw_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
+// CANARY for the redundant execution model: the sub-lanes of an environment run the lane program redundantly and must hold
+// bit-identical copies of every value that is not explicitly per-sub-lane.  True (in EVERY sub-lane of the environment) if
+// some sub-lane's copy of v differs from sub-lane 0's; the stages raise ST_DIVERGED on it (DESIGN.md 5 "compiler sensitivity").
+template <typename T>
+__device__ inline bool sub_disagree(const Env<T>& e, int v) {
+    int bad = v != sub_first(e, v);
+    for (int off = e.lds_stride; off < 64; off <<= 1) bad |= __shfl_xor(bad, off);
+    return bad != 0;
+}
+__device__ inline int canary_bits(float x) { return __builtin_bit_cast(int, x); }
+__device__ inline int canary_bits(double x) { const unsigned long long u = __builtin_bit_cast(unsigned long long, x); return (int)(u ^ (u >> 32)); }
 // exclusive prefix of one int per sub-lane (in sub-lane order) and the total
 template <typename T>
 __device__ inline int sub_scan(const Env<T>& e, const int* n, int* off) {
@@ -327,6 +349,11 @@ inline U sub_sum(const Env<T>& e, const U* p) {
 }
 template <typename T>
 inline int sub_first(const Env<T>&, int v) { return v; }
+inline bool mw_any(bool pred) { return pred; }
+template <typename T>
+inline bool sub_disagree(const Env<T>&, int) { return false; }   // (the host harness computes every value once)
+inline int canary_bits(float) { return 0; }
+inline int canary_bits(double) { return 0; }
 template <typename T>
 inline int sub_scan(const Env<T>& e, const int* n, int* off) {
     int tot = 0;

@@ -176,12 +176,11 @@ struct IOPtrs {
     double* ep_ret;          // [N]   (valid where done)
     int* ep_len;             // [N]
     mw_bookkeeping* book;    // [N] packed per-step record for the cross-rank gather, or null
-    int* status;             // [4] context status: OR of the per-env flags, env-steps with row overflow / contact overflow / instability
+    int* status;             // [MW_STATUS_WORDS] context status: OR of the per-env flags, env-steps with row overflow / contact overflow / instability / sub-lane divergence, solver retries / stalls
     int D;
 };
 
-// per-env status bits of one step (icount[3]); sticky in the context status word until mw_status clears it
-enum { ST_ROW_OVERFLOW = 1, ST_CON_OVERFLOW = 2, ST_UNSTABLE = 4 };
+// (per-env status bits of one step: mw_common.hpp, ST_*; sticky in the context status word until mw_status clears it)
 
 template <typename T>
 struct World {
@@ -289,12 +288,19 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     T act[4], obs[39], reward, success;
     Info info;
     for (int k = 0; k < 4; k++) act[k] = (T)w.io.act[(size_t)gid * 4 + k];
-    e.I(e.lay().icount + 3) = 0;
+    e.I(e.lay().icount + 3) = 0; e.I(e.lay().icount + IC_SOLVER_RETRY) = 0; e.I(e.lay().icount + IC_SOLVER_STALL) = 0;
     env_step(e, td, act, obs, &reward, &success, &info, w.full_forward != 0);
     // Instability guard (the intent of the reference's dead `_did_see_sim_exception` branch, sawyer_xyz_env.py:603-619, and
     // of MuJoCo's own reset on a bad QACC): a non-finite step returns the last stable observation with reward 0, ends the
     // episode as truncated (so the SAME_STEP auto-reset below restores a valid state) and raises ST_UNSTABLE.
     int flags = e.I(e.lay().icount + 3);
+    // canary (mw_common.hpp, sub_disagree): the sub-lanes of an environment must arrive here with bit-identical results
+    {
+        int sig = canary_bits(reward) ^ canary_bits(success);
+        for (int k = 0; k < 18; k++) sig = sig * 31 + canary_bits(obs[k]);
+        if (sub_disagree(e, sig) || sub_disagree(e, flags)) flags |= ST_DIVERGED;
+    }
+    const int nretry = e.I(e.lay().icount + IC_SOLVER_RETRY), nstall = e.I(e.lay().icount + IC_SOLVER_STALL);
     bool bad = !mw_finite((double)reward);
     for (int k = 0; k < 18; k++) bad |= !mw_finite((double)obs[k]);
     if (bad) {
@@ -331,9 +337,19 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
             if (flags & ST_ROW_OVERFLOW) atomicAdd(io.status + 1, 1);
             if (flags & ST_CON_OVERFLOW) atomicAdd(io.status + 2, 1);
             if (flags & ST_UNSTABLE) atomicAdd(io.status + 3, 1);
+            if (flags & ST_DIVERGED) atomicAdd(io.status + 4, 1);
 #else
 #pragma omp critical(mw_status)
-            { io.status[0] |= flags; io.status[1] += (flags & ST_ROW_OVERFLOW) != 0; io.status[2] += (flags & ST_CON_OVERFLOW) != 0; io.status[3] += (flags & ST_UNSTABLE) != 0; }
+            { io.status[0] |= flags; io.status[1] += (flags & ST_ROW_OVERFLOW) != 0; io.status[2] += (flags & ST_CON_OVERFLOW) != 0; io.status[3] += (flags & ST_UNSTABLE) != 0; io.status[4] += (flags & ST_DIVERGED) != 0; }
+#endif
+        }
+        if ((nretry | nstall) && io.status) {          // informational counters (no flag bit): see solve_impl
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (nretry) atomicAdd(io.status + 5, nretry);
+            if (nstall) atomicAdd(io.status + 6, nstall);
+#else
+#pragma omp critical(mw_status)
+            { io.status[5] += nretry; io.status[6] += nstall; }
 #endif
         }
     }
@@ -403,7 +419,7 @@ public:
     virtual void step_resident_gather(int nsteps, int act_stride_steps, float* kernel_ms) = 0;
     virtual void comm_init(const void* id128, int rank, int world) = 0;
     virtual void gather_bookkeeping(mw_bookkeeping* out, int out_on_device) = 0;
-    virtual void status(int* out4, int clear) = 0;
+    virtual void status(int* out /*[MW_STATUS_WORDS]*/, int clear) = 0;
     virtual void set_episode_phase(const int* elapsed) = 0;
     virtual void read_col(int gid, const char* what, int n, double* out) = 0;
     virtual void write_col(int gid, const char* what, int n, const double* in) = 0;
@@ -453,7 +469,7 @@ class Context : public ContextBase {
     std::vector<long long> snap_off_;
     std::vector<int> snap_stride_;
     int* d_snap_ngoal_ = nullptr;
-    int* d_status_ = nullptr;                 // [4], see mw_status
+    int* d_status_ = nullptr;                 // [MW_STATUS_WORDS], see mw_status
     mw_bookkeeping* d_book_ = nullptr;        // [2][N]: the step kernel writes slot (step parity), the gather reads it
     mw_bookkeeping* d_book_all_ = nullptr;    // [2][world][N] gathered records
     int book_slot_ = 0;                       // slot the LAST step wrote
@@ -565,7 +581,11 @@ public:
                 for (auto& kv : by_model) lpb_of[kv.first] = start;
                 if (start >= BLOCK || blocks() <= budget) break;
             }
-            if (const char* mx = getenv("MW_LPB_MAX")) start = atoi(mx);
+            if (const char* mx = getenv("MW_LPB_MAX")) {          // experiments: upper end of the search
+                const int v = atoi(mx);
+                if (v != 1 && v != 2 && v != 4 && v != 8 && v != 16 && v != 32 && v != 64) throw std::runtime_error("MW_LPB_MAX must be a power of two in [1, 64]");
+                start = v;
+            }
             for (auto& kv : by_model) lpb_of[kv.first] = start;
             std::set<int> frozen;
             for (;;) {
@@ -624,7 +644,7 @@ public:
         d_flags_ = (uint8_t*)Backend::alloc(4 * N_); d_info_ = (float*)Backend::alloc(sizeof(float) * 6 * N_);
         d_eplen_ = (int*)Backend::alloc(sizeof(int) * N_); Backend::zero(d_eplen_, sizeof(int) * N_);
         d_act_ = (float*)Backend::alloc(sizeof(float) * 4 * N_); act_capacity_steps_ = 1;
-        d_status_ = (int*)Backend::alloc(sizeof(int) * 4); Backend::zero(d_status_, sizeof(int) * 4);
+        d_status_ = (int*)Backend::alloc(sizeof(int) * MW_STATUS_WORDS); Backend::zero(d_status_, sizeof(int) * MW_STATUS_WORDS);
         d_book_ = (mw_bookkeeping*)Backend::alloc(sizeof(mw_bookkeeping) * 2 * N_); Backend::zero(d_book_, sizeof(mw_bookkeeping) * 2 * N_);
         d_book_all_ = (mw_bookkeeping*)Backend::alloc(sizeof(mw_bookkeeping) * 2 * N_); Backend::zero(d_book_all_, sizeof(mw_bookkeeping) * 2 * N_);
         h_next_goal_.assign(N_, 0); was_reset_.assign(N_, 0);
@@ -684,15 +704,17 @@ public:
             total += (long long)ns * (tasks[t].goals.size() / 6);
         }
         snap.assign((size_t)total, (T)0);
-        // temporary groups: one per model, one lane per (task, goal)
-        std::map<int, std::vector<std::pair<int, int>>> by_model;
+        // temporary groups: one per TASK, one lane per goal.  (One group per model would put two tasks of a shared scene into one
+        // wave; reset_model is task-specific code around the non-inlined physics stages, which would then be entered under a
+        // partial EXEC mask -- every wave of the faithful reset is task-uniform instead.)
+        std::map<int, std::vector<std::pair<int, int>>> by_task;
         for (size_t t = 0; t < tasks.size(); t++)
-            for (size_t g = 0; g < tasks[t].goals.size() / 6; g++) by_model[tasks[t].model].push_back({(int)t, (int)g});
-        for (auto& kv : by_model) {
+            for (size_t g = 0; g < tasks[t].goals.size() / 6; g++) by_task[(int)t].push_back({(int)t, (int)g});
+        for (auto& kv : by_task) {
             Group g;
             std::vector<int> gids(kv.second.size());
             for (size_t i = 0; i < gids.size(); i++) gids[i] = (int)i;
-            make_group(g, kv.first, gids, BLOCK);
+            make_group(g, tasks[kv.first].model, gids, BLOCK);
             // seed the task block of each lane: task id, goal idx, rand_vec
             std::vector<T> host(g.nreal_total(), (T)0);
             for (size_t l = 0; l < kv.second.size(); l++) {
@@ -797,7 +819,14 @@ public:
         Backend::sync();
     }
     void reset_device(const uint8_t* d_mask, const int* d_goal_idx, double* d_obs) override {
-        was_reset_.assign(N_, 1);          // (a device-side mask cannot be inspected here; goal indices are clamped in the kernel)
+        // a full reset (no mask) satisfies the step-before-reset guard; a DEVICE mask cannot be inspected without a copy, so it is
+        // copied back once here (N bytes) and only the envs it selects are marked
+        if (!d_mask) was_reset_.assign(N_, 1);
+        else {
+            std::vector<uint8_t> hm(N_);
+            Backend::d2h(hm.data(), d_mask, N_);
+            for (int i = 0; i < N_; i++) if (hm[i]) was_reset_[i] = 1;
+        }
         World<T> w = world();
         w.io.next_goal = const_cast<int*>(d_goal_idx);
         if (d_obs) w.io.obs = d_obs;
@@ -882,6 +911,9 @@ public:
         Backend::timed_begin();
         for (int s = 0; s < nsteps; s++) {
             book_slot_ ^= 1;
+            // two record slots: the kernel of step k rewrites the slot the gather of step k-2 read.  That gather runs on the side
+            // stream and may lag (first-call RCCL setup, a slow rank): the main stream waits for its "gather done" event.
+            if (gather) Backend::wait_gather_done(book_slot_);
             World<T> w = world();
             w.io.act = base + (size_t)(act_steps > 0 ? s % act_steps : 0) * 4 * N_;
             Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
@@ -924,9 +956,9 @@ public:
             set_task_field(groups_[env_group_[i]], env_lane_[i], TK_PATHLEN, elapsed[i]);
         }
     }
-    void status(int* out4, int clear) override {
-        Backend::d2h(out4, d_status_, sizeof(int) * 4);
-        if (clear) { Backend::zero(d_status_, sizeof(int) * 4); Backend::sync(); }
+    void status(int* out, int clear) override {
+        Backend::d2h(out, d_status_, sizeof(int) * MW_STATUS_WORDS);
+        if (clear) { Backend::zero(d_status_, sizeof(int) * MW_STATUS_WORDS); Backend::sync(); }
     }
 
     void debug(int what, int n) override {

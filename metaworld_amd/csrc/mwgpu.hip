@@ -70,7 +70,7 @@ struct Rccl {
 // One stream / event pair / side stream per HIP device, created on first use; every ABI entry selects its context's
 // device first (Backend::use), so contexts on different devices can live in one process.
 struct Backend {
-    struct Dev { hipStream_t stream = nullptr, side = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr}; int max_lds = 65536, num_cu = 256; bool ready = false; };
+    struct Dev { hipStream_t stream = nullptr, side = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr}, gev[2] = {nullptr, nullptr}; bool gev_used[2] = {false, false}; int max_lds = 65536, num_cu = 256; bool ready = false; };
     static constexpr int MAX_DEV = 64;
     static Dev& dev() { static Dev d[MAX_DEV]; return d[cur()]; }
     static int& cur() { static thread_local int c = 0; return c; }
@@ -96,6 +96,7 @@ struct Backend {
         for (int k = 0; k < 2; k++) {
             hip_check(hipEventCreate(&d.ev[k]), "hipEventCreate");
             hip_check(hipEventCreateWithFlags(&d.xev[k], hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&d.gev[k], hipEventDisableTiming), "hipEventCreate");
         }
         d.ready = true;
     }
@@ -173,7 +174,8 @@ struct Backend {
         return c;
     }
     static void comm_free(Comm* c) { if (c) { if (c->comm) (void)Rccl::get().CommDestroy(c->comm); delete c; } }
-    // side stream waits for everything queued on the main stream so far, then all-gathers `bytes` per rank
+    // side stream waits for everything queued on the main stream so far, then all-gathers `bytes` per rank; the "gather done"
+    // event of the record slot is what the main stream waits for before a later kernel rewrites that slot (wait_gather_done)
     static void allgather_side(Comm* c, const void* send, void* recv, size_t bytes, int slot) {
         if (!c) { allgather_side_local(send, recv, bytes, slot); return; }
         Dev& d = dev();
@@ -181,6 +183,14 @@ struct Backend {
         hip_check(hipStreamWaitEvent(d.side, d.xev[slot & 1], 0), "hipStreamWaitEvent");
         Rccl& r = Rccl::get();
         r.check(r.AllGather(send, recv, bytes, ncclInt8, c->comm, d.side), "ncclAllGather");
+        hip_check(hipEventRecord(d.gev[slot & 1], d.side), "hipEventRecord");
+        d.gev_used[slot & 1] = true;
+    }
+    // back-edge of the two-slot record ring: the main stream may not run the kernel that REWRITES record slot `slot` before the
+    // side stream has finished the gather that READS it (a collective slower than one kernel: first-call RCCL setup, a slow rank)
+    static void wait_gather_done(int slot) {
+        Dev& d = dev();
+        if (d.gev_used[slot & 1]) hip_check(hipStreamWaitEvent(d.stream, d.gev[slot & 1], 0), "hipStreamWaitEvent");
     }
     static void sync_side() { hip_check(hipStreamSynchronize(dev().side), "hipStreamSynchronize(side)"); }
     static void allgather_side_local(const void* send, void* recv, size_t bytes, int slot) {   // world size 1: a device copy
@@ -188,6 +198,8 @@ struct Backend {
         hip_check(hipEventRecord(d.xev[slot & 1], d.stream), "hipEventRecord");
         hip_check(hipStreamWaitEvent(d.side, d.xev[slot & 1], 0), "hipStreamWaitEvent");
         hip_check(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, d.side), "hipMemcpy D2D");
+        hip_check(hipEventRecord(d.gev[slot & 1], d.side), "hipEventRecord");
+        d.gev_used[slot & 1] = true;
     }
     static void copy_side(void* dst, const void* src, size_t bytes, bool dst_on_device) {
         hip_check(hipMemcpyAsync(dst, src, bytes, dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, dev().side), "hipMemcpy (side)");

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmwgpu.so")
 LIB_PATH_V1 = os.path.join(os.path.dirname(LIB_PATH), "libmwgpu_v1.so")          # reward_function_version="v1" (csrc/mw_tasks_v1.hpp)
 NPROBE = 16
+STATUS_WORDS = 8          # MW_STATUS_WORDS (include/mwgpu.h)
 
 
 class MwConfig(C.Structure):
@@ -250,10 +251,12 @@ class Context:
         self._check(self.lib.set_episode_phase(self.ptr, e.ctypes.data))
 
     def status(self, clear=False):
-        """mw_status -> dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps)"""
-        out = np.zeros(4, dtype=np.int32)
+        """mw_status -> dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps, diverged_steps, solver_retries,
+        solver_stalls); flags: 1 / 2 capacity exceeded, 4 non-finite state, 8 sub-lane divergence canary (include/mwgpu.h)"""
+        out = np.zeros(STATUS_WORDS, dtype=np.int32)
         self._check(self.lib.status(self.ptr, out.ctypes.data, int(bool(clear))))
-        return dict(flags=int(out[0]), row_overflow_steps=int(out[1]), contact_overflow_steps=int(out[2]), unstable_steps=int(out[3]))
+        return dict(flags=int(out[0]), row_overflow_steps=int(out[1]), contact_overflow_steps=int(out[2]), unstable_steps=int(out[3]),
+                    diverged_steps=int(out[4]), solver_retries=int(out[5]), solver_stalls=int(out[6]))
 
     def upload_actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32)

@@ -467,9 +467,11 @@ class MetaWorldGpuVectorEnv:
 
     # ---- run-time status (no reference counterpart; SURVEY.md 5 "failure detection") ----
     def status(self, clear=False):
-        """dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps) accumulated since the last clear: flag 1 / 2 =
-        the constraint-row / contact capacity of a scene (metaworld_amd/data/model_caps.json) was exceeded and rows / contacts
-        were DROPPED; 4 = a non-finite state was caught and the env reset (the intent of sawyer_xyz_env.py:603-619)."""
+        """dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps, diverged_steps, solver_retries, solver_stalls)
+        accumulated since the last clear: flag 1 / 2 = the constraint-row / contact capacity of a scene
+        (metaworld_amd/data/model_caps.json) was exceeded and rows / contacts were DROPPED; 4 = a non-finite state was caught
+        and the env reset (the intent of sawyer_xyz_env.py:603-619); 8 = the step kernel's redundancy canary fired (the
+        threads sharing one env disagreed on a value they all compute: a code-generation / hardware fault, never expected)."""
         return self.ctx.status(clear)
 
     def check_status(self):
@@ -477,6 +479,8 @@ class MetaWorldGpuVectorEnv:
         if st["flags"] & 3:
             raise RuntimeError(f"contact / constraint-row capacity exceeded, results differ from the reference: {st} "
                                "(raise maxcon / maxefc)")
+        if st["flags"] & 8:
+            raise RuntimeError(f"the step kernel's redundancy canary fired (threads sharing one env disagreed): {st}")
         if st["flags"] & 4:
             import warnings
             warnings.warn(f"non-finite simulation state caught; the affected envs were truncated and reset: {st}")

@@ -9,6 +9,11 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +23,7 @@
 #include <vector>
 
 #define MW_LAMBDA
+#include "../include/mwgpu.h"
 #include "../metaworld_amd/csrc/mw_common.hpp"
 
 namespace {
@@ -59,17 +65,65 @@ struct Backend {
         if (h->count.fetch_add(1) + 1 == c->world) { h->count.store(0); h->gen.fetch_add(1); }
         else while (h->gen.load() == g) sched_yield();
     }
-    static void allgather_side(Comm* c, const void* send, void* recv, size_t bytes, int) {
-        if (!c) { std::memcpy(recv, send, bytes); return; }
-        if (bytes > c->cap) throw std::runtime_error("host harness: all-gather block larger than the shared segment");
-        char* data = c->base + sizeof(Shm);
-        std::memcpy(data + c->cap * c->rank, send, bytes);
-        barrier(c);
-        for (int r = 0; r < c->world; r++) std::memcpy((char*)recv + bytes * r, data + c->cap * r, bytes);
-        barrier(c);
+    // The product's SIDE STREAM is emulated by a worker thread with a FIFO of closures, so that the ordering rules of the
+    // runtime (side waits for main at enqueue time -- trivially true here, the main "stream" is the calling thread --, main
+    // waits for the "gather done" event of a record slot before rewriting it, sync_side) are exercised on the CPU.
+    // MW_TEST_GATHER_DELAY_MS makes every gather slow (a slow rank / first-call RCCL setup); MW_TEST_NO_BACKEDGE=1 disables
+    // wait_gather_done, which the test uses to show that it CAN see torn / late records.
+    struct Side {
+        std::thread th; std::mutex mu; std::condition_variable cv;
+        std::deque<std::function<void()>> q;
+        int pending[2] = {0, 0}, inflight = 0;
+        bool stop = false;
+        std::vector<int> log;          // episode_length of record 0 as seen by every gather, in order (mwh_test_gather_log)
+        Side() { th = std::thread([this] { run(); }); }
+        ~Side() { { std::lock_guard<std::mutex> l(mu); stop = true; } cv.notify_all(); th.join(); }
+        void run() {
+            std::unique_lock<std::mutex> l(mu);
+            for (;;) {
+                cv.wait(l, [this] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                auto f = std::move(q.front()); q.pop_front();
+                inflight = 1;
+                l.unlock(); f(); l.lock();
+                inflight = 0;
+                cv.notify_all();
+            }
+        }
+        void push(std::function<void()> f) { { std::lock_guard<std::mutex> l(mu); q.push_back(std::move(f)); } cv.notify_all(); }
+        void drain() { std::unique_lock<std::mutex> l(mu); cv.wait(l, [this] { return q.empty() && !inflight; }); }
+    };
+    static Side& side() { static Side s; return s; }
+    static void gather_now(Comm* c, const void* send, void* recv, size_t bytes) {
+        if (const char* d = std::getenv("MW_TEST_GATHER_DELAY_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(std::atoi(d)));
+        if (!c) std::memcpy(recv, send, bytes);
+        else {
+            if (bytes > c->cap) throw std::runtime_error("host harness: all-gather block larger than the shared segment");
+            char* data = c->base + sizeof(Shm);
+            std::memcpy(data + c->cap * c->rank, send, bytes);
+            barrier(c);
+            for (int r = 0; r < c->world; r++) std::memcpy((char*)recv + bytes * r, data + c->cap * r, bytes);
+            barrier(c);
+        }
     }
-    static void sync_side() {}
-    static void copy_side(void* d, const void* s, size_t n, bool) { std::memcpy(d, s, n); }
+    static void allgather_side(Comm* c, const void* send, void* recv, size_t bytes, int slot) {
+        Side& s = side();
+        { std::lock_guard<std::mutex> l(s.mu); s.pending[slot & 1]++; }
+        s.push([c, send, recv, bytes, slot, &s] {
+            gather_now(c, send, recv, bytes);
+            std::lock_guard<std::mutex> l(s.mu);
+            if (bytes >= sizeof(mw_bookkeeping)) s.log.push_back(((const mw_bookkeeping*)recv)[0].episode_length);
+            s.pending[slot & 1]--;
+        });
+    }
+    static void wait_gather_done(int slot) {
+        if (std::getenv("MW_TEST_NO_BACKEDGE")) return;
+        Side& s = side();
+        std::unique_lock<std::mutex> l(s.mu);
+        s.cv.wait(l, [&] { return s.pending[slot & 1] == 0; });
+    }
+    static void sync_side() { side().drain(); }
+    static void copy_side(void* d, const void* s, size_t n, bool) { side().push([d, s, n] { std::memcpy(d, s, n); }); }
     static void* alloc(size_t bytes) { return std::malloc(bytes ? bytes : 16); }
     static void free(void* p) { std::free(p); }
     static void zero(void* p, size_t bytes) { std::memset(p, 0, bytes); }
@@ -128,3 +182,16 @@ extern "C" void mwh_hist(long* out, int reset) {
     for (int i = 0; i < 256; i++) { out[i] = mw::mw_hist()[i]; if (reset) mw::mw_hist()[i] = 0; }
 }
 #endif
+
+// TEST HOOK (host harness only): the episode_length of record 0 as every all-gather of this process saw it, oldest first;
+// returns the number of gathers logged and clears the log when out == nullptr
+extern "C" int mwh_test_gather_log(int* out, int cap) {
+    auto& s = Backend::side();
+    s.drain();
+    std::lock_guard<std::mutex> l(s.mu);
+    const int n = (int)s.log.size();
+    if (!out) { s.log.clear(); return n; }
+    for (int i = 0; i < n && i < cap; i++) out[i] = s.log[i];
+    return n;
+}
+
