@@ -440,7 +440,7 @@ MW_HD void tri_closest_origin(V3<T> a, V3<T> b, V3<T> c, T* w) {
 }
 template <typename T>
 MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V3<T>* v0_override = nullptr) {
-    const T tol = sizeof(T) == 8 ? T(1e-10) : T(2e-6);
+    const T tol = sizeof(T) == 8 ? T(1e-6) : T(2e-6);          // MuJoCo's ccd_tolerance default; single precision cannot resolve less than ~2e-6
     MW_COUNT(5)
     SV<T> v0, v1, v2, v3_, v4;
     v0.a = A.pos; v0.b = B.pos; v0.v = v0.b - v0.a;

@@ -16,7 +16,7 @@
 #include "mjl_core.h"
 
 #define MINVAL 1e-15
-#define CCD_TOL 1e-10
+#define CCD_TOL 1e-6          /* MuJoCo's ccd_tolerance default */
 #define CCD_ITER 50
 
 typedef struct {

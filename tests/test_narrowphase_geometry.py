@@ -121,9 +121,9 @@ def test_contacts_satisfy_the_support_function_identities(hostsim, task):
                     assert lo < dmin - gp < hi, (ctx, dmin, gp)
                 else:
                     assert len(cs) == 1, ctx
-                    assert abs(dmin - gp) < 2e-9, (ctx, dmin, gp)                                 # MPR stops at 1e-10 of the portal distance
+                    assert abs(dmin - gp) < 2e-6, (ctx, dmin, gp)                                 # MPR stops at 1e-6 of the portal distance
                     e1 = extent(A, g1, xpos, xmat, n)
-                    assert abs(cs[0]["pos"] @ n - 0.5 * (e1 + e1 + gp)) < 2e-9, ctx                # midway between the two surfaces
+                    assert abs(cs[0]["pos"] @ n - 0.5 * (e1 + e1 + gp)) < 2e-6, ctx                # midway between the two surfaces
                 if t1 != PLANE and not on_face:
                     other = best_other_direction(A, g1, g2, xpos, xmat, n, rng) - (gp if multi else dmin)
                     if t1 == BOX and t2 == BOX:
@@ -131,9 +131,9 @@ def test_contacts_satisfy_the_support_function_identities(hostsim, task):
                     elif kind != "portal":
                         assert other < 1e-6, (ctx, other)                                            # exact routines: the separating direction
                     elif depth < 5e-3 and CYLINDER not in (t1, t2):
-                        assert other < 2e-5, (ctx, depth, other)                                     # portal refinement + 2 re-shot runs
+                        assert other < 5e-5, (ctx, depth, other)                                     # portal refinement (stop at 1e-6) + 2 re-shot runs
                     elif depth < 5e-3:
-                        assert other < max(2e-5, 0.3 * depth), (ctx, depth, other)                   # a cylinder rim on a box edge
+                        assert other < max(5e-5, 0.3 * depth), (ctx, depth, other)                   # a cylinder rim on a box edge
                     else:
                         assert other < 0.6 * depth, (ctx, depth, other)
     env.close()

@@ -11,9 +11,9 @@ from tests.helpers import golden, make_env, replay_trace
 # the synchronised state to 2e-5 ... 8e-4 in ONE step (tests/test_ill_conditioning.py proves it on the reference's own Python;
 # tools/experiments/waiver_scan.py finds the states): a contact sitting at its activation margin, or a face-on-face contact whose
 # single contact point is not a continuous function of the poses (the lock's flat mesh faces, the plug seated in its socket).
-# The tolerances are ~3x the deviation measured on the host build (door-unlock 8.5e-4 / 1.3e-2, peg-unplug 4.5e-5 / 5.2e-5,
+# The tolerances are ~3x the deviation measured on the host build (door-unlock 9.5e-5 / 1.6e-3, peg-unplug 8.8e-5 / 2.8e-5,
 # door-close 2.1e-6 / 1.1e-5); 16 sub-lanes, FMA contraction and the single-precision Hessian factor change the rounding on the GPU.
-TOL = {"door-unlock-v3": (3e-3, 4e-2), "peg-unplug-side-v3": (1.5e-4, 2e-4), "door-close-v3": (1e-5, 5e-5)}
+TOL = {"door-unlock-v3": (3e-4, 5e-3), "peg-unplug-side-v3": (3e-4, 1e-4), "door-close-v3": (1e-5, 5e-5)}
 
 @pytest.mark.parametrize("task", T.ALL_V3)
 def test_task_matches_reference_trace(hostsim, task):
@@ -48,4 +48,5 @@ def test_task_fp32_close_to_reference_trace(hostsim, task):
     # box-close: the reference's reward adds a bonus once the lid is above z = 0.02 -- exactly its resting height; in the trace
     # the lid sits at 0.02000011 (fp64) / 0.01999891 (fp32) at one step, so the single-precision reward is on the other branch
     tol_rew = 2.0 if task == "box-close-v3" else 5e-2
-    assert r["reset"] < 1e-2 and r["obs"] < 1e-2 and r["reward"] < tol_rew and r["success_mismatch"] == 0, r
+    # door-unlock: one success flag of the trace sits on the threshold of an ill-conditioned state (TOL above) in single precision
+    assert r["reset"] < 1e-2 and r["obs"] < 1e-2 and r["reward"] < tol_rew and r["success_mismatch"] <= (1 if task == "door-unlock-v3" else 0), r
