@@ -174,6 +174,63 @@ MW_HD int sphere_x(const Shape<T>& s, const Shape<T>& o, T margin, Hit<T>* h) {
     return -1;  // not analytic: caller falls back to MPR
 }
 
+// capsule - box in closed form: the capsule is its axis segment inflated by the radius, so the contact is the closest pair
+// (segment point, box point) pushed out by r.  In the box frame the squared distance of p(t) = a + t d to the box,
+// f(t) = sum_i max(|p_i| - s_i, 0)^2, is convex and piecewise quadratic with breakpoints where a coordinate crosses a face plane;
+// f'/2 = sum_i e_i(t) d_i is piecewise linear and non-decreasing: evaluated at the sorted breakpoints, interpolated in the bracketing
+// interval.  -1 when the axis segment itself touches the box (depth >= radius): the caller falls back to portal refinement.
+template <typename T>
+MW_HD T cb_half_slope(const T* a, const T* d, const T* s, T t) {
+    T g = 0;
+    for (int i = 0; i < 3; i++) {
+        const T p = a[i] + t * d[i], e = p > s[i] ? p - s[i] : (p < -s[i] ? p + s[i] : T(0));
+        g += e * d[i];
+    }
+    return g;
+}
+template <typename T>
+MW_HD int capsule_box(const Shape<T>& c, const Shape<T>& b, T margin, Hit<T>* h) {
+    const V3<T> clv = mulT(b.mat, c.pos - b.pos), ulv = mulT(b.mat, col(c.mat, 2));
+    const T cl[3] = {clv.x, clv.y, clv.z}, ul[3] = {ulv.x, ulv.y, ulv.z}, hh = c.size[1];
+    const T s[3] = {b.size[0], b.size[1], b.size[2]};
+    T a[3], d[3], ts[8];
+    for (int i = 0; i < 3; i++) { a[i] = cl[i] - hh * ul[i]; d[i] = 2 * hh * ul[i]; }
+    int n = 0;
+    ts[n++] = 0;
+    for (int i = 0; i < 3; i++) {
+        if (mw_abs(d[i]) <= T(1e-14)) continue;
+        for (int sg = -1; sg <= 1; sg += 2) {
+            const T t = (sg * s[i] - a[i]) / d[i];
+            if (t > 0 && t < 1) ts[n++] = t;
+        }
+    }
+    ts[n++] = 1;
+    for (int i = 1; i < n; i++) {            // insertion sort
+        const T v = ts[i];
+        int j = i - 1;
+        while (j >= 0 && ts[j] > v) { ts[j + 1] = ts[j]; j--; }
+        ts[j + 1] = v;
+    }
+    T tstar, glo = cb_half_slope(a, d, s, T(0));
+    if (glo >= 0) tstar = 0;
+    else {
+        tstar = 1;
+        for (int k = 1; k < n; k++) {
+            const T ghi = cb_half_slope(a, d, s, ts[k]);
+            if (ghi >= 0) { tstar = ts[k - 1] - glo * (ts[k] - ts[k - 1]) / (ghi - glo); break; }
+            glo = ghi;
+        }
+    }
+    T pl[3], ql[3], dist2 = 0;
+    for (int i = 0; i < 3; i++) {
+        pl[i] = a[i] + tstar * d[i];
+        ql[i] = mw_clamp(pl[i], -s[i], s[i]);
+        dist2 += (pl[i] - ql[i]) * (pl[i] - ql[i]);
+    }
+    if (dist2 < (sizeof(T) == 8 ? T(1e-20) : T(1e-12))) return -1;
+    return hit_sphere_sphere(b.pos + b.mat * v3(pl[0], pl[1], pl[2]), c.size[0], b.pos + b.mat * v3(ql[0], ql[1], ql[2]), T(0), margin, h);
+}
+
 template <typename T>
 MW_HD int capsule_capsule(const Shape<T>& a, const Shape<T>& b, T margin, Hit<T>* h) {
     const V3<T> ua = col(a.mat, 2), ub = col(b.mat, 2), w = a.pos - b.pos;
@@ -656,14 +713,16 @@ MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, H
     else if (t1 == G_SPHERE) n = sphere_x(ua, ub, margin, h);
     else if (t1 == G_CAPSULE && t2 == G_CAPSULE) n = capsule_capsule(ua, ub, margin, h);
     else if (t1 == G_BOX && t2 == G_BOX) n = box_box(ua, ub, margin, h, 8);
+    const bool on_box = (t1 == G_CYLINDER || t1 == G_CAPSULE) && t2 == G_BOX;
+    if (t1 == G_CAPSULE && t2 == G_BOX) n = capsule_box(ua, ub, margin, h);
     if (n < 0) {
         Shape<T> a = ua, b = ub;
         a.margin = b.margin = T(0.5) * margin;
         n = mpr_refined(a, b, margin, h);
-        if (n && (t1 == G_CYLINDER || t1 == G_CAPSULE) && t2 == G_BOX) {
-            const int k = face_upgrade(a_, b_, h, margin);
-            if (k) n = k;
-        }
+    }
+    if (n && on_box) {
+        const int k = face_upgrade(a_, b_, h, margin);
+        if (k) n = k;
     }
     return n;
 }

@@ -3,8 +3,8 @@
  *
  * Collision detection for the geom-pair types that occur in the 36 Meta-World
  * scenes.  Analytic routines for plane-X, sphere-X,
- * capsule-capsule and box-box (SAT + face clipping); every other convex pair
- * (cylinder, mesh hulls, capsule-box) goes through one Minkowski-portal-
+ * capsule-capsule, capsule-box (segment-box distance) and box-box (SAT + face
+ * clipping); every other convex pair (cylinder, mesh hulls) goes through one Minkowski-portal-
  * refinement routine on support functions with the MuJoCo convention of
  * inflating both shapes by margin/2.  Contact convention (MuJoCo): frame[0..2]
  * is the normal pointing from geom1 to geom2, dist<0 is penetration, pos is the
@@ -313,6 +313,67 @@ static int capsule_capsule(const Shape* a, const Shape* b, double margin, Hit* h
     addscl3(pa, a->pos, ua, s);
     addscl3(pb, b->pos, ub, t);
     return sphere_sphere_raw(pa, a->size[0], pb, b->size[0], margin, h);
+}
+
+/* ----------------------------------------------------------- capsule - box */
+/* A capsule is its axis segment inflated by the radius, so the contact is the closest pair (segment point, box point) pushed
+   out by r: exact, no iteration (MuJoCo also treats this pair in closed form).  In the box frame the squared distance of the
+   segment point p(t) = a + t (b - a) to the box is f(t) = sum_i max(|p_i| - s_i, 0)^2: convex, piecewise quadratic with
+   breakpoints where a coordinate crosses a face plane.  f'/2 = sum_i e_i(t) d_i is piecewise linear and non-decreasing:
+   evaluate it at the sorted breakpoints and interpolate in the bracketing interval.  Returns -1 when the axis segment itself
+   touches the box (depth >= radius): the caller falls back to portal refinement. */
+static double cb_half_slope(const double* a, const double* d, const double* s, double t) {
+    double g = 0;
+    for (int i = 0; i < 3; i++) {
+        double p = a[i] + t * d[i], e = p > s[i] ? p - s[i] : (p < -s[i] ? p + s[i] : 0);
+        g += e * d[i];
+    }
+    return g;
+}
+static int capsule_box(const Shape* c, const Shape* b, double margin, Hit* h) {
+    double w[3], cl[3], ul[3], ax[3], a[3], d[3], ts[8];
+    sub3(w, c->pos, b->pos);
+    mulT(cl, b->mat, w);
+    col3(ax, c->mat, 2);
+    mulT(ul, b->mat, ax);
+    const double hh = c->size[1], *s = b->size;
+    for (int i = 0; i < 3; i++) { a[i] = cl[i] - hh * ul[i]; d[i] = 2 * hh * ul[i]; }
+    int n = 0;
+    ts[n++] = 0;
+    for (int i = 0; i < 3; i++) {
+        if (fabs(d[i]) <= 1e-14) continue;
+        for (int sg = -1; sg <= 1; sg += 2) {
+            double t = (sg * s[i] - a[i]) / d[i];
+            if (t > 0 && t < 1) ts[n++] = t;
+        }
+    }
+    ts[n++] = 1;
+    for (int i = 1; i < n; i++) {            /* insertion sort */
+        double v = ts[i];
+        int j = i - 1;
+        while (j >= 0 && ts[j] > v) { ts[j + 1] = ts[j]; j--; }
+        ts[j + 1] = v;
+    }
+    double tstar, glo = cb_half_slope(a, d, s, 0);
+    if (glo >= 0) tstar = 0;
+    else {
+        tstar = 1;
+        for (int k = 1; k < n; k++) {
+            double ghi = cb_half_slope(a, d, s, ts[k]);
+            if (ghi >= 0) { tstar = ts[k - 1] - glo * (ts[k] - ts[k - 1]) / (ghi - glo); break; }
+            glo = ghi;
+        }
+    }
+    double pl[3], ql[3], pw[3], qw[3], dist2 = 0;
+    for (int i = 0; i < 3; i++) {
+        pl[i] = a[i] + tstar * d[i];
+        ql[i] = fmax(-s[i], fmin(s[i], pl[i]));
+        dist2 += (pl[i] - ql[i]) * (pl[i] - ql[i]);
+    }
+    if (dist2 < 1e-20) return -1;
+    mul(pw, b->mat, pl); add3(pw, pw, b->pos);
+    mul(qw, b->mat, ql); add3(qw, qw, b->pos);
+    return sphere_sphere_raw(pw, c->size[0], qw, 0, margin, h);
 }
 
 /* ----------------------------------------------------------- box - box */
@@ -763,10 +824,14 @@ int mjl_collide_pair(const MjlModel* m, const MjlData* d, int g1, int g2, double
     else if (t1 == MJL_CAPSULE && t2 == MJL_CAPSULE) n = capsule_capsule(&a, &b, margin, h);
     else if (t1 == MJL_BOX && t2 == MJL_BOX) n = box_box(&a, &b, margin, h, 8);
     else {
-        a.margin = b.margin = 0.5 * margin;
-        n = mpr_refined(&a, &b, margin, h);
-        if (n && h[0].dist > margin) n = 0;
-        a.margin = b.margin = 0;
+        n = -1;
+        if (t1 == MJL_CAPSULE && t2 == MJL_BOX) n = capsule_box(&a, &b, margin, h);
+        if (n < 0) {
+            a.margin = b.margin = 0.5 * margin;
+            n = mpr_refined(&a, &b, margin, h);
+            if (n && h[0].dist > margin) n = 0;
+            a.margin = b.margin = 0;
+        }
         if (n && (t1 == MJL_CYLINDER || t1 == MJL_CAPSULE) && t2 == MJL_BOX) {
             int k = face_upgrade(&a, &b, h, margin);
             if (k) n = k;
