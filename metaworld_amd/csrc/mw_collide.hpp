@@ -696,6 +696,37 @@ MW_HD Shape<T> make_shape(const Env<T> e, int g) {
     return s;
 }
 
+// A convex shape against a box, decided on the six face axes of the box when that is enough.  For the outward face normal v,
+// delta_v = min_A x.v - max_box x.v is the separation along v (one support evaluation of A).  (i) max_v delta_v > margin: a
+// separating axis, no contact.  (ii) otherwise, if the witness p of the best face (A's support point towards it) projects inside
+// that face, at least the depth away from its edges, the face normal is the exact contact direction (delta >= 0: the box lies in
+// the half space below the face and p's projection is a box point; delta < 0: the face (face - p) of the Minkowski difference
+// contains the foot of the origin with an in-plane clearance >= depth, so no other supporting plane is closer than the depth).
+// (iii) anything else (edges, corners, deep or partial overlaps): -1, the caller runs the portal refinement.
+template <typename T>
+MW_HD int box_face_sat(const Shape<T>& A, const Shape<T>& box, bool box_first, T margin, Hit<T>* h) {
+    T best = T(-1e30);
+    V3<T> bp{0, 0, 0}, bv{0, 0, 0};
+    int bk = 0;
+#pragma unroll 1                             // one instance of the (inlined) support function, not six
+    for (int f = 0; f < 6; f++) {            // faces in the order -x +x -y +y -z +z
+        const int k = f >> 1;
+        const V3<T> v = col(box.mat, k) * T((f & 1) ? 1 : -1);
+        const V3<T> p = support(A, -v);
+        const T delta = dot(p - box.pos, v) - box.size[k];
+        if (delta > best) { best = delta; bk = k; bp = p; bv = v; }
+    }
+    if (best > margin) return 0;
+    const V3<T> locv = mulT(box.mat, bp - box.pos);
+    const T loc[3] = {locv.x, locv.y, locv.z}, inset = best < 0 ? -best : T(0);
+    for (int j = 0; j < 3; j++)
+        if (j != bk && mw_abs(loc[j]) > box.size[j] - inset - (sizeof(T) == 8 ? T(1e-9) : T(1e-6))) return -1;
+    h->dist = best;
+    h->normal = box_first ? bv : -bv;
+    h->pos = bp - bv * (T(0.5) * best);
+    return 1;
+}
+
 // UNIFORM: every active lane of the wave tests the same geom pair (no sub-lanes), so the shapes' model constants can
 // live in scalar registers; with sub-lanes each sub-lane group has its own pair and nothing is wave-uniform.
 // `active`: the call itself is made by EVERY live lane of the wave (see collision()); lanes without a pair to test pass false
@@ -715,6 +746,8 @@ MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, H
     else if (t1 == G_BOX && t2 == G_BOX) n = box_box(ua, ub, margin, h, 8);
     const bool on_box = (t1 == G_CYLINDER || t1 == G_CAPSULE) && t2 == G_BOX;
     if (t1 == G_CAPSULE && t2 == G_BOX) n = capsule_box(ua, ub, margin, h);
+    else if (t2 == G_BOX && (t1 == G_CYLINDER || t1 == G_MESH)) n = box_face_sat(ua, ub, false, margin, h);
+    else if (t1 == G_BOX && (t2 == G_CYLINDER || t2 == G_MESH)) n = box_face_sat(ub, ua, true, margin, h);
     if (n < 0) {
         Shape<T> a = ua, b = ub;
         a.margin = b.margin = T(0.5) * margin;

@@ -783,6 +783,40 @@ static int face_upgrade(const Shape* c, const Shape* box, Hit* h, double margin)
     return m;
 }
 
+/* A convex shape against a box, decided on the six face axes of the box when that is enough.  For the outward face normal v,
+   delta_v = min_A x.v - max_box x.v is the separation along v (one support evaluation of A).  (i) max_v delta_v > margin: a
+   separating axis, no contact.  (ii) otherwise, if the witness p of the best face (A's support point towards it) projects inside
+   that face, at least the depth away from its edges, the face normal is the exact contact direction: for delta >= 0 the box lies
+   in the half space below the face and p's projection is a box point, so the distance is delta; for delta < 0 the face
+   (face - p) of the Minkowski difference contains the foot of the origin with an in-plane clearance >= depth, so no other
+   supporting plane is closer than the depth.  (iii) anything else (edges, corners, deep or partial overlaps): -1, the caller
+   runs the portal refinement.  Normal and position follow the contact convention for (geom1, geom2) = (A, box) or (box, A). */
+static int box_face_sat(const Shape* A, const Shape* box, int box_first, double margin, Hit* h) {
+    double best = -1e30, bp[3] = { 0, 0, 0 }, bv[3] = { 0, 0, 0 };
+    int bk = 0;
+    for (int k = 0; k < 3; k++)
+        for (int sg = -1; sg <= 1; sg += 2) {
+            double v[3], mv[3], p[3], t[3];
+            col3(v, box->mat, k);
+            scl3(v, v, sg);
+            scl3(mv, v, -1);
+            support(A, mv, p);
+            sub3(t, p, box->pos);
+            double delta = dot3(t, v) - box->size[k];
+            if (delta > best) { best = delta; bk = k; copy3(bp, p); copy3(bv, v); }
+        }
+    if (best > margin) return 0;
+    double t[3], loc[3], inset = best < 0 ? -best : 0;
+    sub3(t, bp, box->pos);
+    mulT(loc, box->mat, t);
+    for (int j = 0; j < 3; j++)
+        if (j != bk && fabs(loc[j]) > box->size[j] - inset - 1e-9) return -1;
+    h->dist = best;
+    scl3(h->normal, bv, box_first ? 1 : -1);
+    addscl3(h->pos, bp, bv, -0.5 * best);
+    return 1;
+}
+
 /* ------------------------------------------------------------ dispatch */
 static void make_shape(const MjlModel* m, const MjlData* d, int g, Shape* s) {
     s->type = m->geom_type[g];
@@ -826,6 +860,8 @@ int mjl_collide_pair(const MjlModel* m, const MjlData* d, int g1, int g2, double
     else {
         n = -1;
         if (t1 == MJL_CAPSULE && t2 == MJL_BOX) n = capsule_box(&a, &b, margin, h);
+        else if (t2 == MJL_BOX && (t1 == MJL_CYLINDER || t1 == MJL_MESH)) n = box_face_sat(&a, &b, 0, margin, h);
+        else if (t1 == MJL_BOX && (t2 == MJL_CYLINDER || t2 == MJL_MESH)) n = box_face_sat(&b, &a, 1, margin, h);
         if (n < 0) {
             a.margin = b.margin = 0.5 * margin;
             n = mpr_refined(&a, &b, margin, h);

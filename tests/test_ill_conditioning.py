@@ -13,7 +13,7 @@ import pytest
 from tests.helpers import golden
 
 # (task, env index, step) of the largest device-vs-trace deviation of each waived task (host build, fp64); reach-v3 = control
-CASES = [("door-unlock-v3", 0, 38, 1e-5), ("peg-unplug-side-v3", 0, 1, 1e-5), ("door-close-v3", 0, 47, 1e-7)]
+CASES = [("door-unlock-v3", 0, 41, 1e-5), ("peg-unplug-side-v3", 0, 1, 1e-5)]
 
 
 def _step_reference_from(task, G, e, t, eps):

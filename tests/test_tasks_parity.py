@@ -11,9 +11,8 @@ from tests.helpers import golden, make_env, replay_trace
 # the synchronised state to 2e-5 ... 8e-4 in ONE step (tests/test_ill_conditioning.py proves it on the reference's own Python;
 # tools/experiments/waiver_scan.py finds the states): a contact sitting at its activation margin, or a face-on-face contact whose
 # single contact point is not a continuous function of the poses (the lock's flat mesh faces, the plug seated in its socket).
-# The tolerances are ~3x the deviation measured on the host build (door-unlock 9.5e-5 / 1.6e-3, peg-unplug 8.8e-5 / 2.8e-5,
-# door-close 2.1e-6 / 1.1e-5); 16 sub-lanes, FMA contraction and the single-precision Hessian factor change the rounding on the GPU.
-TOL = {"door-unlock-v3": (3e-4, 5e-3), "peg-unplug-side-v3": (3e-4, 1e-4), "door-close-v3": (1e-5, 5e-5)}
+# The tolerances are ~3x the deviation measured on the host build (door-unlock 5.9e-5 / 7.8e-4, peg-unplug 8.8e-5 / 2.8e-5); 16 sub-lanes, FMA contraction and the single-precision Hessian factor change the rounding on the GPU.
+TOL = {"door-unlock-v3": (2e-4, 3e-3), "peg-unplug-side-v3": (3e-4, 1e-4)}          # (door-close meets 1e-5 since box faces are decided on their axes)
 
 @pytest.mark.parametrize("task", T.ALL_V3)
 def test_task_matches_reference_trace(hostsim, task):
