@@ -90,6 +90,39 @@ def test_fullsize_batch_matches_small_batches_and_oracle(gpulib, bench, n):
     big.close()
 
 
+@pytest.mark.parametrize("bench_name,n", CONFIGS)
+def test_bench_states_match_the_oracle(gpulib, bench_name, n):
+    """VERDICT r2 item 2: parity ON THE STATES bench.py TIMES.  The batch is built and pre-rolled exactly like bench.py::prepare
+    (staggered episode phases, one untimed 500-step horizon of random actions + warm-up: late-episode states with mesh
+    contacts, where the narrow phase dominates); for 4 envs of every task, spread over the episode phases, the oracle engine is
+    synchronised to the device state and both advance 5 substeps: same contact / constraint-row counts, qpos 1e-7, qvel 1e-5.
+    (The obs / reward / success layer on these states is checked against the reference's own Python by
+    tests/test_bench_state_parity.py from the recording tools/dump_bench_states.py makes on the GPU.)"""
+    from types import SimpleNamespace
+    import bench
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    from tools.dump_bench_states import pick_envs
+    env = MetaWorldGpuVectorEnv(bench_name, num_envs=n, seed=42, use_one_hot=True, precision="fp64", lib=gpulib)
+    bench.prepare(env, SimpleNamespace(no_stagger=False, warmup=20, allow_status=False), 0)      # raises on any status flag
+    elapsed = (np.arange(n, dtype=np.int64) * 7919 + bench.HORIZON + 20) % bench.HORIZON          # TimeLimit phase of every env now
+    chosen = pick_envs(env, elapsed)
+    assert len(chosen) == 4 * len(env.task_list)
+    for e in chosen[::17]:
+        assert int(env.ctx.read(e, "task")[3]) == elapsed[e], e
+    synced = [(e, env.env_task_names[e], _oracle_synced_to(env.ctx, e, env.env_task_names[e])) for e in chosen]
+    env.ctx.debug("substeps", 5)
+    bad = []
+    for e, name, (om, d) in synced:
+        d.step(5)
+        ic = env.ctx.read_int(e, "icount")
+        eq, ev = np.abs(env.ctx.read(e, "qpos") - d.qpos).max(), np.abs(env.ctx.read(e, "qvel") - d.qvel).max()
+        if not (ic[0] == d.ncon and ic[1] == d.nefc and eq < 1e-7 and ev < 1e-5):
+            bad.append((name, e, int(elapsed[e]), (int(ic[0]), d.ncon), (int(ic[1]), d.nefc), float(eq), float(ev)))
+    assert not bad, bad
+    assert env.status()["flags"] == 0
+    env.close()
+
+
 def test_fullsize_gather_and_status_through_the_abi(gpulib):
     """MT50 @ 4096: the per-step bookkeeping record of the resident loop (world size 1: no communicator needed) and the status word"""
     from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
