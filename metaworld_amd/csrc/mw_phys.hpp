@@ -1132,7 +1132,6 @@ MW_HD void solve_impl(const Env<T> e) {
         if (scale * (old - cost) < m.tolerance) break;
     }
     MW_HIST(0, e.I(L.icount + 2))
-//CANARY
 }
 
 template <typename T>

@@ -107,6 +107,8 @@ _libs = {}
 
 
 def load(prefix="mw_", path=None) -> Lib:
+    if path is None and prefix == "mw_" and os.environ.get("MW_LIB_OVERRIDE"):          # experiments: run anything (tests, tools) on a variant build of the library
+        path = os.path.join(_HERE, os.environ["MW_LIB_OVERRIDE"])
     path = path or LIB_PATH
     key = (prefix, path)
     if key not in _libs:

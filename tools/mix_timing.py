@@ -38,3 +38,13 @@ for t in env.task_list:
     rows.append((tot[m].max(), t, tot[m].mean(), stage[m][i]))
 for mx, t, mean, st in sorted(rows, reverse=True):
     print(f"{t:30s} max {mx:7.0f} mean {mean:7.0f} | slowest env: " + " ".join(f"{k}:{v:.0f}" for k, v in zip(names[8:], st)))
+# solver phases (kcyc / step; n_ls, n_newt: counts / step) and problem sizes, mean over the envs of a task
+cnt = (ic1 - ic0)[:, 10:12].astype(np.float64) / steps
+print("solver phases, mean over the envs of a task: kcyc/step " + " ".join(names[:6]) + " | per step: line-search evals, Newton iterations | now: ncon nefc")
+for t in env.task_list:
+    m = tn == t
+    ph = d[m][:, :6].mean(0)
+    print(f"{t:30s} " + " ".join(f"{v:6.0f}" for v in ph) + f" | {cnt[m][:, 0].mean():5.1f} {cnt[m][:, 1].mean():5.1f} | {ic1[m][:, 0].mean():5.1f} {ic1[m][:, 1].mean():5.1f}")
+if os.environ.get("MW_MIX_JSON"):
+    import json
+    json.dump({t: dict(max_kcyc=float(tot[tn == t].max()), mean_kcyc=float(tot[tn == t].mean())) for t in env.task_list}, open(os.environ["MW_MIX_JSON"], "w"), indent=1)
