@@ -156,9 +156,9 @@ int mw_gather_bookkeeping(mw_ctx* c, mw_bookkeeping* out, int out_on_device);
  *      8 = CANARY: the copies of a redundantly computed value held by the threads that share one environment disagreed -- the
  *      step kernel's own check against silent register corruption; must always be 0),
  *      status[1..4] = number of env-steps that raised flag 1 / 2 / 4 / 8,
- *      status[5] = Newton directions recomputed with a full-precision factor because the single-precision factor's direction
- *      was not a descent direction, status[6] = line searches abandoned on a non-descent direction (both informational: no
- *      flag bit; MuJoCo's solver stops the same way), status[7] reserved. ---- */
+ *      status[5] = line searches abandoned because the Newton direction was not a descent direction (informational, no flag
+ *      bit: MuJoCo's solver stops the same way; frequent in single precision at the optimum, 0 in fp64 on the bench workload),
+ *      status[6..7] reserved. ---- */
 #define MW_STATUS_WORDS 8
 int mw_status(mw_ctx* c, int32_t* status /*[MW_STATUS_WORDS]*/, int clear);
 

@@ -509,7 +509,8 @@ MW_HD int mpr(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, const V
     dir = cross(v1.v, v0.v);
     if (norm(dir) < T(1e-12)) {
         T depth;
-        const V3<T> d_ = normalized(v1.v, &depth);
+        V3<T> d_ = normalized(v1.v, &depth);
+        if (depth == 0) d_ = normalized(-v0.v);   // the surfaces just touch on the centre line (v1 at the origin): the ray is the contact direction, not normalized()'s (1, 0, 0)
         h->dist = -depth + margin; h->normal = -d_; h->pos = (v1.a + v1.b) * T(0.5);
         return 1;
     }

@@ -118,7 +118,7 @@ constexpr int CON_ISTRIDE = 4;   // ints per contact record
 constexpr int EFC_EXTRA = 11;    // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv, fri, info, state
 constexpr int SR_N = 9;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force, block list, aref; the row's Jacobian follows them
 constexpr int IC_NBLK = 18;      // icount slot: number of constraint blocks (single rows / contact cones)
-constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand, 22 / 23 solver retries / stalls
+constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand, 23 solver stalls
 constexpr int IC_DYN_VALID = 19;  // icount slot: 1 = contacts / constraint rows / solver output belong to the CURRENT qpos (see env_step)
 constexpr int IC_WANT_CON = 20, IC_WANT_EFC = 21;   // running maxima of the contacts / constraint rows a step WANTED (capacity planning)
 constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a non-zero Jacobian entry
@@ -128,7 +128,7 @@ constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a n
 //   8      CANARY: the copies of a redundantly computed value held by the sub-lanes of one environment disagreed (sub_disagree)
 //  16      (MW_BOUNDS debug builds) a column-store / scratchpad index was out of range
 enum { ST_ROW_OVERFLOW = 1, ST_CON_OVERFLOW = 2, ST_UNSTABLE = 4, ST_DIVERGED = 8, ST_OOB = 16 };
-constexpr int IC_SOLVER_RETRY = 22, IC_SOLVER_STALL = 23;   // icount slots: Newton directions recomputed with a T-precision factor / searches abandoned on a non-descent direction (this step)
+constexpr int IC_SOLVER_STALL = 23;   // icount slot: line searches abandoned on a non-descent direction (this step)
 
 struct Sizes {
     int nq, nv, nbody, njnt, ngeom, nsite, nmesh, nmeshvert, npair, nu, neq, nprobe, nreloc;

@@ -1036,68 +1036,53 @@ MW_HD void solve_impl(const Env<T> e) {
             if (k < nv) gn += g * g;
         }
         if (scale * mw_sqrt(gn) < m.tolerance) break;
+        MW_TICK(t_c)
         // Newton direction: -g goes through the column store (L.grad) into its own non-inlined function and the direction comes
         // back in L.search, so that the register allocation of the Hessian (nv (nv + 1) / 2 accumulators + up to four Jacobian
-        // rows) is not mixed with everything that is live in this loop.
-        // The factor is single precision also in an fp64 context (HessType).  If the direction it yields is NOT a descent
-        // direction of the double-precision cost (a float factor of an ill-conditioned H can lose positive definiteness), the
-        // direction is recomputed ONCE with a T-precision factor (counted in icount[IC_SOLVER_RETRY]); a search that still
-        // cannot start is abandoned like in the reference solver, and counted (icount[IC_SOLVER_STALL]).
+        // rows) is not mixed with everything that is live in this loop
         vec_store<T, NV>(e, L.grad, nv, sr);
-        T snorm = 0, quadGauss[3] = {0, 0, 0}, c0 = 0, d1 = 0, d2 = 0;
-        bool descent = false, zero_dir = false;
-        for (int attempt = 0; attempt < 2 && !descent && !zero_dir; attempt++) {
-            MW_TICK(t_c)
-            if (attempt == 0) newton_direction<T, typename HessType<T>::type, NV>(e);
-            else {
-                e.I(L.icount + IC_SOLVER_RETRY) += 1;
-                newton_direction<T, T, NV>(e);
-            }
-            vec_load<T, NV>(e, L.search, nv, sr);
-            MW_TICK(t_f)
-            MW_TOCK(e, L, 1, t_c, t_f)
-            // ---- exact line search (safeguarded Newton on the 1-D convex cost) ----
-            snorm = 0; quadGauss[0] = quadGauss[1] = quadGauss[2] = 0;
-            {
-                T Mv[NV];
-                mat_vec_rows<T, NV>(e, L.qM, nv, sr, L.Mv);
-                vec_load<T, NV>(e, L.Mv, nv, Mv);
+        newton_direction<T, typename HessType<T>::type, NV>(e);
+        vec_load<T, NV>(e, L.search, nv, sr);
+        MW_TICK(t_e)
+        MW_TOCK(e, L, 1, t_c, t_e)
+        MW_TICK(t_f)
+        // ---- exact line search (safeguarded Newton on the 1-D convex cost) ----
+        T snorm = 0, quadGauss[3] = {0, 0, 0};
+        {
+            T Mv[NV];
+            vec_store<T, NV>(e, L.search, nv, sr);
+            mat_vec_rows<T, NV>(e, L.qM, nv, sr, L.Mv);
+            vec_load<T, NV>(e, L.Mv, nv, Mv);
 #pragma unroll
-                for (int k = 0; k < NV; k++) {
-                    const int kk = k < nv ? k : 0;
-                    const T sk = sr[k], r = e.R(L.Ma + kk) - e.R(L.smooth + kk), dq = e.R(L.qacc + kk) - e.R(L.qacc_smooth + kk);
-                    if (k < nv) {
-                        snorm += sk * sk;
-                        quadGauss[1] += sk * r;
-                        quadGauss[2] += T(0.5) * sk * Mv[k];
-                        quadGauss[0] += T(0.5) * r * dq;
-                    }
+            for (int k = 0; k < NV; k++) {
+                const int kk = k < nv ? k : 0;
+                const T sk = sr[k], r = e.R(L.Ma + kk) - e.R(L.smooth + kk), dq = e.R(L.qacc + kk) - e.R(L.qacc_smooth + kk);
+                if (k < nv) {
+                    snorm += sk * sk;
+                    quadGauss[1] += sk * r;
+                    quadGauss[2] += T(0.5) * sk * Mv[k];
+                    quadGauss[0] += T(0.5) * r * dq;
                 }
             }
-            snorm = mw_sqrt(snorm);
-            if (snorm < T(1e-15)) { zero_dir = true; break; }
-            MW_SUBS(e, sub) {
-                for (int i = sub; i < nefc; i += e.nsub) {
-                    T j[NV], s = 0;
-                    jrow_load<T, NV>(e, i, nv, j);
-#pragma unroll
-                    for (int k = 0; k < NV; k++) s += j[k] * sr[k];
-                    sr_set(e, i, SR_JV, s);
-                }
-            }
-            MW_SYNC();
-            MW_TICK(t_g0)
-            MW_TOCK(e, L, 3, t_f, t_g0)
-            line_eval(e, nblk, T(0), quadGauss, &c0, &d1, &d2);
-            MW_TICK(t_g1)
-            MW_TOCK(e, L, 4, t_g0, t_g1)
-            descent = !(d1 >= 0 || d2 <= 0);
-            if (sizeof(typename HessType<T>::type) == sizeof(T)) break;   // the factor already has the precision of the context
         }
-        if (zero_dir) break;
-        if (!descent) { e.I(L.icount + IC_SOLVER_STALL) += 1; break; }
+        snorm = mw_sqrt(snorm);
+        if (snorm < T(1e-15)) break;
+        MW_SUBS(e, sub) {
+            for (int i = sub; i < nefc; i += e.nsub) {
+                T j[NV], s = 0;
+                jrow_load<T, NV>(e, i, nv, j);
+#pragma unroll
+                for (int k = 0; k < NV; k++) s += j[k] * sr[k];
+                sr_set(e, i, SR_JV, s);
+            }
+        }
+        MW_SYNC();
         const T gtol = m.tolerance * T(0.01) * snorm / scale;
         MW_TICK(t_g)
+        MW_TOCK(e, L, 3, t_f, t_g)
+        T c0, d1, d2;
+        line_eval(e, nblk, T(0), quadGauss, &c0, &d1, &d2);
+        if (d1 >= 0 || d2 <= 0) { e.I(L.icount + IC_SOLVER_STALL) += 1; break; }   // not a descent direction (single-precision factor of an ill-conditioned H, or rounding at the optimum): the search is abandoned like in the reference solver, and counted (mw_status)
         T lo = 0, hi = -1, alpha = -d1 / d2;
         int nls = 0;
         for (int it = 0; it < m.sz.ls_iterations; it++) {
@@ -1145,7 +1130,6 @@ MW_HD void solve_impl(const Env<T> e) {
         for (int i = sub; i < nl; i += e.nsub) EX(e, i, 5) = e.lds[e.S(i, SR_FORCE) * e.lds_stride];
     }
     MW_SYNC();
-    if (sub_disagree(e, canary_bits(cost))) e.I(L.icount + 3) |= ST_DIVERGED;   // canary: the solver's final cost, computed redundantly
 }
 
 template <typename T>

@@ -176,7 +176,7 @@ struct IOPtrs {
     double* ep_ret;          // [N]   (valid where done)
     int* ep_len;             // [N]
     mw_bookkeeping* book;    // [N] packed per-step record for the cross-rank gather, or null
-    int* status;             // [MW_STATUS_WORDS] context status: OR of the per-env flags, env-steps with row overflow / contact overflow / instability / sub-lane divergence, solver retries / stalls
+    int* status;             // [MW_STATUS_WORDS] context status: OR of the per-env flags, env-steps with row overflow / contact overflow / instability / sub-lane divergence, solver stalls
     int D;
 };
 
@@ -288,7 +288,7 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     T act[4], obs[39], reward, success;
     Info info;
     for (int k = 0; k < 4; k++) act[k] = (T)w.io.act[(size_t)gid * 4 + k];
-    e.I(e.lay().icount + 3) = 0; e.I(e.lay().icount + IC_SOLVER_RETRY) = 0; e.I(e.lay().icount + IC_SOLVER_STALL) = 0;
+    e.I(e.lay().icount + 3) = 0; e.I(e.lay().icount + IC_SOLVER_STALL) = 0;
     env_step(e, td, act, obs, &reward, &success, &info, w.full_forward != 0);
     // Instability guard (the intent of the reference's dead `_did_see_sim_exception` branch, sawyer_xyz_env.py:603-619, and
     // of MuJoCo's own reset on a bad QACC): a non-finite step returns the last stable observation with reward 0, ends the
@@ -300,7 +300,7 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
         for (int k = 0; k < 18; k++) sig = sig * 31 + canary_bits(obs[k]);
         if (sub_disagree(e, sig) || sub_disagree(e, flags)) flags |= ST_DIVERGED;
     }
-    const int nretry = e.I(e.lay().icount + IC_SOLVER_RETRY), nstall = e.I(e.lay().icount + IC_SOLVER_STALL);
+    const int nstall = e.I(e.lay().icount + IC_SOLVER_STALL);
     bool bad = !mw_finite((double)reward);
     for (int k = 0; k < 18; k++) bad |= !mw_finite((double)obs[k]);
     if (bad) {
@@ -343,13 +343,12 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
             { io.status[0] |= flags; io.status[1] += (flags & ST_ROW_OVERFLOW) != 0; io.status[2] += (flags & ST_CON_OVERFLOW) != 0; io.status[3] += (flags & ST_UNSTABLE) != 0; io.status[4] += (flags & ST_DIVERGED) != 0; }
 #endif
         }
-        if ((nretry | nstall) && io.status) {          // informational counters (no flag bit): see solve_impl
+        if (nstall && io.status) {          // informational counter (no flag bit): see solve_impl
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (nretry) atomicAdd(io.status + 5, nretry);
-            if (nstall) atomicAdd(io.status + 6, nstall);
+            atomicAdd(io.status + 5, nstall);
 #else
 #pragma omp critical(mw_status)
-            { io.status[5] += nretry; io.status[6] += nstall; }
+            { io.status[5] += nstall; }
 #endif
         }
     }

@@ -251,12 +251,11 @@ class Context:
         self._check(self.lib.set_episode_phase(self.ptr, e.ctypes.data))
 
     def status(self, clear=False):
-        """mw_status -> dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps, diverged_steps, solver_retries,
-        solver_stalls); flags: 1 / 2 capacity exceeded, 4 non-finite state, 8 sub-lane divergence canary (include/mwgpu.h)"""
+        """mw_status -> dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps, diverged_steps, solver_stalls); flags: 1 / 2 capacity exceeded, 4 non-finite state, 8 sub-lane divergence canary (include/mwgpu.h)"""
         out = np.zeros(STATUS_WORDS, dtype=np.int32)
         self._check(self.lib.status(self.ptr, out.ctypes.data, int(bool(clear))))
         return dict(flags=int(out[0]), row_overflow_steps=int(out[1]), contact_overflow_steps=int(out[2]), unstable_steps=int(out[3]),
-                    diverged_steps=int(out[4]), solver_retries=int(out[5]), solver_stalls=int(out[6]))
+                    diverged_steps=int(out[4]), solver_stalls=int(out[5]))
 
     def upload_actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32)

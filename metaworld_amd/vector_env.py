@@ -467,7 +467,7 @@ class MetaWorldGpuVectorEnv:
 
     # ---- run-time status (no reference counterpart; SURVEY.md 5 "failure detection") ----
     def status(self, clear=False):
-        """dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps, diverged_steps, solver_retries, solver_stalls)
+        """dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps, diverged_steps, solver_stalls)
         accumulated since the last clear: flag 1 / 2 = the constraint-row / contact capacity of a scene
         (metaworld_amd/data/model_caps.json) was exceeded and rows / contacts were DROPPED; 4 = a non-finite state was caught
         and the env reset (the intent of sawyer_xyz_env.py:603-619); 8 = the step kernel's redundancy canary fired (the

@@ -599,6 +599,7 @@ static int mpr(const Shape* A, const Shape* B, double margin, Hit* h, const doub
         /* origin on the v0-v1 ray: penetration along it */
         double d_[3]; copy3(d_, v1.v);
         double depth = normalize3(d_);
+        if (depth == 0) { scl3(d_, v0.v, -1); normalize3(d_); }   /* the surfaces just touch on the centre line: the ray is the contact direction */
         h->dist = -depth + margin;
         scl3(h->normal, d_, -1);
         for (int k = 0; k < 3; k++) h->pos[k] = 0.5 * (v1.a[k] + v1.b[k]);

@@ -66,7 +66,7 @@ def test_capacity_overflow_is_flagged_and_raised(hostsim):
     for _ in range(3):
         ok.step(np.zeros((2, 4), dtype=np.float32))
     st = ok.status()
-    assert st == dict(flags=0, row_overflow_steps=0, contact_overflow_steps=0, unstable_steps=0, diverged_steps=0, solver_retries=0, solver_stalls=0)
+    assert st == dict(flags=0, row_overflow_steps=0, contact_overflow_steps=0, unstable_steps=0, diverged_steps=0, solver_stalls=0)
     ok.close()
 
 
