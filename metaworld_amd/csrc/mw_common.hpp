@@ -53,7 +53,15 @@ namespace mw {
 #define MW_CTICK(var) const long long var = (long long)__builtin_amdgcn_s_memtime();
 #define MW_CTOCK(e, L, slot, t0, t1) e.I(L.icount + 4 + (slot)) += (int)(((t1) - (t0)) >> 4);
 #define MW_CADD(e, L, slot, v) e.I(L.icount + 4 + (slot)) += (v);
+// per-branch cycles inside collide_pair (slots 4 box-box, 5 portal refinement, 6 the other closed-form routines, 7 face upgrade):
+// a lane records the duration of the branches IT takes; the wave executes every branch some lane takes, one after the other
+#define MW_CP_EXTRA , int* tstat
+#define MW_CP_PASS(x) , x
+#define MW_CSTAT(k, t0, t1) tstat[k] += (int)(((t1) - (t0)) >> 4);
 #else
+#define MW_CP_EXTRA
+#define MW_CP_PASS(x)
+#define MW_CSTAT(k, t0, t1)
 #define MW_CTICK(var)
 #define MW_CTOCK(e, L, slot, t0, t1)
 #define MW_CADD(e, L, slot, v)

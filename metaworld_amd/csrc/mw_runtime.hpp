@@ -29,6 +29,12 @@ namespace mw {
 
 constexpr int BLOCK = 64;   // one wavefront per workgroup: spreads small batches over as many CUs as possible
 
+// MW_VERBOSE >= 2: the address range of every device buffer, so that the address of a GPU memory access fault can be attributed
+inline void mw_log_range(const char* what, int id, const void* p, size_t bytes) {
+    static const int verbose = getenv("MW_VERBOSE") ? atoi(getenv("MW_VERBOSE")) : 0;
+    if (verbose >= 2) fprintf(stderr, "[mwgpu] %-10s %3d  %p .. %p  (%zu bytes)\n", what, id, p, (const void*)((const char*)p + bytes), bytes);
+}
+
 // ------------------------------------------------------------------ host-side model description
 struct ModelData {
     std::map<std::string, std::vector<int>> ints;
@@ -134,6 +140,7 @@ struct DeviceModel {
         }
         iblob = (int*)Backend::alloc(ib.size() * sizeof(int));
         rblob = (T*)Backend::alloc(rb.size() * sizeof(T));
+        mw_log_range("model.int", d.sz.nv, iblob, ib.size() * sizeof(int)); mw_log_range("model.real", d.sz.nv, rblob, rb.size() * sizeof(T));
         Backend::h2d(iblob, ib.data(), ib.size() * sizeof(int));
         Backend::h2d(rblob, rb.data(), rb.size() * sizeof(T));
         size_t k = 0;
@@ -518,6 +525,8 @@ class Context : public ContextBase {
         Backend::zero(g.col, sizeof(T) * g.nreal_total());
         Backend::zero(g.icol, sizeof(int) * g.nint_total());
         g.gid_dev = (int*)Backend::alloc(sizeof(int) * g.nenv);
+        mw_log_range("col", model, g.col, sizeof(T) * g.nreal_total()); mw_log_range("icol", model, g.icol, sizeof(int) * g.nint_total());
+        mw_log_range("gid", model, g.gid_dev, sizeof(int) * g.nenv);
         Backend::h2d(g.gid_dev, gids.data(), sizeof(int) * g.nenv);
     }
     void free_group(Group& g) { Backend::free(g.col); Backend::free(g.icol); Backend::free(g.gid_dev); g.col = nullptr; }
@@ -648,6 +657,9 @@ public:
         d_book_ = (mw_bookkeeping*)Backend::alloc(sizeof(mw_bookkeeping) * 2 * N_); Backend::zero(d_book_, sizeof(mw_bookkeeping) * 2 * N_);
         d_book_all_ = (mw_bookkeeping*)Backend::alloc(sizeof(mw_bookkeeping) * 2 * N_); Backend::zero(d_book_all_, sizeof(mw_bookkeeping) * 2 * N_);
         h_next_goal_.assign(N_, 0); was_reset_.assign(N_, 0);
+        mw_log_range("obs", 0, d_obs_, sizeof(double) * N_ * D); mw_log_range("final_obs", 0, d_final_, sizeof(double) * N_ * D);
+        mw_log_range("act", 0, d_act_, sizeof(float) * 4 * N_); mw_log_range("groups", 0, d_groups_, sizeof(GroupDev<T>) * gd.size());
+        mw_log_range("tasks", 0, d_tasks_, sizeof(TaskDesc<T>) * tasks.size());
         for (int i = 0; i < N_; i++) set_task_field(groups_[env_group_[i]], env_lane_[i], TK_TASK, env_task[i]);
         build_snapshots();
     }
@@ -686,6 +698,7 @@ public:
         const long long total = (long long)snap.size();
         d_snap_ = (T*)Backend::alloc(sizeof(T) * (size_t)(total > 0 ? total : 1));
         Backend::h2d(d_snap_, snap.data(), sizeof(T) * (size_t)total);
+        mw_log_range("snapshots", 0, d_snap_, sizeof(T) * (size_t)total);
         d_snap_off_ = (long long*)Backend::alloc(sizeof(long long) * tasks.size());
         Backend::h2d(d_snap_off_, snap_off_.data(), sizeof(long long) * tasks.size());
         d_snap_stride_ = (int*)Backend::alloc(sizeof(int) * tasks.size());
@@ -896,6 +909,7 @@ public:
         if ((size_t)nsteps > act_capacity_steps_) {
             Backend::free(d_act_);
             d_act_ = (float*)Backend::alloc(sizeof(float) * 4 * N_ * nsteps);
+            mw_log_range("act", nsteps, d_act_, sizeof(float) * 4 * N_ * nsteps);
             act_capacity_steps_ = nsteps;
         }
         Backend::h2d(d_act_, act, sizeof(float) * 4 * N_ * nsteps);

@@ -10,7 +10,7 @@ from metaworld_amd import native
 from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 prec = sys.argv[2] if len(sys.argv) > 2 else "fp64"
-lib = native.load("mw_", os.path.join(ROOT, "metaworld_amd", "libmwgpu_colltiming.so"))
+lib = native.load("mw_", os.path.join(ROOT, "metaworld_amd", os.environ.get("MW_LIB", "libmwgpu_colltiming.so")))
 N = 4096
 env = MetaWorldGpuVectorEnv("MT50", num_envs=N, seed=42, use_one_hot=True, precision=prec, lib=lib)
 env.reset()
@@ -22,12 +22,14 @@ ms = env.ctx.step_resident(steps) / steps
 ic1 = np.array([env.ctx.read_int(e, "icount") for e in range(N)])
 d = (ic1 - ic0)[:, 4:18].astype(np.float64) / steps
 mid, narrow, ncand, rounds, coll = d[:, 0] * 16e-3, d[:, 1] * 16e-3, d[:, 2], d[:, 3], d[:, 10] * 16e-3
+br = d[:, 4:8] * 16e-3          # per-branch kcyc / step inside collide_pair: box-box, portal refinement, other closed forms, face upgrade
 tn = np.array(env.env_task_names)
 print(f"{ms:.2f} ms/launch")
 rows = []
 for t in env.task_list:
     m = np.flatnonzero(tn == t)
     i = m[np.argmax(coll[m])]
-    rows.append((coll[i], t, mid[i], narrow[i], ncand[i], rounds[i], coll[m].mean(), mid[m].mean(), narrow[m].mean(), ncand[m].mean(), rounds[m].mean()))
+    rows.append((coll[i], t, mid[i], narrow[i], ncand[i], rounds[i], coll[m].mean(), mid[m].mean(), narrow[m].mean(), ncand[m].mean(), rounds[m].mean(), br[i], br[m].mean(0)))
 for r in sorted(rows, reverse=True):
-    print(f"{r[1]:30s} slowest env: coll {r[0]:6.0f} kcyc/step = mid {r[2]:5.0f} + narrow {r[3]:6.0f}; cand/step {r[4]:5.1f} rounds/step {r[5]:4.1f} -> {r[3] / max(r[5], 1e-9):6.0f} kcyc/round | mean env: coll {r[6]:6.0f} mid {r[7]:5.0f} narrow {r[8]:6.0f} cand {r[9]:5.1f} rounds {r[10]:4.1f}")
+    print(f"{r[1]:30s} slowest env: coll {r[0]:6.0f} kcyc/step = mid {r[2]:5.0f} + narrow {r[3]:6.0f}; cand/step {r[4]:5.1f} rounds/step {r[5]:4.1f} -> {r[3] / max(r[5], 1e-9):6.0f} kcyc/round | mean env: coll {r[6]:6.0f} mid {r[7]:5.0f} narrow {r[8]:6.0f} cand {r[9]:5.1f} rounds {r[10]:4.1f}"
+          f" | branches (box-box, mpr, closed forms, face upgrade) slowest env " + " ".join(f"{v:.0f}" for v in r[11]) + " mean " + " ".join(f"{v:.0f}" for v in r[12]))
