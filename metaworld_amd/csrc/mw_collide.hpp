@@ -733,7 +733,7 @@ MW_HD int box_face_sat(const Shape<T>& A, const Shape<T>& box, bool box_first, T
 // `active`: the call itself is made by EVERY live lane of the wave (see collision()); lanes without a pair to test pass false
 // and leave through a branch inside this function.
 template <typename T, bool UNIFORM>
-MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h, bool active) {
+MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h, bool active MW_CP_EXTRA) {
     if (!active) return 0;
     const Shape<T> ua = UNIFORM ? a_.uniform() : a_, ub = UNIFORM ? b_.uniform() : b_;
     if (UNIFORM) margin = mw_uniform(margin);
@@ -741,22 +741,32 @@ MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, H
     MW_COUNT(7)
     MW_PAIR_BEGIN(t1, t2)
     int n = -1;
+    MW_CTICK(tp0)
     if (t1 == G_PLANE) n = plane_x(ua, ub, margin, h);
     else if (t1 == G_SPHERE) n = sphere_x(ua, ub, margin, h);
     else if (t1 == G_CAPSULE && t2 == G_CAPSULE) n = capsule_capsule(ua, ub, margin, h);
-    else if (t1 == G_BOX && t2 == G_BOX) n = box_box(ua, ub, margin, h, 8);
+    MW_CTICK(tp1)
+    if (t1 == G_BOX && t2 == G_BOX) { n = box_box(ua, ub, margin, h, 8); MW_CTICK(tp2) MW_CSTAT(0, tp1, tp2) }
+    MW_CTICK(tp3)
     const bool on_box = (t1 == G_CYLINDER || t1 == G_CAPSULE) && t2 == G_BOX;
     if (t1 == G_CAPSULE && t2 == G_BOX) n = capsule_box(ua, ub, margin, h);
     else if (t2 == G_BOX && (t1 == G_CYLINDER || t1 == G_MESH)) n = box_face_sat(ua, ub, false, margin, h);
     else if (t1 == G_BOX && (t2 == G_CYLINDER || t2 == G_MESH)) n = box_face_sat(ub, ua, true, margin, h);
+    MW_CTICK(tp4)
+    if (!(t1 == G_BOX && t2 == G_BOX)) { MW_CSTAT(2, tp0, tp1) MW_CSTAT(2, tp3, tp4) }
     if (n < 0) {
         Shape<T> a = ua, b = ub;
         a.margin = b.margin = T(0.5) * margin;
         n = mpr_refined(a, b, margin, h);
+        MW_CTICK(tp5)
+        MW_CSTAT(1, tp4, tp5)
     }
     if (n && on_box) {
+        MW_CTICK(tp6)
         const int k = face_upgrade(a_, b_, h, margin);
         if (k) n = k;
+        MW_CTICK(tp7)
+        MW_CSTAT(3, tp6, tp7)
     }
     return n;
 }
@@ -868,6 +878,9 @@ MW_STAGE_FN void collision(const Env<T> e_) {
     CLayout& L = e.lay();
     const int npair = m.sz.npair, maxcon = m.sz.maxcon;
     int ncon = 0, flags = 0, want = 0;
+#if defined(MW_COLL_TIMING) && defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    int tstat[4] = {0, 0, 0, 0};
+#endif
     if (e.nsub == 1) {
         for (int p = 0; p < npair; p++) {
             const bool near = pair_near(e, p);
@@ -875,7 +888,7 @@ MW_STAGE_FN void collision(const Env<T> e_) {
             const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
             const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
             Hit<T> h[16];
-            const int cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h, near);
+            const int cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h, near MW_CP_PASS(tstat));
             if (cnt <= 0) continue;
             append_contacts(e, p, cnt, h, ncon, maxcon);
             ncon += cnt;
@@ -910,7 +923,7 @@ MW_STAGE_FN void collision(const Env<T> e_) {
                 const int p = act ? e.I(L.ipair + c0 + sub) : 0;           // (an idle sub-lane builds the shapes of pair 0 and discards them)
                 const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
                 const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
-                int cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)], act);
+                int cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)], act MW_CP_PASS(tstat));
                 if (cnt < 0) cnt = 0;
                 n[MW_SLOT(sub)] = cnt; pp[MW_SLOT(sub)] = p;
             }
@@ -925,6 +938,13 @@ MW_STAGE_FN void collision(const Env<T> e_) {
         MW_CTICK(tc2)
         MW_CTOCK(e, L, 1, tc1, tc2)
     }
+#if defined(MW_COLL_TIMING) && defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    for (int k = 0; k < 4; k++) {          // the slowest sub-lane's share of every branch class (max over the environment's sub-lanes)
+        int v = tstat[k];
+        for (int off = e.lds_stride; off < 64; off <<= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+        e.I(L.icount + 8 + k) += v;
+    }
+#endif
     // canary: ncon / want / flags are computed redundantly by every sub-lane of the environment and must agree
     if (sub_disagree(e, ncon) || sub_disagree(e, want) || sub_disagree(e, flags)) flags |= ST_DIVERGED;
     e.I(L.icount) = ncon;

@@ -53,7 +53,15 @@ namespace mw {
 #define MW_CTICK(var) const long long var = (long long)__builtin_amdgcn_s_memtime();
 #define MW_CTOCK(e, L, slot, t0, t1) e.I(L.icount + 4 + (slot)) += (int)(((t1) - (t0)) >> 4);
 #define MW_CADD(e, L, slot, v) e.I(L.icount + 4 + (slot)) += (v);
+// per-branch cycles inside collide_pair (slots 4 box-box, 5 portal refinement, 6 the other closed-form routines, 7 face upgrade):
+// a lane records the duration of the branches IT takes; the wave executes every branch some lane takes, one after the other
+#define MW_CP_EXTRA , int* tstat
+#define MW_CP_PASS(x) , x
+#define MW_CSTAT(k, t0, t1) tstat[k] += (int)(((t1) - (t0)) >> 4);
 #else
+#define MW_CP_EXTRA
+#define MW_CP_PASS(x)
+#define MW_CSTAT(k, t0, t1)
 #define MW_CTICK(var)
 #define MW_CTOCK(e, L, slot, t0, t1)
 #define MW_CADD(e, L, slot, v)
@@ -116,7 +124,7 @@ constexpr int MAX_NV = 17;       // register-resident solver arrays are sized by
 constexpr int CON_STRIDE = 26;   // reals per contact record
 constexpr int CON_ISTRIDE = 4;   // ints per contact record
 constexpr int EFC_EXTRA = 11;    // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv, fri, info, state
-constexpr int SR_N = 8;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force, block list
+constexpr int SR_N = 9;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force, block list, aref; the row's Jacobian follows them
 constexpr int IC_NBLK = 18;      // icount slot: number of constraint blocks (single rows / contact cones)
 constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand, 23 solver stalls
 constexpr int IC_DYN_VALID = 19;  // icount slot: 1 = contacts / constraint rows / solver output belong to the CURRENT qpos (see env_step)
@@ -209,7 +217,7 @@ inline Layout make_layout(const Sizes& s) {
 
 // workgroup scratchpad handed to every lane program: LDS on the device (stride = lanes per workgroup), a private
 // buffer per host thread in the test harness (stride 1)
-struct Scratchpad { MW_LDS void* base; int block_words, host_nsub; };   // 4-byte words of the whole workgroup; host_nsub > 0: host harness (one call per env, that many emulated sub-lanes)
+struct Scratchpad { MW_LDS void* base; int block_words, host_nsub, max_rows; };   // 4-byte words of the whole workgroup; host_nsub > 0: host harness (one call per env, that many emulated sub-lanes); max_rows > 0: cap on the rows kept in the scratchpad (tests of the fallback rows)
 
 template <typename T> using CModel = const MW_CONST Model<T>;
 using CLayout = const MW_CONST Layout;
@@ -228,7 +236,8 @@ struct Env {
     int lds_stride;
     int sub, nsub;     // sub-lane of this thread and sub-lanes per environment (cooperative row sweeps, see below)
     int thr;           // thread index inside the workgroup
-    int lds_rows;      // constraint rows whose solver scalars fit in the scratchpad (the rest stay in the column store)
+    int lds_rows;      // constraint rows that fit in the scratchpad: scalars + Jacobian row (the rest stay in the column store)
+    int lds_w;         // scratchpad slots per row = SR_N + nv
 #if defined(MW_BOUNDS)   // debug build: every column-store access is range-checked; a violation is recorded and redirected to element 0
     unsigned nreal_b, nint_b;
     int* oob;          // context status word: [0] |= ST_OOB, [1] = kind (1 real, 2 int, 3 scratchpad), [2] = index, [3] = limit
@@ -239,14 +248,16 @@ struct Env {
     }
 #endif
     // lpb = environments per workgroup of this environment's group; threads t, t + lpb, ... are its sub-lanes
-    MW_HD void set_scratchpad(Scratchpad sp, int thread, int lpb) {
+    MW_HD void set_scratchpad(Scratchpad sp, int thread, int lpb, int nv_) {
         const bool host = sp.host_nsub > 0;
         lds = (MW_LDS T*)sp.base + (host ? 0 : thread % lpb);
         lds_stride = host ? 1 : lpb;
         sub = host ? 0 : thread / lpb;
         thr = thread;
         nsub = host ? sp.host_nsub : 64 / lpb;
-        lds_rows = (int)((host ? sp.block_words : sp.block_words / lpb) * 4 / (SR_N * sizeof(T)));
+        lds_w = SR_N + nv_;
+        lds_rows = (int)((host ? sp.block_words : sp.block_words / lpb) * 4 / (lds_w * sizeof(T)));
+        if (sp.max_rows > 0 && lds_rows > sp.max_rows) lds_rows = sp.max_rows;
     }
     MW_HD void cache_layout(const Layout& L, int nv_) {
         nv = nv_; o_efcJ = L.efcJ; o_efcX = L.efcX; o_con = L.con; o_icon = L.icon; o_iefc = L.iefc; o_icount = L.icount; o_task = L.task;
@@ -257,7 +268,7 @@ struct Env {
         u.stride = mw_uniform(stride);
         u.nv = mw_uniform(nv); u.o_efcJ = mw_uniform(o_efcJ); u.o_efcX = mw_uniform(o_efcX); u.o_con = mw_uniform(o_con);
         u.o_icon = mw_uniform(o_icon); u.o_iefc = mw_uniform(o_iefc); u.o_icount = mw_uniform(o_icount); u.o_task = mw_uniform(o_task);
-        u.lds_rows = mw_uniform(lds_rows); u.lds_stride = mw_uniform(lds_stride); u.nsub = mw_uniform(nsub);
+        u.lds_rows = mw_uniform(lds_rows); u.lds_w = mw_uniform(lds_w); u.lds_stride = mw_uniform(lds_stride); u.nsub = mw_uniform(nsub);
         return u;
     }
     MW_HD CModel<T>& model() const { return *(CModel<T>*)(unsigned long long)m; }
@@ -265,11 +276,11 @@ struct Env {
 #if defined(MW_BOUNDS)
     MW_HD GRef<T> R(int i) const { return ((MW_GLOBAL T*)col)[chk(i, nreal_b, 1) * stride]; }
     MW_HD GRef<int> I(int i) const { return ((MW_GLOBAL int*)icol)[chk(i, nint_b, 2) * stride]; }
-    MW_HD int S(int row, int f) const { return (int)chk(row, (unsigned)lds_rows, 3) * SR_N + f; }   // scratchpad slot of (row, field)
+    MW_HD int S(int row, int f) const { return (int)chk(row, (unsigned)lds_rows, 3) * lds_w + f; }   // scratchpad slot of (row, field)
 #else
     MW_HD GRef<T> R(int i) const { return ((MW_GLOBAL T*)col)[(unsigned)i * stride]; }
     MW_HD GRef<int> I(int i) const { return ((MW_GLOBAL int*)icol)[(unsigned)i * stride]; }
-    MW_HD int S(int row, int f) const { return row * SR_N + f; }
+    MW_HD int S(int row, int f) const { return row * lds_w + f; }   // scratchpad slot of (row, field); fields >= SR_N: the row's Jacobian
 #endif
 };
 

@@ -401,21 +401,72 @@ MW_STAGE_FN void smooth_forces(const Env<T> e_) {
 }
 
 // ------------------------------------------------------------------ constraint rows
-// efcX per row: 0 pos, 1 margin, 2 R, 3 D, 4 aref, 5 force, 6 jar, 7 Jv
+// A constraint row = its Jacobian (nv entries) + the scalars the solver sweeps need.  Rows live in the WORKGROUP SCRATCHPAD
+// (LDS on the device) while there is room -- row r of the environment in lane l: slots (r * (SR_N + nv) + field) * lpb + l,
+// fields 0 .. SR_N-1 the scalars (enum SR_*), SR_N + i the Jacobian entry of dof i -- and in the column store beyond that
+// (efcJ[row][nv], efcX[row][EFC_EXTRA]).  The solver sweeps every row ~10-30 times per dynamics evaluation; from LDS a row is
+// one ~100-cycle round trip, from the column store (L2 / HBM) 300-900, and the rows no longer travel to HBM and back once per
+// evaluation (they were the largest part of the kernel's write traffic).
+// efcX per row: 3 D, 4 aref, 5 force, 6 jar, 7 Jv, 8 friction scale, 9 row descriptor, 10 state (0-2 unused)
 template <typename T> MW_HD GRef<T> EX(const Env<T> e, int row, int k) { return e.R(e.o_efcX + EFC_EXTRA * row + k); }
 template <typename T> MW_HD GRef<T> EJ(const Env<T> e, int row, int i) { return e.R(e.o_efcJ + row * e.nv + i); }
 template <typename T> MW_HD GRef<T> CON(const Env<T> e, int c, int k) { return e.R(e.o_con + CON_STRIDE * c + k); }
 // contact record: 0 dist, 1-3 pos, 4-12 frame, 13 includemargin, 14-16 friction(slide,torsion,roll), 17-18 solref, 19-23 solimp, 24 mu
 template <typename T> MW_HD GRef<int> ICON(const Env<T> e, int c, int k) { return e.I(e.o_icon + CON_ISTRIDE * c + k); }  // g1,g2,dim,efc_address
-template <typename T> MW_HD GRef<int> IEFC(const Env<T> e, int r, int k) { return e.I(e.o_iefc + EFC_ISTRIDE * r + k); }  // type,id,state
+template <typename T> MW_HD GRef<int> IEFC(const Env<T> e, int r, int k) { return e.I(e.o_iefc + EFC_ISTRIDE * r + k); }  // 0 type, 1 id, 2 first row of block r (rows beyond the scratchpad)
 
-// dense load of constraint row `row` of J into registers (rows are zero outside their dof range; entries >= nv
-// re-read column 0 and are never used -- no per-element branches, so the loads issue back to back)
-template <typename T, int NV>
-MW_HD void jrow_load(const Env<T> e, int row, int nv, T* j) {
-#pragma unroll
-    for (int k = 0; k < NV; k++) j[k] = EJ(e, row, k < nv ? k : 0);
+// Solver row scalars: `info` = type + 16 * dim + 256 * k (k-th row of a dim-row cone block); the rows of a block are visited
+// from its first row with a wave-uniform counter.
+enum { SR_D = 0, SR_JAR, SR_JV, SR_FRI, SR_INFO, SR_STATE, SR_FORCE, SR_BLK, SR_AREF };
+MW_HD constexpr int sr_slot(int f) { return f == SR_D ? 3 : f == SR_JAR ? 6 : f == SR_JV ? 7 : f == SR_FRI ? 8 : f == SR_INFO ? 9 : f == SR_STATE ? 10 : f == SR_AREF ? 4 : 5; }
+template <typename T>
+MW_HD T sr_get(const Env<T> e, int i, int f) {
+    if (i < e.lds_rows) return e.lds[e.S(i, f) * e.lds_stride];
+    return EX(e, i, sr_slot(f));
 }
+template <typename T>
+MW_HD void sr_set(const Env<T> e, int i, int f, T v) {
+    if (i < e.lds_rows) e.lds[e.S(i, f) * e.lds_stride] = v;
+    else EX(e, i, sr_slot(f)) = v;
+}
+template <typename T>
+MW_HD void ej_set(const Env<T> e, int row, int i, T v) {
+    if (row < e.lds_rows) e.lds[e.S(row, SR_N + i) * e.lds_stride] = v;
+    else EJ(e, row, i) = v;
+}
+template <typename T>
+MW_HD T ej_get(const Env<T> e, int row, int i) {
+    if (row < e.lds_rows) return e.lds[e.S(row, SR_N + i) * e.lds_stride];
+    return EJ(e, row, i);
+}
+// first row of constraint block k (list built by make_constraints)
+template <typename T>
+MW_HD int block_row(const Env<T> e, int k) {
+    if (k < e.lds_rows) return (int)e.lds[e.S(k, SR_BLK) * e.lds_stride];
+    return IEFC(e, k, 2);
+}
+template <typename T>
+MW_HD void set_block_row(const Env<T> e, int k, int row) {
+    if (k < e.lds_rows) e.lds[e.S(k, SR_BLK) * e.lds_stride] = T(row);
+    else IEFC(e, k, 2) = row;
+}
+
+// dense load of constraint row `row` of J into registers (rows are zero outside their dof range; entries >= nv re-read
+// entry 0 and are never used -- no per-element branches, so the loads issue back to back)
+template <typename T, typename HT, int NV>
+MW_HD void jrow_load_as(const Env<T> e, int row, int nv, HT* j) {
+    if (row < e.lds_rows) {
+        const int base = e.S(row, SR_N);
+#pragma unroll
+        for (int k = 0; k < NV; k++) j[k] = (HT)e.lds[(base + (k < nv ? k : 0)) * e.lds_stride];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NV; k++) j[k] = (HT)EJ(e, row, k < nv ? k : 0);
+    }
+}
+template <typename T, int NV>
+MW_HD void jrow_load(const Env<T> e, int row, int nv, T* j) { jrow_load_as<T, T, NV>(e, row, nv, j); }
+
 template <typename T, typename P>
 MW_HD T impedance(P solimp, T x) {
     T d0 = mw_clamp(solimp[0], T(0.0001), T(0.9999)), dw = mw_clamp(solimp[1], T(0.0001), T(0.9999));
@@ -431,53 +482,28 @@ MW_HD T impedance(P solimp, T x) {
     return d0 + y * (dw - d0);
 }
 
-// finish a row whose J / pos / margin are set: regulariser R, D, reference acceleration
+// The scalars of a row whose Jacobian is written: regulariser R -> D = 1 / R and the reference acceleration, from the row's
+// residual r = pos - margin and velocity vel = J qvel (accumulated by the caller while it fills the row, dof by dof in ascending
+// order: the sum the row-by-row form took from the stored row); Jv starts at 0 (it is read, times alpha = 0, before the first
+// search direction exists).
 template <typename T, typename P1, typename P2>
-MW_HD void finish_row(const Env<T> e, int row, P1 solref, P2 solimp, T diagApprox, T* Rout, T* Bout, T* Iout) {
+MW_HD void finish_row(const Env<T> e, int row, P1 solref, P2 solimp, T diagApprox, T r, T vel, T fri, T info, T* Rout, T* Bout) {
     CModel<T>& m = e.model();
-    const int nv = m.sz.nv;
     T tc = solref[0], dr = solref[1];
     if (tc > 0) tc = mw_max(tc, 2 * m.timestep);
     const T dmax = mw_clamp(solimp[1], T(0.0001), T(0.9999));
     const T K = 1 / mw_max(T(1e-15), dmax * dmax * tc * tc * dr * dr), B = 2 / mw_max(T(1e-15), dmax * tc);
-    const T r = EX(e, row, 0) - EX(e, row, 1);
     const T imp = impedance(solimp, r);
     const T R = mw_max(T(1e-15), (1 - imp) / imp * diagApprox);
-    T vel = 0;
-    for (int i = IEFC(e, row, 3); i <= IEFC(e, row, 4); i++) vel += EJ(e, row, i) * e.R(e.lay().qvel + i);
-    (void)nv;
-    EX(e, row, 2) = R; EX(e, row, 3) = 1 / R;
-    EX(e, row, 4) = -B * vel - K * imp * r;
-    if (Rout) { *Rout = R; *Bout = B; *Iout = imp; }
+    sr_set(e, row, SR_D, 1 / R); sr_set(e, row, SR_AREF, -B * vel - K * imp * r);
+    sr_set(e, row, SR_FRI, fri); sr_set(e, row, SR_INFO, info); sr_set(e, row, SR_JV, T(0));
+    if (Rout) { *Rout = R; *Bout = B; }
 }
 
-template <typename T>
-MW_HD void row_range(const Env<T> e, int row, int first, int last) {
-    if (first < IEFC(e, row, 3)) IEFC(e, row, 3) = first;
-    if (last > IEFC(e, row, 4)) IEFC(e, row, 4) = last;
-}
 // Jacobian rows are filled DOF BY DOF: body_dofmask[b] (derived at upload) says which dofs lie on body b's chain, so the motion
 // axes cdof[i] are loaded once per dof at an address that does not depend on a previous load, and every entry
-// J[row][i] = sign_a * (axis . jac_a) + sign_b * (axis . jac_b) is stored once.  (The row-by-row form walked dof_parentid for
-// every row and body: ~2 dependent round trips per entry, and a read-modify-write of the row in the column store.)  The two
-// terms are added in the order the reference-style accumulation used (first body of the call order first), so the values
-// are the same.
-MW_HD int mask_first(int mask) { int i = 0; while (!((mask >> i) & 1)) i++; return i; }
-MW_HD int mask_last(int mask) { int i = 31; while (!((mask >> i) & 1)) i--; return i; }
-// initialise rows r0 .. r0+n-1 of one constraint (type, id): empty Jacobian rows, descriptor, friction scale
-template <typename T>
-MW_HD void init_rows(const Env<T> e, int r0, int n, int type, int id) {
-    const int nv = e.nv;
-    for (int k = 0; k < n; k++) {
-        IEFC(e, r0 + k, 0) = type; IEFC(e, r0 + k, 1) = id;
-        IEFC(e, r0 + k, 3) = nv; IEFC(e, r0 + k, 4) = -1;
-        for (int i = 0; i < nv; i++) EJ(e, r0 + k, i) = 0;
-        EX(e, r0 + k, 0) = 0; EX(e, r0 + k, 1) = 0;
-        // solver row descriptor: type + 16 * (rows in this cone block) + 256 * (index inside the block)
-        EX(e, r0 + k, 8) = 0; EX(e, r0 + k, 9) = type == C_CONTACT ? T(type + 16 * n + 256 * k) : T(type + 16);
-    }
-}
-
+// J[row][i] = sign_a * (axis . jac_a) + sign_b * (axis . jac_b) is stored once (zero off the chains).  The two terms are added in
+// the order the reference-style accumulation used (first body of the call order first), so the values are the same.
 template <typename T>
 MW_HD void weld_rows(const Env<T> e, int q, int r0) {
     CModel<T>& m = e.model();
@@ -491,13 +517,17 @@ MW_HD void weld_rows(const Env<T> e, int q, int r0) {
     Q4<T> qa = qmul(ld4(e, L.xquat + 4 * b1), mq4(data + 6));
     Q4<T> q2n = qconj(ld4(e, L.xquat + 4 * b2));
     Q4<T> qr = qmul(q2n, qa);
-    init_rows(e, r0, 6, C_EQUALITY, q);
     // translational rows k: + axis_k . (v + w x p1) of body 1, - axis_k . (v + w x p2) of body 2
     // rotational rows: 0.5 * imag( conj(q2) * (w1 - w2) * q1 * rel ) * torquescale
     const int m1 = m.body_dofmask[b1], m2 = m.body_dofmask[b2], both = m1 | m2;
+    T vel[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < e.nv; i++) {
-        if (!((both >> i) & 1)) continue;
+        if (!((both >> i) & 1)) {
+            for (int k = 0; k < 6; k++) ej_set(e, r0 + k, i, T(0));
+            continue;
+        }
         const V3<T> w = ld3(e, L.cdof + 6 * i), v = ld3(e, L.cdof + 6 * i + 3);
+        const T qd = e.R(L.qvel + i);
         const bool in1 = (m1 >> i) & 1, in2 = (m2 >> i) & 1;
         const V3<T> l1 = v + cross(w, p1), l2 = v + cross(w, p2);
         const Q4<T> q4 = qmul(qmul(q2n, Q4<T>{0, w.x, w.y, w.z}), qa);
@@ -507,15 +537,16 @@ MW_HD void weld_rows(const Env<T> e, int q, int r0) {
             T acc = 0, acr = 0;
             if (in1) { acc += T(1) * dot(ax, l1); acr += T(1) * T(0.5) * rot[k] * ts; }
             if (in2) { acc += T(-1) * dot(ax, l2); acr += T(-1) * T(0.5) * rot[k] * ts; }
-            EJ(e, r0 + k, i) = acc;
-            EJ(e, r0 + 3 + k, i) = acr;
+            ej_set(e, r0 + k, i, acc);
+            ej_set(e, r0 + 3 + k, i, acr);
+            vel[k] += acc * qd; vel[3 + k] += acr * qd;
         }
     }
-    if (both) for (int k = 0; k < 6; k++) { IEFC(e, r0 + k, 3) = mask_first(both); IEFC(e, r0 + k, 4) = mask_last(both); }
     const T res[6] = {cp.x, cp.y, cp.z, ts * qr.x, ts * qr.y, ts * qr.z};
     for (int k = 0; k < 6; k++) {
-        EX(e, r0 + k, 0) = res[k];
-        finish_row(e, r0 + k, m.eq_solref + 2 * q, m.eq_solimp + 5 * q, m.eq_invweight0[2 * q + (k >= 3)], (T*)nullptr, (T*)nullptr, (T*)nullptr);
+        IEFC(e, r0 + k, 0) = C_EQUALITY; IEFC(e, r0 + k, 1) = q;
+        finish_row(e, r0 + k, m.eq_solref + 2 * q, m.eq_solimp + 5 * q, m.eq_invweight0[2 * q + (k >= 3)], res[k], vel[k], T(0), T(C_EQUALITY + 16),
+                   (T*)nullptr, (T*)nullptr);
     }
 }
 
@@ -523,14 +554,14 @@ template <typename T>
 MW_HD void limit_row(const Env<T> e, int id, int r) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    const int j = id >> 1, side = (id & 1) ? 1 : -1;
+    const int j = id >> 1, side = (id & 1) ? 1 : -1, dof = m.jnt_dofadr[j];
     const T q = e.R(L.qpos + m.jnt_qposadr[j]), margin = m.jnt_margin[j];
     const T dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - q);
-    init_rows(e, r, 1, C_LIMIT, id);
-    EJ(e, r, m.jnt_dofadr[j]) = T(-side);
-    row_range(e, r, m.jnt_dofadr[j], m.jnt_dofadr[j]);
-    EX(e, r, 0) = dist; EX(e, r, 1) = margin;
-    finish_row(e, r, m.jnt_solref + 2 * j, m.jnt_solimp + 5 * j, m.dof_invweight0[m.jnt_dofadr[j]], (T*)nullptr, (T*)nullptr, (T*)nullptr);
+    for (int i = 0; i < e.nv; i++) ej_set(e, r, i, i == dof ? T(-side) : T(0));
+    IEFC(e, r, 0) = C_LIMIT; IEFC(e, r, 1) = id;
+    T vel = 0;
+    vel += T(-side) * e.R(L.qvel + dof);
+    finish_row(e, r, m.jnt_solref + 2 * j, m.jnt_solimp + 5 * j, m.dof_invweight0[dof], dist - margin, vel, T(0), T(C_LIMIT + 16), (T*)nullptr, (T*)nullptr);
 }
 
 template <typename T>
@@ -539,41 +570,43 @@ MW_HD void contact_rows(const Env<T> e, int c, int r0) {
     CLayout& L = e.lay();
     const T dist = CON(e, c, 0), inc = CON(e, c, 13);
     const int g1 = ICON(e, c, 0), g2 = ICON(e, c, 1), dim = ICON(e, c, 2);
-    init_rows(e, r0, dim, C_CONTACT, c);
     const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
     V3<T> pos{CON(e, c, 1), CON(e, c, 2), CON(e, c, 3)};
     const int m1 = m.body_dofmask[b1], m2 = m.body_dofmask[b2], both = m1 | m2;
     V3<T> ax[3];
     for (int a = 0; a < 3; a++) ax[a] = V3<T>{CON(e, c, 4 + 3 * a), CON(e, c, 5 + 3 * a), CON(e, c, 6 + 3 * a)};
+    T vel[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < e.nv; i++) {
-        if (!((both >> i) & 1)) continue;
+        if (!((both >> i) & 1)) {
+            for (int k = 0; k < dim; k++) ej_set(e, r0 + k, i, T(0));
+            continue;
+        }
         const V3<T> w = ld3(e, L.cdof + 6 * i), lin = ld3(e, L.cdof + 6 * i + 3) + cross(w, pos);
+        const T qd = e.R(L.qvel + i);
         const bool in1 = (m1 >> i) & 1, in2 = (m2 >> i) & 1;
         for (int k = 0; k < dim; k++) {
             const T val = k >= 3 ? dot(ax[k - 3], w) : dot(ax[k], lin);
             T acc = 0;
             if (in2) acc += T(1) * val;            // body 2 first, then body 1 (the order of the row-by-row accumulation)
             if (in1) acc += T(-1) * val;
-            EJ(e, r0 + k, i) = acc;
+            ej_set(e, r0 + k, i, acc);
+            vel[k] += acc * qd;
         }
     }
-    if (both) for (int k = 0; k < dim; k++) { IEFC(e, r0 + k, 3) = mask_first(both); IEFC(e, r0 + k, 4) = mask_last(both); }
-    EX(e, r0, 0) = dist; EX(e, r0, 1) = inc;
+    for (int k = 0; k < dim; k++) { IEFC(e, r0 + k, 0) = C_CONTACT; IEFC(e, r0 + k, 1) = c; }
     T solref[2] = {CON(e, c, 17), CON(e, c, 18)}, solimp[5];
     for (int k = 0; k < 5; k++) solimp[k] = CON(e, c, 19 + k);
     const T wt = m.geom_invweight0[2 * g1] + m.geom_invweight0[2 * g2];
-    T R0, B, imp;
-    finish_row(e, r0, solref, solimp, wt, &R0, &B, &imp);
-    // friction rows: R scaled by friction ratios (impratio 1), aref = -B * vel
     const T f0 = CON(e, c, 14), f1 = CON(e, c, 15);
-    EX(e, r0, 8) = f0;   // mu
+    T R0, B;
+    // solver row descriptor: type + 16 * (rows in this cone block) + 256 * (index inside the block); friction scale of row 0 = mu
+    finish_row(e, r0, solref, solimp, wt, dist - inc, vel[0], f0, T(C_CONTACT + 16 * dim), &R0, &B);
+    // friction rows: R scaled by friction ratios (impratio 1), aref = -B * vel
     for (int k = 1; k < dim; k++) {
         const T fk = k < 3 ? f0 : f1;
-        EX(e, r0 + k, 8) = fk;
         const T R = R0 * f0 * f0 / (fk * fk);
-        T vel = 0;
-        for (int i = IEFC(e, r0 + k, 3); i <= IEFC(e, r0 + k, 4); i++) vel += EJ(e, r0 + k, i) * e.R(L.qvel + i);
-        EX(e, r0 + k, 2) = R; EX(e, r0 + k, 3) = 1 / R; EX(e, r0 + k, 4) = -B * vel;
+        sr_set(e, r0 + k, SR_D, 1 / R); sr_set(e, r0 + k, SR_AREF, -B * vel[k]);
+        sr_set(e, r0 + k, SR_FRI, fk); sr_set(e, r0 + k, SR_INFO, T(C_CONTACT + 16 * dim + 256 * k)); sr_set(e, r0 + k, SR_JV, T(0));
     }
     CON(e, c, 24) = f0;  // mu = friction[0] * sqrt(R[1]/R[0]) with impratio 1
 }
@@ -597,7 +630,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
         want += 6;
         if (nefc + 6 > maxefc) { flags |= ST_ROW_OVERFLOW; continue; }
         work(C_EQUALITY, q, nefc);
-        for (int k = 0; k < 6; k++) IEFC(e, nblk + k, 2) = nefc + k;
+        for (int k = 0; k < 6; k++) set_block_row(e, nblk + k, nefc + k);
         nblk += 6; nefc += 6;
     }
     // ---- joint limits ----
@@ -610,7 +643,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
                 want += 1;
                 if (nefc + 1 > maxefc) { flags |= ST_ROW_OVERFLOW; continue; }
                 work(C_LIMIT, 2 * j + (side > 0), nefc);
-                IEFC(e, nblk, 2) = nefc;
+                set_block_row(e, nblk, nefc);
                 nblk++; nefc++;
             }
         }
@@ -627,7 +660,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
             else {
                 adr = nefc;
                 work(C_CONTACT, c, nefc);
-                IEFC(e, nblk, 2) = nefc;
+                set_block_row(e, nblk, nefc);
                 nblk++; nefc += dim;
             }
         }
@@ -652,25 +685,6 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
 
 
 // ------------------------------------------------------------------ Newton solver
-// Solver row scalars.  The solver sweeps the constraint rows many times (cost/force updates, Hessian assembly and
-// every line-search evaluation); on the GPU each sweep is a chain of dependent memory round trips per row.  The
-// scalars a sweep needs (D, jar, Jv, friction scale, descriptor, state, force, block list) therefore live in the
-// workgroup scratchpad (LDS, ~50-cycle reads instead of ~200-900) for the first `lds_rows` rows; rows beyond the
-// scratchpad capacity use slots of the row's record in the column store.  `info` = type + 16 * dim + 256 * k (k-th
-// row of a dim-row cone block); the rows of a block are visited from its first row with a wave-uniform counter.
-enum { SR_D = 0, SR_JAR, SR_JV, SR_FRI, SR_INFO, SR_STATE, SR_FORCE, SR_BLK };
-MW_HD constexpr int sr_slot(int f) { return f == SR_D ? 3 : f == SR_JAR ? 6 : f == SR_JV ? 7 : f == SR_FRI ? 8 : f == SR_INFO ? 9 : f == SR_STATE ? 10 : 5; }
-template <typename T>
-MW_HD T sr_get(const Env<T> e, int i, int f) {
-    if (i < e.lds_rows) return e.lds[e.S(i, f) * e.lds_stride];
-    return EX(e, i, sr_slot(f));
-}
-template <typename T>
-MW_HD void sr_set(const Env<T> e, int i, int f, T v) {
-    if (i < e.lds_rows) e.lds[e.S(i, f) * e.lds_stride] = v;
-    else EX(e, i, sr_slot(f)) = v;
-}
-
 // Row accessors for the sweep bodies: Rows<T, true> reads the scratchpad unconditionally (the caller has checked
 // that row i .. i+3 are inside it), Rows<T, false> takes the per-access generic path.  Instantiating each sweep body
 // for both keeps the scratchpad reads of one row in a single basic block (issued back to back, one wait).
@@ -725,9 +739,9 @@ MW_HD void uc_row(const R& rows, const Env<T> e, int i, T* cost) {
     if (type == C_EQUALITY || (type == C_LIMIT && jar < 0)) {
         const T f = -D * jar;
         *cost += T(0.5) * D * jar * jar;
-        rows.set(i, SR_FORCE, f); rows.set(i, SR_STATE, T(S_QUADRATIC)); EX(e, i, 5) = f;
+        rows.set(i, SR_FORCE, f); rows.set(i, SR_STATE, T(S_QUADRATIC));
     } else if (type == C_LIMIT) {
-        rows.set(i, SR_FORCE, T(0)); rows.set(i, SR_STATE, T(S_SATISFIED)); EX(e, i, 5) = 0;
+        rows.set(i, SR_FORCE, T(0)); rows.set(i, SR_STATE, T(S_SATISFIED));
     } else {
         const int dim = (info >> 4) & 15;
         ConeEval<T> z = cone_eval<T>(rows, i, dim, T(0));
@@ -751,15 +765,8 @@ MW_HD void uc_row(const R& rows, const Env<T> e, int i, T* cost) {
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (k < dim) { rows.set(i + k, SR_FORCE, f[k]); rows.set(i + k, SR_STATE, T(st)); EX(e, i + k, 5) = f[k]; }
+            if (k < dim) { rows.set(i + k, SR_FORCE, f[k]); rows.set(i + k, SR_STATE, T(st)); }
     }
-}
-
-// first row of constraint block k (scratchpad copy of the list built by make_constraints)
-template <typename T>
-MW_HD int block_row(const Env<T> e, int k) {
-    if (k < e.lds_rows) return (int)e.lds[e.S(k, SR_BLK) * e.lds_stride];
-    return IEFC(e, k, 2);
 }
 
 // cost, forces, states at the current jar; qfrc_constraint = J' force; returns total cost incl. Gauss term
@@ -887,11 +894,6 @@ MW_HD void tri_load_as(const Env<T> e, int A, int n, HT* h) {
             h[tri(i, j)] = i < n ? (HT)v : (i == j ? HT(1) : HT(0));
         }
 }
-template <typename T, typename HT, int NV>
-MW_HD void jrow_load_as(const Env<T> e, int row, int nv, HT* j) {
-#pragma unroll
-    for (int k = 0; k < NV; k++) j[k] = (HT)EJ(e, row, k < nv ? k : 0);
-}
 
 // search direction s = -H^-1 g of one Newton iteration: reads -g from L.grad, writes s to L.search.
 // H = M + J' D J over quadratic rows (+ dense cone blocks): lower triangle in registers (a partial sum per sub-lane over its
@@ -997,16 +999,6 @@ MW_HD void solve_impl(const Env<T> e) {
     const int nv = e.nv, nefc = e.I(L.icount + 1), nblk = e.I(L.icount + IC_NBLK);
     constexpr int NT = NV * (NV + 1) / 2;
     MW_TICK(t_a)
-    MW_SUBS(e, sub) {   // stage the static row scalars and the block list into the scratchpad
-        for (int i = sub; i < nefc; i += e.nsub) {
-            if (i >= e.lds_rows) { EX(e, i, 7) = 0; continue; }
-            const T D = EX(e, i, 3), fri = EX(e, i, 8), info = EX(e, i, 9);
-            const int blk = IEFC(e, i, 2);
-            sr_set(e, i, SR_D, D); sr_set(e, i, SR_FRI, fri); sr_set(e, i, SR_INFO, info);
-            sr_set(e, i, SR_JV, T(0));   // read (times alpha = 0) before the first search direction exists
-            sr_set(e, i, SR_BLK, T(blk));
-        }
-    }
     auto set_point = [&](int src) {   // qacc <- src ; Ma, jar
         T x[NV];
         vec_load<T, NV>(e, src, nv, x);
@@ -1014,7 +1006,7 @@ MW_HD void solve_impl(const Env<T> e) {
         mat_vec_rows<T, NV>(e, L.qM, nv, x, L.Ma);
         MW_SUBS(e, sub) {
             for (int i = sub; i < nefc; i += e.nsub) {
-                T j[NV], s = -EX(e, i, 4);
+                T j[NV], s = -sr_get(e, i, SR_AREF);
                 jrow_load<T, NV>(e, i, nv, j);
 #pragma unroll
                 for (int k = 0; k < NV; k++) s += j[k] * x[k];
@@ -1132,6 +1124,12 @@ MW_HD void solve_impl(const Env<T> e) {
         if (scale * (old - cost) < m.tolerance) break;
     }
     MW_HIST(0, e.I(L.icount + 2))
+    // efc_force of the rows kept in the scratchpad -> efcX (read by touching_object and through the ABI); fallback rows already are there
+    MW_SUBS(e, sub) {
+        const int nl = nefc < e.lds_rows ? nefc : e.lds_rows;
+        for (int i = sub; i < nl; i += e.nsub) EX(e, i, 5) = e.lds[e.S(i, SR_FORCE) * e.lds_stride];
+    }
+    MW_SYNC();
 }
 
 template <typename T>
@@ -1145,6 +1143,18 @@ MW_STAGE_FN void solve(const Env<T> e_) {
         return;
     }
     MW_NV_DISPATCH(nv, (solve_impl<T, NVC>(e)))
+}
+
+// debugging / parity hooks only (lane_debug): copy the rows kept in the scratchpad into the column store (efcJ, efcX), where
+// mw_read finds them; the product path never does this
+template <typename T>
+MW_HD void mirror_rows(const Env<T> e) {
+    const int nefc = e.I(e.lay().icount + 1), nl = nefc < e.lds_rows ? nefc : e.lds_rows;
+    for (int i = 0; i < nl; i++) {
+        for (int k = 0; k < e.nv; k++) EJ(e, i, k) = e.lds[e.S(i, SR_N + k) * e.lds_stride];
+        for (int f = 0; f < SR_N; f++)
+            if (f != SR_BLK) EX(e, i, sr_slot(f)) = e.lds[e.S(i, f) * e.lds_stride];
+    }
 }
 
 // ------------------------------------------------------------------ pipeline

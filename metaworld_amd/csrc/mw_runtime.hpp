@@ -213,7 +213,7 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Scratchpad sp, Env<T
     const int lin = host ? thread : thread % lpb;
     const int lane = (block - G.block0) * lpb + lin;
     if (lane >= G.nenv) return false;
-    e->set_scratchpad(sp, thread, lpb);
+    e->set_scratchpad(sp, thread, lpb, G.m.sz.nv);
     // element i of this environment: chunk base + i * lpb + (lane in chunk) -- consecutive elements of a workgroup's
     // environments are adjacent in memory (a Jacobian row of 8 environments is a few cache lines, not one line per entry)
     const size_t chunk = (size_t)(block - G.block0);
@@ -389,6 +389,7 @@ MW_HD void lane_debug(const World<T>& w, int what, int n, int block, int thread,
             if (k >= 4) smooth_forces(e);
             if (k >= 5) solve(e);
         }
+    if (what == 0 || what == 1 || what >= 10) mirror_rows(e);   // the constraint rows of the last evaluation, for mw_read("efcJ" / "efcX")
 }
 
 // ------------------------------------------------------------------ host-side context

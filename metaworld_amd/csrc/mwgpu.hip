@@ -28,7 +28,7 @@ namespace {
 template <class F>
 __global__ void __launch_bounds__(64) k_lanes(F f, int block_words) {
     extern __shared__ float mw_scratchpad[];
-    f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, block_words, 0});
+    f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, block_words, 0, 0});
 }
 
 // one thread per environment, no scratchpad: the small per-env kernels around the step (scripted policies, accounting)

@@ -137,13 +137,14 @@ struct Backend {
     template <class F>
     static void launch(int nblocks, F f) {   // one call per environment (locate() rejects threads >= lanes per workgroup): the sub-lanes are emulated inside (MW_SUBS)
         const int rows = lds_rows(), ns = nsub();
-        const int words = rows * mw::SR_N * 2;   // SR_N doubles per row
+        const size_t slots = (size_t)rows * (mw::SR_N + mw::MAX_NV);   // room for `rows` rows of the widest scene; Scratchpad::max_rows caps narrower ones
+        const int words = (int)slots * 2;
 #pragma omp parallel
         {
-            std::vector<double> pad((size_t)rows * mw::SR_N + 1, std::nan(""));   // LDS is not zero-initialised either
+            std::vector<double> pad(slots + 1, std::nan(""));   // LDS is not zero-initialised either
 #pragma omp for schedule(dynamic)
             for (int b = 0; b < nblocks; b++)
-                for (int t = 0; t < 64; t++) f(b, t, mw::Scratchpad{pad.data(), words, ns});
+                for (int t = 0; t < 64; t++) f(b, t, mw::Scratchpad{pad.data(), words, ns, rows});
         }
     }
     template <class F>
