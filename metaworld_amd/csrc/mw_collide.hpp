@@ -898,17 +898,49 @@ MW_STAGE_FN void collision(const Env<T> e_) {
     } else {
         int ncand = 0;
         MW_CTICK(tc0)
-        for (int p0 = 0; p0 < npair; p0 += e.nsub) {
-            int f[MW_NSLOT], foff[MW_NSLOT];
+        // broad + mid phase, MID_BATCH pairs per sub-lane and trip: the loads of a batch (pair -> geoms -> positions, bounds) are
+        // issued together, so a sub-lane pays the two dependent round trips once per batch instead of once per pair; the
+        // candidate list is written in pair order (batch slot q covers pairs p0 + q * nsub + sub)
+        constexpr int MID_BATCH = 4;
+        for (int p0 = 0; p0 < npair; p0 += MID_BATCH * e.nsub) {
+            int f[MID_BATCH][MW_NSLOT], foff[MW_NSLOT];
             MW_SUBS(e, sub) {
-                const int p = p0 + sub;
-                f[MW_SLOT(sub)] = (p < npair && pair_near(e, p)) ? 1 : 0;
+                int g1[MID_BATCH], g2[MID_BATCH];
+                bool ok[MID_BATCH], plane[MID_BATCH];
+                T margin[MID_BATCH];
+#pragma unroll
+                for (int q = 0; q < MID_BATCH; q++) {
+                    const int p = p0 + q * e.nsub + sub;
+                    ok[q] = p < npair;
+                    g1[q] = m.pair_geom[2 * (ok[q] ? p : 0)]; g2[q] = m.pair_geom[2 * (ok[q] ? p : 0) + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < MID_BATCH; q++) {
+                    margin[q] = mw_max(m.geom_margin[g1[q]], m.geom_margin[g2[q]]);
+                    plane[q] = m.geom_type[g1[q]] == G_PLANE;
+                    const V3<T> p1 = ld3(e, L.geom_xpos + 3 * g1[q]), p2 = ld3(e, L.geom_xpos + 3 * g2[q]);
+                    if (!plane[q]) {
+                        const T bound = m.geom_rbound[g1[q]] + m.geom_rbound[g2[q]] + margin[q];
+                        const V3<T> t = p1 - p2;
+                        ok[q] = ok[q] && dot(t, t) <= bound * bound;
+                    } else {
+                        const V3<T> nn{e.R(L.geom_xmat + 9 * g1[q] + 2), e.R(L.geom_xmat + 9 * g1[q] + 5), e.R(L.geom_xmat + 9 * g1[q] + 8)};
+                        ok[q] = ok[q] && dot(p2 - p1, nn) <= m.geom_rbound[g2[q]] + margin[q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < MID_BATCH; q++) {
+                    if (ok[q] && !plane[q]) ok[q] = obb_overlap(e, g1[q], g2[q], margin[q]);
+                    f[q][MW_SLOT(sub)] = ok[q] ? 1 : 0;
+                }
             }
-            const int tot = sub_scan(e, f, foff);
-            MW_SUBS(e, sub) {
-                if (f[MW_SLOT(sub)]) e.I(L.ipair + ncand + foff[MW_SLOT(sub)]) = p0 + sub;
+            for (int q = 0; q < MID_BATCH; q++) {
+                const int tot = sub_scan(e, f[q], foff);
+                MW_SUBS(e, sub) {
+                    if (f[q][MW_SLOT(sub)]) e.I(L.ipair + ncand + foff[MW_SLOT(sub)]) = p0 + q * e.nsub + sub;
+                }
+                ncand += tot;
             }
-            ncand += tot;
         }
         MW_SYNC();
         MW_CTICK(tc1)
