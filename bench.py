@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 # (200 B) = 1.1 KB; fp64: 1.6 KB + the one-hot as float64 (400 B) = 2.0 KB.  Without one-hot (MT1): 0.9 / 1.6 KB.
 ALGO_BYTES_PER_ENV_STEP = {("fp32", True): 1100.0, ("fp64", True): 2000.0, ("fp32", False): 900.0, ("fp64", False): 1600.0}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md
-N_SIMD, F_CLK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 2 cycles
+N_SIMD, F_CLK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs of 16 lanes; a wave64 VALU instruction occupies its SIMD for 4 cycles
 HORIZON = 500                   # SawyerXYZEnv.max_path_length (sawyer_xyz_env.py:153) = TimeLimit default
 
 
@@ -279,26 +279,42 @@ def main(argv=None):
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                     "traffic": None, "kernel_ms_per_launch": kernel_ms / args.steps, "algorithmic_bytes_per_env_step": algo,
                     "note": "achieved = algorithmic bytes/env-step x envs / HIP-event kernel time (events on the library's own stream); "
-                            "traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of the committed rocprofv3 PMC profile of this command; "
+                            "traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of the committed rocprofv3 PMC profile of this command on the same sources; "
                             "the step kernel is bound by the latency of its per-environment dependency chain, not by HBM (DESIGN.md 5): "
                             "see alu_issue"}
-        prof = os.path.join(ROOT, "profiles", f"r02_mt50_{args.precision}_pmc.json")
-        if os.path.exists(prof) and world == 1:
+        # counter-derived numbers are quoted only from a profile of THESE device sources (tools/profile_bench.sh writes the content
+        # hash of csrc/ into the summary): a stale profile gives traffic = null instead of another kernel's counters
+        from metaworld_amd import native as _native
+        src_hash = _native.source_hash()
+        roofline["source_hash"] = src_hash
+        pj = None
+        import glob
+        for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_mt50_{args.precision}_pmc.json")), reverse=True):
             with open(prof) as f:
-                pj = json.load(f)
-            if pj.get("workload") == workload:
+                cand = json.load(f)
+            if cand.get("workload") == workload and cand.get("source_hash") == src_hash:
+                pj = cand
+                roofline["profile"] = os.path.relpath(prof, ROOT)
+                break
+        if pj is None:
+            roofline["note"] += "; NO committed PMC profile matches these sources (source_hash): traffic / alu_issue not quoted"
+        if pj is not None and world == 1:
                 roofline["traffic"] = pj["fetch_bytes_per_launch"] + pj["write_bytes_per_launch"]
-                # the bound that actually moves: VALU issue.  A wave64 VALU instruction holds its SIMD for 2
-                # cycles, so the chip issues N_SIMD x f_clk / 2 wave-instructions per second at most.
+                # the bound that actually moves: VALU issue.  The SIMD is 16 lanes wide: a wave64 VALU instruction
+                # occupies it for 4 cycles (fp64 and unpacked fp32 alike; 78.6 TFLOP/s fp64 = 1024 SIMDs x 16 lanes x 2 x 2.4 GHz),
+                # so the chip issues at most N_SIMD x f_clk / 4 such wave-instructions per second.
                 valu = pj["valu_wave_instr_per_launch"]
-                slots = N_SIMD * F_CLK_HZ / 2
+                slots = N_SIMD * F_CLK_HZ / 4
                 roofline["alu_issue"] = {
                     "valu_wave_instr_per_env_step": valu / N, "achieved_wave_instr_per_s": valu / per_launch_s,
                     "peak_wave_instr_per_s": slots, "frac": valu / per_launch_s / slots,
+                    "valu_f64_share": (pj["valu_f64_wave_instr_per_launch"] / valu) if pj.get("valu_f64_wave_instr_per_launch") else None,
+                    "valu_active_frac_of_wave_cycles": pj.get("valu_active_frac"),
                     "lane_utilisation": pj.get("lane_utilisation"), "wave_slot_occupancy": pj.get("wave_slot_occupancy"),
                     "wait_frac": pj.get("wait_frac"),
-                    "note": "VALU wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU) / this run's kernel time vs "
-                            "1024 SIMDs x 2.4 GHz / 2; lane_utilisation = envs x sub-lanes doing distinct work / (waves x 64); "
+                    "note": "VALU wave-instructions per launch from the PMC pass of the same sources (SQ_INSTS_VALU) / this run's kernel time vs "
+                            "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; valu_f64_share = SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 / SQ_INSTS_VALU; "
+                            "valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; lane_utilisation = envs / (waves x 64); "
                             "wave_slot_occupancy = SQ_WAVE_CYCLES x 4 / (1024 SIMDs x kernel cycles); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
         out = {"metric": "env-steps/sec (whole node) MT50 @4096 envs/GPU; achieved HBM GB/s vs peak", "value": value,
                "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -309,6 +325,7 @@ def main(argv=None):
                           f"staggered uniformly over the {HORIZON}-step horizon (mw_set_episode_phase + untimed {HORIZON}-step pre-roll): "
                           "every window samples whole episodes incl. auto-resets",
                           "parallelism": f"dp{world} (independent env shards, no data-path collective)", "bookkeeping_gather": gather_mode,
+                          "comm": env.ctx.comm_info(),
                           "status_flags": status},
                "roofline": roofline}
         if world == 1 and not args.no_extra_precision and on_gpu:

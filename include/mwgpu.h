@@ -146,6 +146,10 @@ typedef struct mw_bookkeeping {
 } mw_bookkeeping;
 int mw_comm_unique_id(uint8_t* id_out /*[128] ncclUniqueId, created on the calling rank*/);
 int mw_comm_init(mw_ctx* c, const uint8_t* id /*[128], the same bytes on every rank*/, int rank, int world_size);
+/* what the collective library reports for the context's communicator: info[0] = ranks in it (ncclCommCount), info[1] = this rank
+ * (ncclCommUserRank), info[2] = 1 if a RCCL communicator exists (0: world size 1, the "gather" is a device copy), info[3] = HIP
+ * device of the context.  bench.py prints it in `config`, so that a multi-GPU run shows that RCCL saw N ranks. */
+int mw_comm_info(mw_ctx* c, int32_t* info /*[4]*/);
 /* all-gather the records of the LAST step; out = [world_size][N] records, a HOST pointer (out_on_device = 0) or a DEVICE
  * pointer (1); NULL keeps the result in the context's own device buffer.  world_size 1 needs no communicator. */
 int mw_gather_bookkeeping(mw_ctx* c, mw_bookkeeping* out, int out_on_device);

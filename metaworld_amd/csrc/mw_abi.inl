@@ -125,6 +125,7 @@ int MW_API(comm_unique_id)(uint8_t* id_out) {
 int MW_API(comm_init)(mw_ctx* c, const uint8_t* id, int rank, int world) {
     MW_TRY(c, { MW_NEED_IMPL(c); if (world > 1 && !id) throw std::invalid_argument("comm_init: id is required when world_size > 1"); c->impl->comm_init(id, rank, world); });
 }
+int MW_API(comm_info)(mw_ctx* c, int32_t* out) { MW_TRY(c, { MW_NEED_IMPL(c); if (!out) throw std::invalid_argument("comm_info: null output"); c->impl->comm_info(out); }); }
 int MW_API(gather_bookkeeping)(mw_ctx* c, mw_bookkeeping* out, int out_on_device) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->gather_bookkeeping(out, out_on_device); }); }
 int MW_API(set_episode_phase)(mw_ctx* c, const int32_t* elapsed) { MW_TRY(c, { MW_NEED_IMPL(c); if (!elapsed) throw std::invalid_argument("set_episode_phase: null argument"); c->impl->set_episode_phase(elapsed); }); }
 int MW_API(status)(mw_ctx* c, int32_t* out, int clear) { MW_TRY(c, { MW_NEED_IMPL(c); if (!out) throw std::invalid_argument("status: null output"); c->impl->status(out, clear); }); }

@@ -425,6 +425,7 @@ public:
     virtual void upload_actions(const float* act, int nsteps) = 0;
     virtual void step_resident_gather(int nsteps, int act_stride_steps, float* kernel_ms) = 0;
     virtual void comm_init(const void* id128, int rank, int world) = 0;
+    virtual void comm_info(int* out /*[4]*/) = 0;
     virtual void gather_bookkeeping(mw_bookkeeping* out, int out_on_device) = 0;
     virtual void status(int* out /*[MW_STATUS_WORDS]*/, int clear) = 0;
     virtual void set_episode_phase(const int* elapsed) = 0;
@@ -943,13 +944,16 @@ public:
     void comm_init(const void* id128, int rank, int world) override {
         if (world < 1 || rank < 0 || rank >= world) throw std::invalid_argument("comm_init: bad rank / world size");
         Backend::comm_free(comm_); comm_ = nullptr;
-        if (world > 1) comm_ = Backend::comm_init(id128, rank, world);
+        // world size 1 needs no communicator (the gather is a device copy); MW_COMM_FORCE_RCCL=1 creates a one-rank RCCL communicator
+        // anyway, so that ncclCommInitRank / ncclAllGather run on a single-GPU box (tests/test_gpu_fullsize.py)
+        if (world > 1 || (id128 && getenv("MW_COMM_FORCE_RCCL"))) comm_ = Backend::comm_init(id128, rank, world);
         Backend::free(d_book_all_);
         d_book_all_ = (mw_bookkeeping*)Backend::alloc(sizeof(mw_bookkeeping) * 2 * (size_t)world * N_);
         Backend::zero(d_book_all_, sizeof(mw_bookkeeping) * 2 * (size_t)world * N_);
         Backend::sync();
         cfg.rank = rank; cfg.world_size = world;
     }
+    void comm_info(int* out) override { Backend::comm_info(comm_, out); }
     mw_bookkeeping* gathered() const { return d_book_all_ + (size_t)book_slot_ * world_size() * N_; }
     void gather_async() {          // records of the step just queued on the main stream -> every rank, on the side stream
         const mw_bookkeeping* src = d_book_ + (size_t)book_slot_ * N_;

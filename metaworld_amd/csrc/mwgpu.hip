@@ -46,6 +46,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     static Rccl& get() {
         static Rccl r;
@@ -58,6 +60,8 @@ struct Rccl {
             r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
             r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
             r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+            r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+            r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
             r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
         }
         return r;
@@ -156,7 +160,7 @@ struct Backend {
     }
     // ---- cross-rank exchange (RCCL over xGMI): one communicator per context, collectives on the device's SIDE stream so
     //      that the gather of step k overlaps the kernel of step k+1 ----
-    struct Comm { ncclComm_t comm = nullptr; int rank = 0, world = 1; };
+    struct Comm { ncclComm_t comm = nullptr; int rank = 0, world = 1, count_seen = 0, rank_seen = -1; };
     static void comm_unique_id(void* out128) {
         ncclUniqueId id;
         Rccl& r = Rccl::get();
@@ -171,7 +175,16 @@ struct Backend {
         Comm* c = new Comm();
         c->rank = rank; c->world = world;
         r.check(r.CommInitRank(&c->comm, world, id, rank), "ncclCommInitRank");
+        // what RCCL itself reports for the new communicator (mw_comm_info): proof that it spans `world` ranks
+        r.check(r.CommCount(c->comm, &c->count_seen), "ncclCommCount");
+        r.check(r.CommUserRank(c->comm, &c->rank_seen), "ncclCommUserRank");
+        if (getenv("MW_VERBOSE")) fprintf(stderr, "[mwgpu] RCCL communicator: ncclCommCount = %d, ncclCommUserRank = %d (asked for world %d, rank %d)\n", c->count_seen, c->rank_seen, world, rank);
         return c;
+    }
+    // [0] ranks in the communicator as the collective library reports them (ncclCommCount), [1] this rank (ncclCommUserRank),
+    // [2] 1 = a real RCCL communicator, 0 = none (world size 1: the gather is a device copy), [3] HIP device of the context
+    static void comm_info(const Comm* c, int* out) {
+        out[0] = c ? c->count_seen : 1; out[1] = c ? c->rank_seen : 0; out[2] = c ? 1 : 0; out[3] = cur();
     }
     static void comm_free(Comm* c) { if (c) { if (c->comm) (void)Rccl::get().CommDestroy(c->comm); delete c; } }
     // side stream waits for everything queued on the main stream so far, then all-gathers `bytes` per rank; the "gather done"

@@ -18,6 +18,19 @@ NPROBE = 16
 STATUS_WORDS = 8          # MW_STATUS_WORDS (include/mwgpu.h)
 
 
+def source_hash():
+    """sha256 over the device sources (csrc/*, include/mwgpu.h): written into every profile summary (tools/summarize_pmc.py) and
+    compared by bench.py, which only quotes counter-derived numbers (roofline.traffic / alu_issue) of a profile taken on the SAME
+    sources (the .git directory does not travel to the GPU box, so this is a content hash, not a commit id)"""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    for f in sorted(os.listdir(src)) + [os.path.join("..", "..", "include", "mwgpu.h")]:
+        with open(os.path.join(src, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 class MwConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("precision", "device_id", "rank", "world_size", "max_episode_steps",
                                          "terminate_on_success", "one_hot", "num_tasks", "full_forward")]
@@ -87,6 +100,7 @@ class Lib:
         f("step_resident_gather", C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float))
         f("comm_unique_id", C.c_int, C.c_void_p)
         f("comm_init", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+        f("comm_info", C.c_int, C.c_void_p, C.c_void_p)
         f("gather_bookkeeping", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
         f("status", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
         f("set_episode_phase", C.c_int, C.c_void_p, C.c_void_p)
@@ -118,7 +132,7 @@ def load(prefix="mw_", path=None) -> Lib:
 
 EXPORTED_SYMBOLS = ["model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
                     "add_model", "add_task", "set_envs", "finalize", "set_terminate_on_success", "destroy", "last_error", "num_envs", "obs_dim",
-                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "upload_actions", "step_resident", "step_resident_gather", "comm_unique_id", "comm_init", "gather_bookkeeping", "status", "set_episode_phase", "column_size", "read", "write", "read_int",
+                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "upload_actions", "step_resident", "step_resident_gather", "comm_unique_id", "comm_init", "comm_info", "gather_bookkeeping", "status", "set_episode_phase", "column_size", "read", "write", "read_int",
                     "debug"]
 
 
@@ -230,6 +244,12 @@ class Context:
         if self.lib.comm_unique_id(buf.ctypes.data) != 0:
             raise RuntimeError("mwgpu: cannot create a communicator id (is RCCL loadable?)")
         return buf
+
+    def comm_info(self):
+        """mw_comm_info: what the collective library itself reports for this context's communicator"""
+        out = np.zeros(4, dtype=np.int32)
+        self._check(self.lib.comm_info(self.ptr, out.ctypes.data))
+        return {"comm_count": int(out[0]), "comm_rank": int(out[1]), "rccl": bool(out[2]), "device": int(out[3])}
 
     def comm_init(self, unique_id, rank, world_size):
         uid = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)

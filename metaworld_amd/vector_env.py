@@ -74,8 +74,34 @@ class _RunningMeanStd:
         self.count[i] += 1
 
 
-class MetaWorldGpuVectorEnv:
-    metadata = {"autoreset_mode": "SameStep", "render_modes": []}
+def _vector_env_base():
+    """gymnasium.vector.VectorEnv when gymnasium is importable -- `gym.make_vec("Meta-World/MT50")` (metaworld/__init__.py:707-722),
+    vector wrappers and `isinstance` checks then see a real VectorEnv --, a plain object otherwise (this container, the GPU box);
+    the class below defines every attribute of the base itself, so both spellings behave alike."""
+    try:
+        from gymnasium.vector import VectorEnv  # type: ignore
+        return VectorEnv
+    except Exception:
+        return object
+
+
+def _autoreset_same_step():
+    try:
+        from gymnasium.vector import AutoresetMode  # type: ignore
+        return AutoresetMode.SAME_STEP
+    except Exception:
+        return "SameStep"
+
+
+class MetaWorldGpuVectorEnv(_vector_env_base()):
+    # gymnasium.vector.VectorEnv's class attributes (gymnasium 1.1, vector/vector_env.py): make_vec writes `env.unwrapped.spec`,
+    # vector wrappers read `metadata["autoreset_mode"]`, `render_mode`, `closed`, `np_random`
+    metadata = {"autoreset_mode": _autoreset_same_step(), "render_modes": []}
+    spec = None
+    render_mode = None
+    closed = False
+    _np_random = None
+    _np_random_seed = None
 
     def __init__(self, benchmark="MT1", env_name=None, num_envs=None, seed=None, use_one_hot=False,
                  max_episode_steps=None, terminate_on_success=False, precision="fp64", device_id=0,
@@ -494,10 +520,43 @@ class MetaWorldGpuVectorEnv:
         done = (c.terminated | c.truncated).astype(np.float64)
         return np.stack([done, c.success.astype(np.float64), tid, c.ep_ret * done, c.ep_len * done], axis=1)
 
-    def close(self):
+    # ---- the rest of gymnasium.vector.VectorEnv's surface ----
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def np_random(self):
+        """gymnasium's lazily created generator (seeded by reset(seed=...) there; the reference's reset drops the seed, so this
+        one is seeded from the construction seed and never drives the task selection: `_draw` / `_shuffle_perm` do)"""
+        if self._np_random is None:
+            self._np_random_seed = self.seed_value
+            self._np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(self.seed_value)))
+        return self._np_random
+
+    @np_random.setter
+    def np_random(self, value):
+        self._np_random, self._np_random_seed = value, -1
+
+    @property
+    def np_random_seed(self):
+        if self._np_random is None:
+            self.np_random  # noqa: B018  (creates it)
+        return self._np_random_seed
+
+    def render(self):
+        return None          # render_modes = []: the batched env has no renderer (SURVEY.md 2, out of scope)
+
+    def close_extras(self, **kwargs):
+        self.ctx.close()
+
+    def close(self, **kwargs):
         if not self.closed:
-            self.ctx.close()
+            self.close_extras(**kwargs)
             self.closed = True
+
+    def __repr__(self):
+        return f"MetaWorldGpuVectorEnv({self.task_list[0] if len(self.task_list) == 1 else str(len(self.task_list)) + ' tasks'}, num_envs={self.num_envs})"
 
 
 def gather_bookkeeping(local: np.ndarray, device=None):

@@ -545,7 +545,12 @@ def _make_gymnasium(mujoco_mod):
         if spec["vector_entry_point"] is None:
             raise NotImplementedError("the gymnasium stand-in only builds specs that have a vector_entry_point")
         kw = dict(spec["kwargs"]); kw.update(kwargs)
-        return spec["vector_entry_point"](num_envs=num_envs, **kw)
+        env = spec["vector_entry_point"](num_envs=num_envs, **kw)
+        # what gymnasium 1.1's make_vec does with the object it gets back (envs/registration.py): the spec is written through
+        # `unwrapped`, and a vector env without an autoreset mode in its metadata draws a warning
+        env.unwrapped.spec = types.SimpleNamespace(id=id, kwargs=kw, vector_entry_point=spec["vector_entry_point"])
+        assert "autoreset_mode" in env.metadata, "vector env without metadata['autoreset_mode']"
+        return env
 
     registration.register = _register
     envs.registration = registration

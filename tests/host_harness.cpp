@@ -53,6 +53,7 @@ struct Backend {
         if (c->base == (char*)MAP_FAILED) throw std::runtime_error("host harness: mmap failed");
         return c;          // a fresh segment is zero-filled: count = gen = 0
     }
+    static void comm_info(const Comm* c, int* out) { out[0] = c ? c->world : 1; out[1] = c ? c->rank : 0; out[2] = 0; out[3] = -1; }   // (no RCCL in the harness)
     static void comm_free(Comm* c) {
         if (!c) return;
         if (c->base) munmap(c->base, sizeof(Shm) + c->cap * c->world);

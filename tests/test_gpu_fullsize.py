@@ -137,8 +137,9 @@ def test_bench_states_match_the_oracle(gpulib, bench_name, n):
     env.close()
 
 
-def test_fullsize_gather_and_status_through_the_abi(gpulib):
-    """MT50 @ 4096: the per-step bookkeeping record of the resident loop (world size 1: no communicator needed) and the status word"""
+def test_fullsize_gather_and_status_through_the_abi(gpulib, monkeypatch):
+    """MT50 @ 4096: the per-step bookkeeping record of the resident loop (world size 1: no communicator needed) and the status word;
+    then the same loop over a REAL one-rank RCCL communicator (ncclCommInitRank + ncclAllGather on the side stream)"""
     from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
     env = MetaWorldGpuVectorEnv("MT50", num_envs=4096, seed=1, use_one_hot=True, precision="fp32", lib=gpulib, max_episode_steps=25)
     env.reset()
@@ -149,11 +150,25 @@ def test_fullsize_gather_and_status_through_the_abi(gpulib):
     ids = np.array([T.TASK_CONST[n]["id"] for n in env.env_task_names])
     assert (book["task_id"][0] == ids).all() and np.isfinite(book["episode_return"]).all() and (book["episode_return"] >= 0).all()
     assert env.status()["flags"] == 0
-    # an RCCL communicator of one rank works too (the driver's 1-GPU box): same records
+    assert env.ctx.comm_info()["rccl"] is False
+    # world size 1 through mw_comm_init: still no communicator (device copy), same records
     env.ctx.comm_init(env.ctx.comm_unique_id(), 0, 1)
     env.ctx.step_resident_gather(3)
     b2 = env.ctx.gather_bookkeeping()
     assert (b2["episode_length"] == 3).all() and (b2["done"] == 0).all()
+    # a REAL RCCL communicator of one rank (MW_COMM_FORCE_RCCL): ncclCommInitRank, then ncclAllGather per step on the side stream
+    # with the gather-done back-edge, checked against the records of the plain loop continued from the same state
+    monkeypatch.setenv("MW_COMM_FORCE_RCCL", "1")
+    env.ctx.comm_init(env.ctx.comm_unique_id(), 0, 1)
+    info = env.ctx.comm_info()
+    assert info["rccl"] is True and info["comm_count"] == 1 and info["comm_rank"] == 0, info
+    env.ctx.step_resident_gather(5)
+    b3 = env.ctx.gather_bookkeeping()
+    assert b3.shape == (1, 4096) and (b3["episode_length"] == 8).all() and (b3["done"] == 0).all() and (b3["task_id"][0] == ids).all()
+    env.ctx.step_resident_gather(17)                       # ... to the end of the 25-step episode: every env done in the gathered record
+    b4 = env.ctx.gather_bookkeeping()
+    assert (b4["done"] == 1).all() and (b4["episode_length"] == 25).all() and np.isfinite(b4["episode_return"]).all()
+    assert env.status()["flags"] == 0
     env.close()
 
 

@@ -13,7 +13,7 @@ from tests.helpers import ROOT, make_env, replay_trace
 
 DIR = os.path.join(ROOT, "tests", "golden_mujoco")
 HAVE = sorted(glob.glob(os.path.join(DIR, "trace_*_seed42.npz")))
-needs_traces = pytest.mark.skipif(not HAVE, reason="no MuJoCo traces recorded (run tools/dump_reference_traces.py where mujoco installs)")
+needs_traces = pytest.mark.skipif(not HAVE, reason="no MuJoCo traces recorded: run `pip install -r tools/pin/requirements.txt && bash tools/pin/run_pin.sh` where the mujoco wheel installs")
 
 
 def test_dump_tool_reports_the_missing_stack_instead_of_faking_it():

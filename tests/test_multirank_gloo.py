@@ -29,6 +29,8 @@ def _worker(rank, world, port, lib_path, out_dir):
     uid = torch.from_numpy(env.ctx.comm_unique_id()) if rank == 0 else torch.zeros(128, dtype=torch.uint8)
     dist.broadcast(uid, 0)
     env.ctx.comm_init(uid.numpy(), rank, world)
+    info = env.ctx.comm_info()                        # mw_comm_info: the communicator as the collective layer itself reports it
+    assert info["comm_count"] == world and info["comm_rank"] == rank, info
     env.reset()
     rng = np.random.default_rng(100 + rank)          # different actions per shard
     for _ in range(3):
@@ -78,6 +80,7 @@ def test_bench_launcher_spawns_one_rank_per_gpu():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
     assert out["config"]["envs_per_gpu"] == 8 and "all-gather" in out["config"]["bookkeeping_gather"]
+    assert out["config"]["comm"]["comm_count"] == 2 and out["config"]["comm"]["comm_rank"] == 0
     assert out["value"] > 0 and abs(out["value"] - 2 * 8 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
 
 

@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden_mujoco"))
     ap.add_argument("--gate", action="store_true", help="also run the >= 0.8 scripted-policy gate per task (slow)")
+    ap.add_argument("--first", default=None, help="task to record (and gate) first, e.g. basketball-v3 (tools/pin/run_pin.sh)")
     args = ap.parse_args()
     ok, why = real_stack_available()
     if not ok:
@@ -78,13 +79,17 @@ def main():
     from tools.gen_golden import run_task          # same recorder, real engine underneath
     from metaworld_amd import tasks as T
     os.makedirs(args.out, exist_ok=True)
-    for name in args.tasks or T.ALL_V3:
+    names = list(args.tasks or T.ALL_V3)
+    if args.first in names:
+        names.remove(args.first)
+        names.insert(0, args.first)
+    for name in names:
         rng = np.random.default_rng(args.seed)
         res = run_task(name, args.seed, args.episodes, args.steps, "mixed", rng)
         path = os.path.join(args.out, f"trace_{name}_seed{args.seed}.npz")
         np.savez_compressed(path, **res)
-        line = f"{name:32s} -> {path} success steps {int(res['success'].sum())}"
-        if args.gate:
+        line = f"trace {name:32s} -> {path} success steps {int(res['success'].sum())}"
+        if args.gate or name == args.first:
             line += f"  scripted-policy gate {policy_gate(name, args.seed):.2f}"
         print(line, flush=True)
     return 0

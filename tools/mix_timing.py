@@ -45,6 +45,8 @@ for t in env.task_list:
     m = tn == t
     ph = d[m][:, :6].mean(0)
     print(f"{t:30s} " + " ".join(f"{v:6.0f}" for v in ph) + f" | {cnt[m][:, 0].mean():5.1f} {cnt[m][:, 1].mean():5.1f} | {ic1[m][:, 0].mean():5.1f} {ic1[m][:, 1].mean():5.1f}")
+if os.environ.get("MW_MIX_NPZ"):          # raw per-env numbers for offline analysis (wave-time distribution, load balance)
+    np.savez_compressed(os.environ["MW_MIX_NPZ"], d=d, task=tn, ms=ms, ncon=ic1[:, 0], nefc=ic1[:, 1], names=np.array(names))
 if os.environ.get("MW_MIX_JSON"):
     import json
     json.dump({t: dict(max_kcyc=float(tot[tn == t].max()), mean_kcyc=float(tot[tn == t].mean())) for t in env.task_list}, open(os.environ["MW_MIX_JSON"], "w"), indent=1)

@@ -3,7 +3,7 @@
 #   kernel-trace stats (its own pass) + separate PMC passes, all CSV under gpurun_out/prof_<tag>/
 # usage: tools/profile_bench.sh <tag> [bench args...]      (the bench runs with --no-cpu-baseline --no-extra-precision)
 set -u
-tag=${1:-r02}; shift || true
+tag=${1:-r03}; shift || true
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
@@ -13,7 +13,8 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python $root/bench.py $args > "$out/kt.log" 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" \
-           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_LDS TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32"; do
   name=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --output-format csv -d "$out/pmc_$name" -- python $root/bench.py $args > "$out/pmc_$name.log" 2>&1
 done

@@ -8,6 +8,11 @@ import collections
 import csv
 import glob
 import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from metaworld_amd import native  # noqa: E402  (source_hash: which sources the profile belongs to)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("pattern", nargs="?", default="gpurun_out/pmc_*/**/*counter_collection.csv")
@@ -41,7 +46,11 @@ if meta:
     print("  launch:", meta)
 if args.json and mean:
     waves = mean.get("SQ_WAVES", 0.0)
-    out = {"workload": args.workload, "kernel": args.kernel, "launch": meta,
+    f64 = sum(mean.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+    out = {"workload": args.workload, "kernel": args.kernel, "launch": meta, "source_hash": native.source_hash(),
+           "valu_f64_wave_instr_per_launch": f64 if any(k.endswith("_F64") for k in mean) else None,
+           "valu_active_frac": mean.get("SQ_ACTIVE_INST_VALU", 0.0) / mean["SQ_WAVE_CYCLES"] if mean.get("SQ_ACTIVE_INST_VALU") and mean.get("SQ_WAVE_CYCLES") else None,
+           "busy_cycles_frac": mean.get("SQ_BUSY_CYCLES", 0.0) / mean["GRBM_GUI_ACTIVE"] if mean.get("SQ_BUSY_CYCLES") and mean.get("GRBM_GUI_ACTIVE") else None,
            "fetch_bytes_per_launch": mean.get("FETCH_SIZE", 0.0) * 1024, "write_bytes_per_launch": mean.get("WRITE_SIZE", 0.0) * 1024,
            "valu_wave_instr_per_launch": mean.get("SQ_INSTS_VALU", 0.0), "salu_wave_instr_per_launch": mean.get("SQ_INSTS_SALU", 0.0),
            "vmem_rd_wave_instr_per_launch": mean.get("SQ_INSTS_VMEM_RD", 0.0), "vmem_wr_wave_instr_per_launch": mean.get("SQ_INSTS_VMEM_WR", 0.0),
