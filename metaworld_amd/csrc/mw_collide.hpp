@@ -393,8 +393,10 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
         pl = v3(dl.x >= -tie ? s.size[0] : -s.size[0], dl.y >= -tie ? s.size[1] : -s.size[1], dl.z >= -tie ? s.size[2] : -s.size[2]);
         break;
     case G_MESH: {
-        int best = 0;
         T bd = T(-1e30);
+        // (the coordinates of the best vertex so far travel with its index: they were loaded to compute its dot product, and
+        //  fetching them again at the end was one more dependent memory round trip per support call)
+        T bx = 0, by = 0, bz = 0;
         if (s.hill) {
             MW_COUNT(3)
             // steepest-ascent walk over the hull graph (MuJoCo's mesh-graph support): from the previous result on this
@@ -406,11 +408,13 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
             // neighbours go on through the adjacency lists.  Same comparisons in the same order as a walk over the lists.
             const int cell = hill_cell(dl.x, dl.y, dl.z);
             int cur = s.start[cell];
-            bd = s.startxyz[3 * cell] * dl.x + s.startxyz[3 * cell + 1] * dl.y + s.startxyz[3 * cell + 2] * dl.z;
+            bx = s.startxyz[3 * cell]; by = s.startxyz[3 * cell + 1]; bz = s.startxyz[3 * cell + 2];
+            bd = bx * dl.x + by * dl.y + bz * dl.z;
             if (s.hint >= 0) {
                 const int hv = s.hint;
-                const T hd = s.vert[3 * hv] * dl.x + s.vert[3 * hv + 1] * dl.y + s.vert[3 * hv + 2] * dl.z;
-                if (hd > bd) { bd = hd; cur = hv; }
+                const T hx = s.vert[3 * hv], hy = s.vert[3 * hv + 1], hz = s.vert[3 * hv + 2];
+                const T hd = hx * dl.x + hy * dl.y + hz * dl.z;
+                if (hd > bd) { bd = hd; cur = hv; bx = hx; by = hy; bz = hz; }
             }
             for (int it = 0; it < s.nvert; it++) {
                 MW_COUNT(4)
@@ -419,47 +423,54 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
                 const int j0 = s.nbradr[cur], j1 = s.nbradr[cur + 1];
                 {
                     int id[8];
-                    T dd[8];
+                    T xx[8], yy[8], zz[8], dd[8];
 #pragma unroll
                     for (int q = 0; q < 8; q++) id[q] = s.nb8[8 * cur + q];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) dd[q] = s.nb8xyz[24 * cur + 3 * q] * dl.x + s.nb8xyz[24 * cur + 3 * q + 1] * dl.y + s.nb8xyz[24 * cur + 3 * q + 2] * dl.z;
+                    for (int q = 0; q < 8; q++) {
+                        xx[q] = s.nb8xyz[24 * cur + 3 * q]; yy[q] = s.nb8xyz[24 * cur + 3 * q + 1]; zz[q] = s.nb8xyz[24 * cur + 3 * q + 2];
+                        dd[q] = xx[q] * dl.x + yy[q] * dl.y + zz[q] * dl.z;
+                    }
 #pragma unroll
                     for (int q = 0; q < 8; q++)
-                        if (j0 + q < j1 && dd[q] > bd) { bd = dd[q]; nxt = id[q]; }
+                        if (j0 + q < j1 && dd[q] > bd) { bd = dd[q]; nxt = id[q]; bx = xx[q]; by = yy[q]; bz = zz[q]; }
                 }
                 for (int jb = j0 + 8; jb < j1; jb += 8) {        // further neighbours in batches of 8: ids, then coordinates, issued together
                     int id[8];
-                    T dd[8];
+                    T xx[8], yy[8], zz[8], dd[8];
 #pragma unroll
                     for (int q = 0; q < 8; q++) id[q] = s.nbr[jb + q < j1 ? jb + q : j1 - 1];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) dd[q] = s.vert[3 * id[q]] * dl.x + s.vert[3 * id[q] + 1] * dl.y + s.vert[3 * id[q] + 2] * dl.z;
+                    for (int q = 0; q < 8; q++) {
+                        xx[q] = s.vert[3 * id[q]]; yy[q] = s.vert[3 * id[q] + 1]; zz[q] = s.vert[3 * id[q] + 2];
+                        dd[q] = xx[q] * dl.x + yy[q] * dl.y + zz[q] * dl.z;
+                    }
 #pragma unroll
                     for (int q = 0; q < 8; q++)
-                        if (jb + q < j1 && dd[q] > bd) { bd = dd[q]; nxt = id[q]; }
+                        if (jb + q < j1 && dd[q] > bd) { bd = dd[q]; nxt = id[q]; bx = xx[q]; by = yy[q]; bz = zz[q]; }
                 }
                 if (nxt == cur) break;
                 cur = nxt;
             }
             s.hint = cur;
-            best = cur;
         } else {
             // exhaustive scan of a small hull (<= 64 vertices) in batches of 16: the 48 coordinate loads of a batch are issued
             // back to back and waited for once (a 4-vertex batch spent most of a support call in 16 dependent round trips)
+            bx = s.vert[0]; by = s.vert[1]; bz = s.vert[2];          // (vertex 0 is the answer if no vertex beats -1e30 + tie: never, but keeps the old default)
             for (int i0 = 0; i0 < s.nvert; i0 += 16) {
-                T dd[16];
+                T xx[16], yy[16], zz[16], dd[16];
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const int i = i0 + q < s.nvert ? i0 + q : s.nvert - 1;
-                    dd[q] = s.vert[3 * i] * dl.x + s.vert[3 * i + 1] * dl.y + s.vert[3 * i + 2] * dl.z;
+                    xx[q] = s.vert[3 * i]; yy[q] = s.vert[3 * i + 1]; zz[q] = s.vert[3 * i + 2];
+                    dd[q] = xx[q] * dl.x + yy[q] * dl.y + zz[q] * dl.z;
                 }
 #pragma unroll
                 for (int q = 0; q < 16; q++)
-                    if (i0 + q < s.nvert && dd[q] > bd + tie) { bd = dd[q]; best = i0 + q; }
+                    if (i0 + q < s.nvert && dd[q] > bd + tie) { bd = dd[q]; bx = xx[q]; by = yy[q]; bz = zz[q]; }
             }
         }
-        pl = mv3(s.vert + 3 * best);
+        pl = v3(bx, by, bz);
         break;
     }
     default: break;

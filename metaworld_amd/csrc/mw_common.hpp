@@ -186,6 +186,7 @@ struct Model {
     CP<int> mesh_nb8;
     CP<T> mesh_nb8xyz, mesh_startxyz;
     CP<int> body_dofmask;   // derived at upload: bit i = dof i lies on the chain from body b to the root (nv <= 31)
+    CP<int> dof_qposadr;    // derived at upload: the qpos element that dof i integrates into by qpos += h * qvel (slide / hinge joints, the three translational dofs of a free joint); -1 for the rotational dofs of a free joint
     Layout L;        // make_layout(sz)
 };
 
@@ -217,7 +218,7 @@ inline Layout make_layout(const Sizes& s) {
 
 // workgroup scratchpad handed to every lane program: LDS on the device (stride = lanes per workgroup), a private
 // buffer per host thread in the test harness (stride 1)
-struct Scratchpad { MW_LDS void* base; int block_words, host_nsub, max_rows; };   // 4-byte words of the whole workgroup; host_nsub > 0: host harness (one call per env, that many emulated sub-lanes); max_rows > 0: cap on the rows kept in the scratchpad (tests of the fallback rows)
+struct Scratchpad { MW_LDS void* base; int block_words, host_nsub, max_rows, chain; };   // 4-byte words of the whole workgroup; host_nsub > 0: host harness (one call per env, that many emulated sub-lanes); max_rows > 0: cap on the rows kept in the scratchpad (tests of the fallback rows); chain: 0 = never stage the body-level chains in the scratchpad (Env::chain_lds), else when they fit
 
 template <typename T> using CModel = const MW_CONST Model<T>;
 using CLayout = const MW_CONST Layout;
@@ -238,6 +239,15 @@ struct Env {
     int thr;           // thread index inside the workgroup
     int lds_rows;      // constraint rows that fit in the scratchpad: scalars + Jacobian row (the rest stay in the column store)
     int lds_w;         // scratchpad slots per row = SR_N + nv
+    // BODY-LEVEL CHAINS IN THE SCRATCHPAD.  Kinematics, the composite inertias and the recursive Newton-Euler passes are chains
+    // over the body tree in which every link reads what the previous one wrote: through the column store that is one L2 round
+    // trip (~700 cycles) per link and array, through LDS ~100.  When the environment's share of the scratchpad is large enough
+    // (chain_lds), its first lds_perm = 7 nv slots hold cdof[6 nv] and a copy of qvel[nv] for the whole dynamics evaluation (read
+    // by the mass matrix, the bias forces and every constraint row), the constraint rows start behind them, and the slots of the
+    // rows -- dead until make_constraints fills them -- carry the chains' transients first (mw_phys.hpp: body frames + qpos in
+    // kinematics, composite inertias in crb, body velocities / accelerations / forces in smooth_forces).  Same values either way.
+    int lds_perm;      // slots in front of the rows (0 without chain_lds)
+    int chain_lds;     // 1 = the layout above is in force for this environment's workgroup
 #if defined(MW_BOUNDS)   // debug build: every column-store access is range-checked; a violation is recorded and redirected to element 0
     unsigned nreal_b, nint_b;
     int* oob;          // context status word: [0] |= ST_OOB, [1] = kind (1 real, 2 int, 3 scratchpad), [2] = index, [3] = limit
@@ -248,7 +258,7 @@ struct Env {
     }
 #endif
     // lpb = environments per workgroup of this environment's group; threads t, t + lpb, ... are its sub-lanes
-    MW_HD void set_scratchpad(Scratchpad sp, int thread, int lpb, int nv_) {
+    MW_HD void set_scratchpad(Scratchpad sp, int thread, int lpb, int nv_, int nbody) {
         const bool host = sp.host_nsub > 0;
         lds = (MW_LDS T*)sp.base + (host ? 0 : thread % lpb);
         lds_stride = host ? 1 : lpb;
@@ -256,7 +266,10 @@ struct Env {
         thr = thread;
         nsub = host ? sp.host_nsub : 64 / lpb;
         lds_w = SR_N + nv_;
-        lds_rows = (int)((host ? sp.block_words : sp.block_words / lpb) * 4 / (lds_w * sizeof(T)));
+        const int words = (int)((host ? sp.block_words : sp.block_words / lpb) * 4 / sizeof(T));          // slots of this environment
+        chain_lds = sp.chain != 0 && words >= 7 * nv_ + 18 * nbody + 2 * lds_w;
+        lds_perm = chain_lds ? 7 * nv_ : 0;
+        lds_rows = (words - lds_perm) / lds_w;
         if (sp.max_rows > 0 && lds_rows > sp.max_rows) lds_rows = sp.max_rows;
     }
     MW_HD void cache_layout(const Layout& L, int nv_) {
@@ -269,6 +282,7 @@ struct Env {
         u.nv = mw_uniform(nv); u.o_efcJ = mw_uniform(o_efcJ); u.o_efcX = mw_uniform(o_efcX); u.o_con = mw_uniform(o_con);
         u.o_icon = mw_uniform(o_icon); u.o_iefc = mw_uniform(o_iefc); u.o_icount = mw_uniform(o_icount); u.o_task = mw_uniform(o_task);
         u.lds_rows = mw_uniform(lds_rows); u.lds_w = mw_uniform(lds_w); u.lds_stride = mw_uniform(lds_stride); u.nsub = mw_uniform(nsub);
+        u.lds_perm = mw_uniform(lds_perm); u.chain_lds = mw_uniform(chain_lds);
         return u;
     }
     MW_HD CModel<T>& model() const { return *(CModel<T>*)(unsigned long long)m; }
@@ -276,11 +290,11 @@ struct Env {
 #if defined(MW_BOUNDS)
     MW_HD GRef<T> R(int i) const { return ((MW_GLOBAL T*)col)[chk(i, nreal_b, 1) * stride]; }
     MW_HD GRef<int> I(int i) const { return ((MW_GLOBAL int*)icol)[chk(i, nint_b, 2) * stride]; }
-    MW_HD int S(int row, int f) const { return (int)chk(row, (unsigned)lds_rows, 3) * lds_w + f; }   // scratchpad slot of (row, field)
+    MW_HD int S(int row, int f) const { return lds_perm + (int)chk(row, (unsigned)lds_rows, 3) * lds_w + f; }   // scratchpad slot of (row, field)
 #else
     MW_HD GRef<T> R(int i) const { return ((MW_GLOBAL T*)col)[(unsigned)i * stride]; }
     MW_HD GRef<int> I(int i) const { return ((MW_GLOBAL int*)icol)[(unsigned)i * stride]; }
-    MW_HD int S(int row, int f) const { return row * lds_w + f; }   // scratchpad slot of (row, field); fields >= SR_N: the row's Jacobian
+    MW_HD int S(int row, int f) const { return lds_perm + row * lds_w + f; }   // scratchpad slot of (row, field); fields >= SR_N: the row's Jacobian
 #endif
 };
 
@@ -298,7 +312,18 @@ struct Env {
 #define MW_SUBS(e, sub) for (int sub = (e).sub, mw_once_ = 1; mw_once_; mw_once_ = 0)
 #define MW_SLOT(sub) 0
 constexpr int MW_NSLOT = 1;
+// The threads that exchange data through memory at an MW_SYNC all belong to ONE wavefront (a workgroup is one wave).  A wave's
+// memory instructions are issued and performed in order, so a later load of any lane observes an earlier store of any other lane
+// of the same wave without waiting: wavefront-scope release / acquire need no instructions on gfx9 (LLVM AMDGPU memory model).
+// What must be prevented is the COMPILER moving memory operations across the exchange point: a wavefront-scope fence (emits
+// nothing) + the wave barrier (a scheduling barrier for convergent code).  __syncthreads() instead emits s_waitcnt vmcnt(0)
+// lgkmcnt(0) + s_barrier: every exchange point drained all outstanding loads AND store acknowledgements (a full L2 round trip
+// after any store), ~30 times per dynamics evaluation.  -DMW_SYNC_STRONG restores it (fault hunting).
+#if defined(MW_SYNC_STRONG)
 #define MW_SYNC() __syncthreads()
+#else
+#define MW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); } while (0)
+#endif
 template <typename T>
 __device__ inline T sub_sum(const Env<T>& e, const T* p) {
     T v = p[0];

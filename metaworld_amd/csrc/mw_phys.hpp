@@ -17,16 +17,50 @@ namespace mw {
 
 template <typename T> MW_STAGE_FN void collision(const Env<T> e);  // mw_collide.hpp
 
+// ------------------------------------------------------------------ views: an array in the scratchpad or in the column store
+// (Env::chain_lds, mw_common.hpp).  LM is a compile-time switch: every stage below exists in both forms and picks one per call.
+template <typename T, bool LM>
+struct View {
+    Env<T> e;
+    int base;          // LM: first scratchpad slot; else: first element in the column store
+    MW_HD T get(int i) const {
+        if (LM) return e.lds[(base + i) * e.lds_stride];
+        return e.R(base + i);
+    }
+    MW_HD void set(int i, T v) const {
+        if (LM) e.lds[(base + i) * e.lds_stride] = v;
+        else e.R(base + i) = v;
+    }
+    MW_HD V3<T> get3(int i) const { return {get(i), get(i + 1), get(i + 2)}; }
+    MW_HD Q4<T> get4(int i) const { return {get(i), get(i + 1), get(i + 2), get(i + 3)}; }
+    MW_HD M3<T> get9(int i) const { M3<T> r; for (int k = 0; k < 9; k++) r.m[k] = get(i + k); return r; }
+};
+// cdof / qvel as the dynamics stages read them: the copies in front of the rows (scratchpad slots 0 .. 6 nv - 1 / 6 nv .. 7 nv - 1)
+// or the columns
+template <typename T, bool LM> MW_HD View<T, LM> cdof_view(const Env<T> e) { return View<T, LM>{e, LM ? 0 : e.lay().cdof}; }
+template <typename T, bool LM> MW_HD View<T, LM> qvel_view(const Env<T> e) { return View<T, LM>{e, LM ? 6 * e.nv : e.lay().qvel}; }
+
 // ------------------------------------------------------------------ kinematics
-template <typename T>
-MW_STAGE_FN void kinematics(const Env<T> e_) {
-    const Env<T> e = e_.uniform();
+// LM: the body frames the tree walk reads back (xpos, xquat, xmat of the parent) and qpos live in the scratchpad while the walk
+// runs; everything is ALSO stored to the columns, where the later stages and the task layer read it.  cdof and qvel go to their
+// slots in front of the rows.
+template <typename T, bool LM>
+MW_HD void kinematics_impl(const Env<T> e) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    const int nb = m.sz.nbody;
-    st3(e, L.xpos, v3<T>(0, 0, 0));
-    st4(e, L.xquat, Q4<T>{1, 0, 0, 0});
-    st9(e, L.xmat, q2mat(Q4<T>{1, 0, 0, 0}));
+    const int nb = m.sz.nbody, T0 = e.lds_perm;
+    const View<T, LM> xpos{e, LM ? T0 : L.xpos}, xquat{e, LM ? T0 + 3 * nb : L.xquat}, xmat{e, LM ? T0 + 7 * nb : L.xmat};
+    const View<T, LM> qpos{e, LM ? T0 + 16 * nb : L.qpos}, cdof = cdof_view<T, LM>(e);
+    if (LM) {
+        for (int i = 0; i < m.sz.nq; i++) qpos.set(i, e.R(L.qpos + i));
+        const View<T, LM> qv = qvel_view<T, LM>(e);
+        for (int i = 0; i < e.nv; i++) qv.set(i, e.R(L.qvel + i));
+    }
+    auto put = [&](const View<T, LM>& v, int col, int i, T x) { v.set(i, x); if (LM) e.R(col + i) = x; };   // scratchpad copy + column
+    auto put3 = [&](const View<T, LM>& v, int col, int i, V3<T> x) { put(v, col, i, x.x); put(v, col, i + 1, x.y); put(v, col, i + 2, x.z); };
+    put3(xpos, L.xpos, 0, v3<T>(0, 0, 0));
+    { const T q0[4] = {1, 0, 0, 0}; for (int k = 0; k < 4; k++) put(xquat, L.xquat, k, q0[k]); }
+    { const M3<T> R0 = q2mat(Q4<T>{1, 0, 0, 0}); for (int k = 0; k < 9; k++) put(xmat, L.xmat, k, R0.m[k]); }
     st3(e, L.xipos, v3<T>(0, 0, 0));
     for (int k = 0; k < 10; k++) e.R(L.cinert + k) = 0;
     for (int b = 1; b < nb; b++) {
@@ -39,57 +73,57 @@ MW_STAGE_FN void kinematics(const Env<T> e_) {
         } else {
             const int rl = m.body_relocid[b];
             V3<T> bp = rl >= 0 ? ld3(e, L.reloc + 3 * rl) : mv3(m.body_pos + 3 * b);
-            pos = ld3(e, L.xpos + 3 * p) + ld9(e, L.xmat + 9 * p) * bp;
-            quat = qmul(ld4(e, L.xquat + 4 * p), mq4(m.body_quat + 4 * b));
+            pos = xpos.get3(3 * p) + xmat.get9(9 * p) * bp;
+            quat = qmul(xquat.get4(4 * p), mq4(m.body_quat + 4 * b));
         }
         const int j0 = m.body_jntadr[b], jn = m.body_jntnum[b];
         for (int k = 0; k < jn; k++) {
             const int j = j0 + k, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j], jt = m.jnt_type[j];
             if (jt == J_FREE) {
-                Q4<T> q = qnormalized(ld4(e, L.qpos + qa + 3));
-                st4(e, L.qpos + qa + 3, q);
-                pos = ld3(e, L.qpos + qa);
+                Q4<T> q = qnormalized(qpos.get4(qa + 3));
+                put(qpos, L.qpos, qa + 3, q.w); put(qpos, L.qpos, qa + 4, q.x); put(qpos, L.qpos, qa + 5, q.y); put(qpos, L.qpos, qa + 6, q.z);
+                pos = qpos.get3(qa);
                 quat = q;
                 M3<T> R = q2mat(quat);
                 for (int c = 0; c < 3; c++) {
-                    const int o = L.cdof + 6 * (da + c);
-                    for (int r = 0; r < 6; r++) e.R(o + r) = (r == 3 + c) ? T(1) : T(0);
+                    const int o = 6 * (da + c);
+                    for (int r = 0; r < 6; r++) put(cdof, L.cdof, o + r, (r == 3 + c) ? T(1) : T(0));
                     V3<T> ax = col(R, c);
-                    st3(e, L.cdof + 6 * (da + 3 + c), ax);
-                    st3(e, L.cdof + 6 * (da + 3 + c) + 3, cross(pos, ax));
+                    put3(cdof, L.cdof, 6 * (da + 3 + c), ax);
+                    put3(cdof, L.cdof, 6 * (da + 3 + c) + 3, cross(pos, ax));
                 }
             } else {
                 M3<T> R = q2mat(quat);
                 V3<T> anchor = pos + R * mv3(m.jnt_pos + 3 * j);
                 V3<T> axis = R * mv3(m.jnt_axis + 3 * j);
-                const T q = e.R(L.qpos + qa);
+                const T q = qpos.get(qa);
                 if (jt == J_SLIDE) {
                     pos = pos + axis * q;
-                    st3(e, L.cdof + 6 * da, v3<T>(0, 0, 0));
-                    st3(e, L.cdof + 6 * da + 3, axis);
+                    put3(cdof, L.cdof, 6 * da, v3<T>(0, 0, 0));
+                    put3(cdof, L.cdof, 6 * da + 3, axis);
                 } else {
                     const T h = T(0.5) * q, s = sin(h);
                     const T* a = m.jnt_axis + 3 * j;
                     quat = qmul(quat, Q4<T>{cos(h), s * a[0], s * a[1], s * a[2]});
                     pos = anchor - q2mat(quat) * mv3(m.jnt_pos + 3 * j);
-                    st3(e, L.cdof + 6 * da, axis);
-                    st3(e, L.cdof + 6 * da + 3, cross(anchor, axis));
+                    put3(cdof, L.cdof, 6 * da, axis);
+                    put3(cdof, L.cdof, 6 * da + 3, cross(anchor, axis));
                 }
             }
         }
         quat = qnormalized(quat);
         M3<T> R = q2mat(quat);
-        st3(e, L.xpos + 3 * b, pos);
-        st4(e, L.xquat + 4 * b, quat);
-        st9(e, L.xmat + 9 * b, R);
+        put3(xpos, L.xpos, 3 * b, pos);
+        put(xquat, L.xquat, 4 * b, quat.w); put(xquat, L.xquat, 4 * b + 1, quat.x); put(xquat, L.xquat, 4 * b + 2, quat.y); put(xquat, L.xquat, 4 * b + 3, quat.z);
+        for (int k = 0; k < 9; k++) put(xmat, L.xmat, 9 * b + k, R.m[k]);
     }
     // The tree walk above is a serial chain (replicated on the sub-lanes: each reads back what it wrote itself); the
     // per-body inertial quantities and the geom frames only depend on the finished body frames -> split over sub-lanes.
     MW_SUBS(e, sub) {
     for (int b = 1 + sub; b < nb; b += e.nsub) {
-        const V3<T> pos = ld3(e, L.xpos + 3 * b);
-        const Q4<T> quat = ld4(e, L.xquat + 4 * b);
-        const M3<T> R = ld9(e, L.xmat + 9 * b);
+        const V3<T> pos = xpos.get3(3 * b);
+        const Q4<T> quat = xquat.get4(4 * b);
+        const M3<T> R = xmat.get9(9 * b);
         // inertial frame and spatial inertia about the world origin: {m, m*c, J(xx,yy,zz,xy,xz,yz)}
         V3<T> c = pos + R * mv3(m.body_ipos + 3 * b);
         st3(e, L.xipos + 3 * b, c);
@@ -114,11 +148,17 @@ MW_STAGE_FN void kinematics(const Env<T> e_) {
     }
     for (int g = sub; g < m.sz.ngeom; g += e.nsub) {
         const int b = m.geom_bodyid[g];
-        st3(e, L.geom_xpos + 3 * g, ld3(e, L.xpos + 3 * b) + ld9(e, L.xmat + 9 * b) * mv3(m.geom_pos + 3 * g));
-        st9(e, L.geom_xmat + 9 * g, q2mat(qmul(ld4(e, L.xquat + 4 * b), mq4(m.geom_quat + 4 * g))));
+        st3(e, L.geom_xpos + 3 * g, xpos.get3(3 * b) + xmat.get9(9 * b) * mv3(m.geom_pos + 3 * g));
+        st9(e, L.geom_xmat + 9 * g, q2mat(qmul(xquat.get4(4 * b), mq4(m.geom_quat + 4 * g))));
     }
     }
     MW_SYNC();
+}
+template <typename T>
+MW_STAGE_FN void kinematics(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
+    if (e.chain_lds) kinematics_impl<T, true>(e);
+    else kinematics_impl<T, false>(e);
 }
 
 // world pose of probe `p` (named body / geom / site frames the task layer reads)
@@ -273,20 +313,22 @@ MW_HD void chol_factor_solve_via_reg(const Env<T> e, int A, int x, int n) {   //
     }
 
 // ------------------------------------------------------------------ mass matrix
-template <typename T>
-MW_STAGE_FN void crb(const Env<T> e_) {
-    const Env<T> e = e_.uniform();
+// LM: the composite inertias are accumulated in the scratchpad (the leaf-to-root sum is a chain of read-modify-writes per
+// component) and the rows of M read them and cdof from there; only M itself goes to the column store.
+template <typename T, bool LM>
+MW_HD void crb_impl(const Env<T> e) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nb = m.sz.nbody, nv = m.sz.nv;
+    const View<T, LM> crbv{e, LM ? e.lds_perm : L.crb}, cdof = cdof_view<T, LM>(e);
     MW_SUBS(e, sub) {
         // composite inertias: the leaf-to-root accumulation is a serial chain per component, the 10 components are
         // independent -> one (or two) per sub-lane; same order of additions as a serial sweep
         for (int k = sub; k < 10; k += e.nsub) {
-            for (int b = 0; b < nb; b++) e.R(L.crb + 10 * b + k) = e.R(L.cinert + 10 * b + k);
+            for (int b = 0; b < nb; b++) crbv.set(10 * b + k, e.R(L.cinert + 10 * b + k));
             for (int b = nb - 1; b > 0; b--) {
                 const int p = m.body_parentid[b];
-                if (p > 0) e.R(L.crb + 10 * p + k) += e.R(L.crb + 10 * b + k);
+                if (p > 0) crbv.set(10 * p + k, crbv.get(10 * p + k) + crbv.get(10 * b + k));
             }
         }
         for (int i = sub; i < nv * nv; i += e.nsub) e.R(L.qM + i) = 0;
@@ -296,12 +338,12 @@ MW_STAGE_FN void crb(const Env<T> e_) {
         for (int i = sub; i < nv; i += e.nsub) {          // row / column i of M: one dof per sub-lane
             T I[10], s[6], f[6];
             const int b = m.dof_bodyid[i];
-            for (int k = 0; k < 10; k++) I[k] = e.R(L.crb + 10 * b + k);
-            for (int k = 0; k < 6; k++) s[k] = e.R(L.cdof + 6 * i + k);
+            for (int k = 0; k < 10; k++) I[k] = crbv.get(10 * b + k);
+            for (int k = 0; k < 6; k++) s[k] = cdof.get(6 * i + k);
             inertia_mul(f, I, s);
             for (int j = i; j >= 0; j = m.dof_parentid[j]) {
                 T v = 0;
-                for (int k = 0; k < 6; k++) v += e.R(L.cdof + 6 * j + k) * f[k];
+                for (int k = 0; k < 6; k++) v += cdof.get(6 * j + k) * f[k];
                 if (j == i) v += m.dof_armature[i];
                 e.R(L.qM + i * nv + j) = v;
                 e.R(L.qM + j * nv + i) = v;
@@ -312,6 +354,12 @@ MW_STAGE_FN void crb(const Env<T> e_) {
     // Cholesky factor of M (lower triangle) into qL, through registers (replicated on the sub-lanes)
     MW_NV_DISPATCH(nv, (chol_factor_via_reg<T, NVC>(e, L.qM, L.qL, nv)))
 }
+template <typename T>
+MW_STAGE_FN void crb(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
+    if (e.chain_lds) crb_impl<T, true>(e);
+    else crb_impl<T, false>(e);
+}
 
 // ------------------------------------------------------------------ bias forces (RNE), passive, actuation
 template <typename T>
@@ -320,41 +368,75 @@ MW_HD void cross_motion(T* r, const T* v, const T* s) {
     V3<T> a = cross(vw, sw), b = cross(vw, sl) + cross(vl, sw);
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = b.x; r[4] = b.y; r[5] = b.z;
 }
-template <typename T>
-MW_STAGE_FN void smooth_forces(const Env<T> e_) {
-    const Env<T> e = e_.uniform();
+// end of smooth_forces: qfrc_smooth += position actuators; qacc_smooth = M^-1 qfrc_smooth through the factor of M.  All loads
+// first, then arithmetic and stores (see integrate_impl: an element-wise read-modify-write or copy loop over the column store is
+// one memory round trip per element).  The actuated dof is a wave-uniform model constant: the addition is selected per
+// compile-time register index, not by indexing the register array.
+template <typename T, int NV>
+MW_HD void smooth_tail(const Env<T> e) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    const int nb = m.sz.nbody, nv = m.sz.nv;
-    for (int k = 0; k < 6; k++) { e.R(L.cvel + k) = 0; e.R(L.cfrc + k) = 0; }
-    e.R(L.cacc) = 0; e.R(L.cacc + 1) = 0; e.R(L.cacc + 2) = 0;
-    e.R(L.cacc + 3) = -m.gravity[0]; e.R(L.cacc + 4) = -m.gravity[1]; e.R(L.cacc + 5) = -m.gravity[2];
+    const int nv = e.nv;
+    T sm[NV], h[NV * (NV + 1) / 2], inv[NV], add[2] = {0, 0};
+    int dof[2] = {-1, -1};
+    vec_load<T, NV>(e, L.smooth, nv, sm);
+    tri_load<T, NV>(e, L.qL, nv, h);
+    const int nu = m.sz.nu < 2 ? m.sz.nu : 2;          // (ModelData::finalize insists on the two finger actuators)
+    for (int u = 0; u < nu; u++) {
+        const T c = mw_clamp(e.R(L.ctrl + u), m.act_ctrlrange[2 * u], m.act_ctrlrange[2 * u + 1]);
+        add[u] = m.act_kp[u] * (c - e.R(L.qpos + m.act_qposid[u]));
+        dof[u] = m.act_dofid[u];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        if (k == dof[0]) sm[k] += add[0];
+        if (k == dof[1]) sm[k] += add[1];
+    }
+    vec_store<T, NV>(e, L.smooth, nv, sm);
+#pragma unroll
+    for (int i = 0; i < NV; i++) inv[i] = T(1) / h[tri(i, i)];
+    chol_solve_reg<T, NV>(h, inv, sm);
+    vec_store<T, NV>(e, L.qacc_smooth, nv, sm);
+}
+
+// LM: body velocities / accelerations / forces (every body reads its parent's, then the forces are summed leaf to root) stay in
+// the scratchpad and are never written to the column store; cdof and qvel come from their slots in front of the rows.
+template <typename T, bool LM>
+MW_HD void smooth_forces_impl(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
+    const int nb = m.sz.nbody, nv = m.sz.nv, T0 = e.lds_perm;
+    const View<T, LM> cvel{e, LM ? T0 : L.cvel}, cacc{e, LM ? T0 + 6 * nb : L.cacc}, cfrc{e, LM ? T0 + 12 * nb : L.cfrc};
+    const View<T, LM> cdof = cdof_view<T, LM>(e), qvel = qvel_view<T, LM>(e);
+    for (int k = 0; k < 6; k++) { cvel.set(k, T(0)); cfrc.set(k, T(0)); }
+    cacc.set(0, T(0)); cacc.set(1, T(0)); cacc.set(2, T(0));
+    cacc.set(3, -m.gravity[0]); cacc.set(4, -m.gravity[1]); cacc.set(5, -m.gravity[2]);
     for (int b = 1; b < nb; b++) {
         const int p = m.body_parentid[b];
         T v[6], a[6];
-        for (int k = 0; k < 6; k++) { v[k] = e.R(L.cvel + 6 * p + k); a[k] = e.R(L.cacc + 6 * p + k); }
+        for (int k = 0; k < 6; k++) { v[k] = cvel.get(6 * p + k); a[k] = cacc.get(6 * p + k); }
         const int j0 = m.body_jntadr[b], jn = m.body_jntnum[b];
         for (int jj = 0; jj < jn; jj++) {
             const int j = j0 + jj, da = m.jnt_dofadr[j];
             if (m.jnt_type[j] == J_FREE) {
                 for (int i = 0; i < 3; i++) {
-                    const T qd = e.R(L.qvel + da + i);
-                    for (int c = 0; c < 6; c++) v[c] += e.R(L.cdof + 6 * (da + i) + c) * qd;
+                    const T qd = qvel.get(da + i);
+                    for (int c = 0; c < 6; c++) v[c] += cdof.get(6 * (da + i) + c) * qd;
                 }
                 T vs[6];
                 for (int c = 0; c < 6; c++) vs[c] = v[c];
                 for (int i = 3; i < 6; i++) {
                     T s[6], sd[6];
-                    for (int c = 0; c < 6; c++) s[c] = e.R(L.cdof + 6 * (da + i) + c);
+                    for (int c = 0; c < 6; c++) s[c] = cdof.get(6 * (da + i) + c);
                     cross_motion(sd, vs, s);
-                    const T qd = e.R(L.qvel + da + i);
+                    const T qd = qvel.get(da + i);
                     for (int c = 0; c < 6; c++) { v[c] += s[c] * qd; a[c] += sd[c] * qd; }
                 }
             } else {
                 T s[6], sd[6];
-                for (int c = 0; c < 6; c++) s[c] = e.R(L.cdof + 6 * da + c);
+                for (int c = 0; c < 6; c++) s[c] = cdof.get(6 * da + c);
                 cross_motion(sd, v, s);
-                const T qd = e.R(L.qvel + da);
+                const T qd = qvel.get(da);
                 for (int c = 0; c < 6; c++) { v[c] += s[c] * qd; a[c] += sd[c] * qd; }
             }
         }
@@ -365,16 +447,16 @@ MW_STAGE_FN void smooth_forces(const Env<T> e_) {
         // v x* (I v)
         V3<T> vw{v[0], v[1], v[2]}, vl{v[3], v[4], v[5]}, fn{Iv[0], Iv[1], Iv[2]}, ff{Iv[3], Iv[4], Iv[5]};
         V3<T> tn = cross(vw, fn) + cross(vl, ff), tf = cross(vw, ff);
-        for (int k = 0; k < 6; k++) { e.R(L.cvel + 6 * b + k) = v[k]; e.R(L.cacc + 6 * b + k) = a[k]; }
-        e.R(L.cfrc + 6 * b) = Ia[0] + tn.x; e.R(L.cfrc + 6 * b + 1) = Ia[1] + tn.y; e.R(L.cfrc + 6 * b + 2) = Ia[2] + tn.z;
-        e.R(L.cfrc + 6 * b + 3) = Ia[3] + tf.x; e.R(L.cfrc + 6 * b + 4) = Ia[4] + tf.y; e.R(L.cfrc + 6 * b + 5) = Ia[5] + tf.z;
+        for (int k = 0; k < 6; k++) { cvel.set(6 * b + k, v[k]); cacc.set(6 * b + k, a[k]); }
+        cfrc.set(6 * b, Ia[0] + tn.x); cfrc.set(6 * b + 1, Ia[1] + tn.y); cfrc.set(6 * b + 2, Ia[2] + tn.z);
+        cfrc.set(6 * b + 3, Ia[3] + tf.x); cfrc.set(6 * b + 4, Ia[4] + tf.y); cfrc.set(6 * b + 5, Ia[5] + tf.z);
     }
     MW_SYNC();
     MW_SUBS(e, sub) {
         for (int k = sub; k < 6; k += e.nsub)          // leaf-to-root force accumulation: one component per sub-lane
             for (int b = nb - 1; b > 0; b--) {
                 const int p = m.body_parentid[b];
-                if (p > 0) e.R(L.cfrc + 6 * p + k) += e.R(L.cfrc + 6 * b + k);
+                if (p > 0) cfrc.set(6 * p + k, cfrc.get(6 * p + k) + cfrc.get(6 * b + k));
             }
     }
     MW_SYNC();
@@ -383,21 +465,22 @@ MW_STAGE_FN void smooth_forces(const Env<T> e_) {
     for (int i = sub; i < nv; i += e.nsub) {
         T bias = 0;
         const int b = m.dof_bodyid[i];
-        for (int k = 0; k < 6; k++) bias += e.R(L.cdof + 6 * i + k) * e.R(L.cfrc + 6 * b + k);
+        for (int k = 0; k < 6; k++) bias += cdof.get(6 * i + k) * cfrc.get(6 * b + k);
         e.R(L.bias + i) = bias;
-        T f = -m.dof_damping[i] * e.R(L.qvel + i) - bias;
+        T f = -m.dof_damping[i] * qvel.get(i) - bias;
         const int j = m.dof_jntid[i];
         if (m.jnt_type[j] != J_FREE && m.jnt_stiffness[j] != 0)
             f -= m.jnt_stiffness[j] * (e.R(L.qpos + m.jnt_qposadr[j]) - m.jnt_springref[j]);
         e.R(L.smooth + i) = f;
     }
     MW_SYNC();
-    for (int u = 0; u < m.sz.nu; u++) {
-        const T c = mw_clamp(e.R(L.ctrl + u), m.act_ctrlrange[2 * u], m.act_ctrlrange[2 * u + 1]);
-        e.R(L.smooth + m.act_dofid[u]) += m.act_kp[u] * (c - e.R(L.qpos + m.act_qposid[u]));
-    }
-    for (int i = 0; i < nv; i++) e.R(L.qacc_smooth + i) = e.R(L.smooth + i);
-    MW_NV_DISPATCH(nv, (chol_solve_via_reg<T, NVC>(e, L.qL, L.qacc_smooth, nv)))
+    MW_NV_DISPATCH(nv, (smooth_tail<T, NVC>(e)))
+}
+template <typename T>
+MW_STAGE_FN void smooth_forces(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
+    if (e.chain_lds) smooth_forces_impl<T, true>(e);
+    else smooth_forces_impl<T, false>(e);
 }
 
 // ------------------------------------------------------------------ constraint rows
@@ -504,7 +587,7 @@ MW_HD void finish_row(const Env<T> e, int row, P1 solref, P2 solimp, T diagAppro
 // axes cdof[i] are loaded once per dof at an address that does not depend on a previous load, and every entry
 // J[row][i] = sign_a * (axis . jac_a) + sign_b * (axis . jac_b) is stored once (zero off the chains).  The two terms are added in
 // the order the reference-style accumulation used (first body of the call order first), so the values are the same.
-template <typename T>
+template <typename T, bool LM>
 MW_HD void weld_rows(const Env<T> e, int q, int r0) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
@@ -521,13 +604,14 @@ MW_HD void weld_rows(const Env<T> e, int q, int r0) {
     // rotational rows: 0.5 * imag( conj(q2) * (w1 - w2) * q1 * rel ) * torquescale
     const int m1 = m.body_dofmask[b1], m2 = m.body_dofmask[b2], both = m1 | m2;
     T vel[6] = {0, 0, 0, 0, 0, 0};
+    const View<T, LM> cdof = cdof_view<T, LM>(e), qvel = qvel_view<T, LM>(e);
     for (int i = 0; i < e.nv; i++) {
         if (!((both >> i) & 1)) {
             for (int k = 0; k < 6; k++) ej_set(e, r0 + k, i, T(0));
             continue;
         }
-        const V3<T> w = ld3(e, L.cdof + 6 * i), v = ld3(e, L.cdof + 6 * i + 3);
-        const T qd = e.R(L.qvel + i);
+        const V3<T> w = cdof.get3(6 * i), v = cdof.get3(6 * i + 3);
+        const T qd = qvel.get(i);
         const bool in1 = (m1 >> i) & 1, in2 = (m2 >> i) & 1;
         const V3<T> l1 = v + cross(w, p1), l2 = v + cross(w, p2);
         const Q4<T> q4 = qmul(qmul(q2n, Q4<T>{0, w.x, w.y, w.z}), qa);
@@ -550,7 +634,7 @@ MW_HD void weld_rows(const Env<T> e, int q, int r0) {
     }
 }
 
-template <typename T>
+template <typename T, bool LM>
 MW_HD void limit_row(const Env<T> e, int id, int r) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
@@ -560,11 +644,11 @@ MW_HD void limit_row(const Env<T> e, int id, int r) {
     for (int i = 0; i < e.nv; i++) ej_set(e, r, i, i == dof ? T(-side) : T(0));
     IEFC(e, r, 0) = C_LIMIT; IEFC(e, r, 1) = id;
     T vel = 0;
-    vel += T(-side) * e.R(L.qvel + dof);
+    vel += T(-side) * qvel_view<T, LM>(e).get(dof);
     finish_row(e, r, m.jnt_solref + 2 * j, m.jnt_solimp + 5 * j, m.dof_invweight0[dof], dist - margin, vel, T(0), T(C_LIMIT + 16), (T*)nullptr, (T*)nullptr);
 }
 
-template <typename T>
+template <typename T, bool LM>
 MW_HD void contact_rows(const Env<T> e, int c, int r0) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
@@ -576,13 +660,14 @@ MW_HD void contact_rows(const Env<T> e, int c, int r0) {
     V3<T> ax[3];
     for (int a = 0; a < 3; a++) ax[a] = V3<T>{CON(e, c, 4 + 3 * a), CON(e, c, 5 + 3 * a), CON(e, c, 6 + 3 * a)};
     T vel[6] = {0, 0, 0, 0, 0, 0};
+    const View<T, LM> cdof = cdof_view<T, LM>(e), qvel = qvel_view<T, LM>(e);
     for (int i = 0; i < e.nv; i++) {
         if (!((both >> i) & 1)) {
             for (int k = 0; k < dim; k++) ej_set(e, r0 + k, i, T(0));
             continue;
         }
-        const V3<T> w = ld3(e, L.cdof + 6 * i), lin = ld3(e, L.cdof + 6 * i + 3) + cross(w, pos);
-        const T qd = e.R(L.qvel + i);
+        const V3<T> w = cdof.get3(6 * i), lin = cdof.get3(6 * i + 3) + cross(w, pos);
+        const T qd = qvel.get(i);
         const bool in1 = (m1 >> i) & 1, in2 = (m2 >> i) & 1;
         for (int k = 0; k < dim; k++) {
             const T val = k >= 3 ? dot(ax[k - 3], w) : dot(ax[k], lin);
@@ -675,9 +760,15 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
     MW_SUBS(e, sub) {
         for (int w = sub; w < nwork; w += e.nsub) {
             const int kind = e.I(L.iwork + 3 * w), id = e.I(L.iwork + 3 * w + 1), r0 = e.I(L.iwork + 3 * w + 2);
-            if (kind == C_EQUALITY) weld_rows(e, id, r0);
-            else if (kind == C_LIMIT) limit_row(e, id, r0);
-            else contact_rows(e, id, r0);
+            if (e.chain_lds) {          // (cdof / qvel from their scratchpad slots: wave-uniform choice)
+                if (kind == C_EQUALITY) weld_rows<T, true>(e, id, r0);
+                else if (kind == C_LIMIT) limit_row<T, true>(e, id, r0);
+                else contact_rows<T, true>(e, id, r0);
+            } else {
+                if (kind == C_EQUALITY) weld_rows<T, false>(e, id, r0);
+                else if (kind == C_LIMIT) limit_row<T, false>(e, id, r0);
+                else contact_rows<T, false>(e, id, r0);
+            }
         }
     }
     MW_SYNC();
@@ -1139,7 +1230,10 @@ MW_STAGE_FN void solve(const Env<T> e_) {
     const int nv = e.nv;
     e.I(L.icount + 2) = 0;
     if (e.I(L.icount + 1) == 0) {
-        for (int k = 0; k < nv; k++) { e.R(L.qacc + k) = e.R(L.qacc_smooth + k); e.R(L.qfrc_c + k) = 0; }
+        T x[MAX_NV];
+        vec_load<T, MAX_NV>(e, L.qacc_smooth, nv, x);          // (all loads, then all stores)
+        vec_store<T, MAX_NV>(e, L.qacc, nv, x);
+        for (int k = 0; k < nv; k++) e.R(L.qfrc_c + k) = 0;
         return;
     }
     MW_NV_DISPATCH(nv, (solve_impl<T, NVC>(e)))
@@ -1173,18 +1267,20 @@ MW_STAGE_FN void forward_dynamics(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CLayout& L = e.lay();
 #if defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    // (the bias forces do not depend on the contacts: smooth_forces runs BEFORE make_constraints fills the constraint rows,
+    //  because its chain transients use the rows' scratchpad slots, Env::chain_lds; the timer slots keep their meaning)
     MW_TICK(t1) crb(e);
-    MW_TICK(t2) collision(e);
-    MW_TICK(t3) make_constraints(e);
-    MW_TICK(t4) smooth_forces(e);
+    MW_TICK(t2) smooth_forces(e);
+    MW_TICK(t3) collision(e);
+    MW_TICK(t4) make_constraints(e);
     MW_TICK(t5) solve(e);
     MW_TICK(t6)
-    MW_TOCK(e, L, 9, t1, t2) MW_TOCK(e, L, 10, t2, t3) MW_TOCK(e, L, 11, t3, t4) MW_TOCK(e, L, 12, t4, t5) MW_TOCK(e, L, 13, t5, t6)
+    MW_TOCK(e, L, 9, t1, t2) MW_TOCK(e, L, 12, t2, t3) MW_TOCK(e, L, 10, t3, t4) MW_TOCK(e, L, 11, t4, t5) MW_TOCK(e, L, 13, t5, t6)
 #else
     MW_STAGE(1, crb(e))
+    MW_STAGE(4, smooth_forces(e))
     MW_STAGE(2, collision(e))
     MW_STAGE(3, make_constraints(e))
-    MW_STAGE(4, smooth_forces(e))
     MW_STAGE(5, solve(e))
 #endif
     e.I(L.icount + IC_DYN_VALID) = 1;
@@ -1203,6 +1299,50 @@ MW_STAGE_FN void forward(const Env<T> e_) {
     forward_dynamics(e);
 }
 
+// The Euler step of mj_step after the solver: warm start <- qacc; (M + h B) a = qfrc_smooth + qfrc_constraint (implicit joint
+// damping); qvel += h a; qpos += h qvel (quaternions of free joints integrated on the sphere).
+// Everything is read into registers FIRST and stored afterwards.  The compiler may not move a load of the column store above
+// an earlier store to it (it cannot prove that the two do not overlap), so an element-wise `dst[k] = f(src[k])` loop is one
+// memory round trip PER ELEMENT (load, s_waitcnt vmcnt(0), store): the former element-wise form of this tail -- copying the
+// lower triangle of M into a column qH, adding h B, then qvel / qpos dof by dof -- was ~230 dependent round trips per substep.
+// Same operations on the same values in the same order; M + h B now only ever exists in registers.
+template <typename T, int NV>
+MW_HD void integrate_impl(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
+    const int nv = e.nv;
+    const T h = m.timestep;
+    constexpr int NT = NV * (NV + 1) / 2;
+    T acc[NV], rhs[NV], fc[NV], qv[NV], qp[NV], H[NT], inv[NV];
+    int qa[NV];
+    vec_load<T, NV>(e, L.qacc, nv, acc);
+    vec_load<T, NV>(e, L.smooth, nv, rhs);
+    vec_load<T, NV>(e, L.qfrc_c, nv, fc);
+    vec_load<T, NV>(e, L.qvel, nv, qv);
+    tri_load<T, NV>(e, L.qM, nv, H);
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        qa[k] = k < nv ? m.dof_qposadr[k] : -1;
+        qp[k] = e.R(L.qpos + (qa[k] >= 0 ? qa[k] : 0));
+    }
+    // ---- all loads are issued; from here on only arithmetic and stores ----
+    vec_store<T, NV>(e, L.warm, nv, acc);
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        if (k < nv) H[tri(k, k)] += h * m.dof_damping[k];
+        rhs[k] = rhs[k] + fc[k];
+    }
+    chol_reg<T, NV>(H, inv);
+    chol_solve_reg<T, NV>(H, inv, rhs);
+    vec_store<T, NV>(e, L.search, nv, rhs);
+#pragma unroll
+    for (int k = 0; k < NV; k++) qv[k] += h * rhs[k];
+    vec_store<T, NV>(e, L.qvel, nv, qv);
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        if (qa[k] >= 0) e.R(L.qpos + qa[k]) = qp[k] + h * qv[k];
+}
+
 template <typename T>
 MW_STAGE_FN void substep(const Env<T> e_) {
     const Env<T> e = e_.uniform();
@@ -1211,29 +1351,19 @@ MW_STAGE_FN void substep(const Env<T> e_) {
     const int nv = m.sz.nv;
     const T h = m.timestep;
     forward(e);
-    // warmstart <- solver acceleration; then (M + h B) a = f_smooth + f_constraint in qH / search
-    for (int k = 0; k < nv; k++) e.R(L.warm + k) = e.R(L.qacc + k);
-    for (int a = 0; a < nv; a++) {
-        for (int b = 0; b <= a; b++) e.R(L.qH + a * nv + b) = e.R(L.qM + a * nv + b);
-        e.R(L.qH + a * nv + a) += h * m.dof_damping[a];
-        e.R(L.search + a) = e.R(L.smooth + a) + e.R(L.qfrc_c + a);
-    }
-    MW_NV_DISPATCH(nv, (chol_factor_solve_via_reg<T, NVC>(e, L.qH, L.search, nv)))
-    for (int k = 0; k < nv; k++) e.R(L.qvel + k) += h * e.R(L.search + k);
-    for (int j = 0; j < m.sz.njnt; j++) {
+    MW_NV_DISPATCH(nv, (integrate_impl<T, NVC>(e)))
+    for (int j = 0; j < m.sz.njnt; j++) {          // orientation of the free bodies: q <- q * exp(h w / 2)
+        if (m.jnt_type[j] != J_FREE) continue;
         const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-        if (m.jnt_type[j] == J_FREE) {
-            for (int k = 0; k < 3; k++) e.R(L.qpos + qa + k) += h * e.R(L.qvel + da + k);
-            V3<T> w = ld3(e, L.qvel + da + 3);
-            T wn;
-            V3<T> ax = normalized(w, &wn);
-            const T ang = wn * h;
-            if (ang >= T(1e-15)) {
-                const T s = sin(T(0.5) * ang);
-                Q4<T> q = qmul(ld4(e, L.qpos + qa + 3), Q4<T>{cos(T(0.5) * ang), s * ax.x, s * ax.y, s * ax.z});
-                st4(e, L.qpos + qa + 3, qnormalized(q));
-            }
-        } else e.R(L.qpos + qa) += h * e.R(L.qvel + da);
+        V3<T> w = ld3(e, L.qvel + da + 3);
+        T wn;
+        V3<T> ax = normalized(w, &wn);
+        const T ang = wn * h;
+        if (ang >= T(1e-15)) {
+            const T s = sin(T(0.5) * ang);
+            Q4<T> q = qmul(ld4(e, L.qpos + qa + 3), Q4<T>{cos(T(0.5) * ang), s * ax.x, s * ax.y, s * ax.z});
+            st4(e, L.qpos + qa + 3, qnormalized(q));
+        }
     }
     e.R(L.time) += h;
 }

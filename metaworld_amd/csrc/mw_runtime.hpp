@@ -103,7 +103,7 @@ struct DeviceModel {
         for (auto& f : rfs) { roff.push_back(rb.size()); const auto& v = d.Rr(f.name); for (double x : v) rb.push_back((T)x); rb.push_back(0); }
         // derived hull tables (see Model::mesh_nb8): neighbour q < 8 of vertex v, padded with the last neighbour exactly like the
         // batched walk in support() pads a short batch, so the walk compares the same values in the same order
-        size_t o_nb8, o_nb8xyz, o_startxyz, o_dofmask;
+        size_t o_nb8, o_nb8xyz, o_startxyz, o_dofmask, o_dofqpos;
         {
             const auto &vadr = d.I("mesh_vertadr"), &vnum = d.I("mesh_vertnum"), &nadr = d.I("mesh_nbradr"), &nbr = d.I("mesh_nbr"),
                        &hill = d.I("mesh_hill"), &start = d.I("mesh_start");
@@ -135,6 +135,14 @@ struct DeviceModel {
             for (size_t b = 0; b < lastdof.size(); b++)
                 for (int i = lastdof[b]; i >= 0; i = dpar[i]) dm[b] |= 1 << i;
             o_dofmask = ib.size(); ib.insert(ib.end(), dm.begin(), dm.end());
+            // qpos element of every dof (see Model::dof_qposadr): the Euler step then updates qpos dof by dof from registers
+            const auto &djnt = d.I("dof_jntid"), &jtype = d.I("jnt_type"), &jqa = d.I("jnt_qposadr"), &jda = d.I("jnt_dofadr");
+            std::vector<int> dq(djnt.size() + 1, -1);
+            for (size_t i = 0; i < djnt.size(); i++) {
+                const int j = djnt[i], k = (int)i - jda[j];
+                dq[i] = jtype[j] == J_FREE ? (k < 3 ? jqa[j] + k : -1) : jqa[j];
+            }
+            o_dofqpos = ib.size(); ib.insert(ib.end(), dq.begin(), dq.end());
             o_nb8xyz = rb.size(); rb.insert(rb.end(), nb8xyz.begin(), nb8xyz.end());
             o_startxyz = rb.size(); rb.insert(rb.end(), sxyz.begin(), sxyz.end());
         }
@@ -149,6 +157,7 @@ struct DeviceModel {
         for (auto& f : rfs) { const T* q = rblob + roff[k++]; ::memcpy(&(m.*(f.p)), &q, sizeof(q)); }
         { const int* q = iblob + o_nb8; ::memcpy(&m.mesh_nb8, &q, sizeof(q)); }
         { const int* q = iblob + o_dofmask; ::memcpy(&m.body_dofmask, &q, sizeof(q)); }
+        { const int* q = iblob + o_dofqpos; ::memcpy(&m.dof_qposadr, &q, sizeof(q)); }
         { const T* q = rblob + o_nb8xyz; ::memcpy(&m.mesh_nb8xyz, &q, sizeof(q)); }
         { const T* q = rblob + o_startxyz; ::memcpy(&m.mesh_startxyz, &q, sizeof(q)); }
         m.sz = d.sz;
@@ -213,7 +222,7 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Scratchpad sp, Env<T
     const int lin = host ? thread : thread % lpb;
     const int lane = (block - G.block0) * lpb + lin;
     if (lane >= G.nenv) return false;
-    e->set_scratchpad(sp, thread, lpb, G.m.sz.nv);
+    e->set_scratchpad(sp, thread, lpb, G.m.sz.nv, G.m.sz.nbody);
     // element i of this environment: chunk base + i * lpb + (lane in chunk) -- consecutive elements of a workgroup's
     // environments are adjacent in memory (a Jacobian row of 8 environments is a few cache lines, not one line per entry)
     const size_t chunk = (size_t)(block - G.block0);
@@ -242,7 +251,14 @@ MW_HD void load_snapshot(const World<T>& w, const Env<T> e, int task, int goal, 
     const T* s = w.snap + w.snap_off[task] + (long long)goal * w.snap_stride[task];
     const int ns = e.lay().nstate;
     const V3<T> persist = tk3(e, TK_PERSIST0);
-    for (int k = 0; k < ns; k++) e.R(k) = s[k];
+    for (int k0 = 0; k0 < ns; k0 += 16) {          // in batches of 16: loads first, then stores (an element-wise copy is one round trip per element)
+        T x[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) x[q] = s[k0 + q < ns ? k0 + q : ns - 1];
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (k0 + q < ns) e.R(k0 + q) = x[q];
+    }
     for (int k = 0; k < 39; k++) obs39[k] = s[ns + k];
     if (w.tasks[task].kind == 1) task_after_reset(e, w.tasks[task], persist, obs39);
 }
@@ -382,11 +398,11 @@ MW_HD void lane_debug(const World<T>& w, int what, int n, int block, int thread,
     else if (what >= 10)            // stage timing: run stages 0..(what-10) of one dynamics evaluation, n times
         for (int it = 0; it < n; it++) {
             const int k = what - 10;
-            kinematics(e);
+            kinematics(e);          // (stages in the order of forward_dynamics: the bias forces before the constraint rows)
             if (k >= 1) crb(e);
-            if (k >= 2) collision(e);
-            if (k >= 3) make_constraints(e);
-            if (k >= 4) smooth_forces(e);
+            if (k >= 2) smooth_forces(e);
+            if (k >= 3) collision(e);
+            if (k >= 4) make_constraints(e);
             if (k >= 5) solve(e);
         }
     if (what == 0 || what == 1 || what >= 10) mirror_rows(e);   // the constraint rows of the last evaluation, for mw_read("efcJ" / "efcX")

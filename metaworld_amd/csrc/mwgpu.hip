@@ -26,9 +26,9 @@ inline void hip_check(hipError_t e, const char* what) {
 namespace {
 // one wavefront per workgroup; the dynamic LDS allocation is the lanes' scratchpad (solver row scalars, mw_phys.hpp)
 template <class F>
-__global__ void __launch_bounds__(64) k_lanes(F f, int block_words) {
+__global__ void __launch_bounds__(64) k_lanes(F f, int block_words, int chain) {
     extern __shared__ float mw_scratchpad[];
-    f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, block_words, 0, 0});
+    f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, block_words, 0, 0, chain});
 }
 
 // one thread per environment, no scratchpad: the small per-env kernels around the step (scripted policies, accounting)
@@ -141,7 +141,8 @@ struct Backend {
             hip_check(hipFuncSetAttribute((const void*)k_lanes<F>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute(LDS)");
             configured[cur()] = bytes;
         }
-        hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), bytes, stream(), f, bytes / 4);
+        static const int chain = getenv("MW_CHAIN_LDS") ? atoi(getenv("MW_CHAIN_LDS")) : 1;   // experiments: 0 = body-level chains through the column store (Env::chain_lds)
+        hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), bytes, stream(), f, bytes / 4, chain);
         hip_check(hipGetLastError(), "kernel launch");
     }
     template <class F>

@@ -138,14 +138,17 @@ struct Backend {
     template <class F>
     static void launch(int nblocks, F f) {   // one call per environment (locate() rejects threads >= lanes per workgroup): the sub-lanes are emulated inside (MW_SUBS)
         const int rows = lds_rows(), ns = nsub();
-        const size_t slots = (size_t)rows * (mw::SR_N + mw::MAX_NV);   // room for `rows` rows of the widest scene; Scratchpad::max_rows caps narrower ones
+        // room for `rows` rows of the widest scene (Scratchpad::max_rows caps narrower ones) + the slots in front of the rows and the
+        // chain transients of the widest scene (Env::chain_lds; MW_CHAIN_LDS=0: body-level chains through the column store)
+        static const int chain = std::getenv("MW_CHAIN_LDS") ? std::atoi(std::getenv("MW_CHAIN_LDS")) : 1;
+        const size_t slots = (size_t)rows * (mw::SR_N + mw::MAX_NV) + 7 * mw::MAX_NV + 18 * 64;
         const int words = (int)slots * 2;
 #pragma omp parallel
         {
             std::vector<double> pad(slots + 1, std::nan(""));   // LDS is not zero-initialised either
 #pragma omp for schedule(dynamic)
             for (int b = 0; b < nblocks; b++)
-                for (int t = 0; t < 64; t++) f(b, t, mw::Scratchpad{pad.data(), words, ns, rows});
+                for (int t = 0; t < 64; t++) f(b, t, mw::Scratchpad{pad.data(), words, ns, rows, chain});
         }
     }
     template <class F>

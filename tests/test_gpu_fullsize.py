@@ -35,6 +35,23 @@ def _oracle_synced_to(ctx, e, task):
     return om, d
 
 
+def _oracle_response(ctx, e, task, state, eps=1e-12, trials=3):
+    """max |change| of the oracle's own qpos / qvel, 5 substeps after the synchronised state `state` (columns read BEFORE the device
+    stepped), when qpos is perturbed by eps: the conditioning of the reference computation at that state"""
+    class _Cols:          # _oracle_synced_to reads the state through ctx.read
+        def read(self, _e, col):
+            return state[col]
+    out = []
+    rng = np.random.default_rng(0)
+    for k in range(trials + 1):
+        om, d = _oracle_synced_to(_Cols(), e, task)
+        if k:
+            d.qpos[:] += eps * rng.standard_normal(len(d.qpos))
+        d.step(5)
+        out.append((d.qpos.copy(), d.qvel.copy()))
+    return (max(np.abs(q - out[0][0]).max() for q, _ in out[1:]), max(np.abs(v - out[0][1]).max() for _, v in out[1:]))
+
+
 @pytest.mark.parametrize("bench,n", CONFIGS)
 def test_fullsize_batch_matches_small_batches_and_oracle(gpulib, bench, n):
     from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
@@ -111,8 +128,9 @@ def test_bench_states_match_the_oracle(gpulib, bench_name, n):
     for e in chosen[::17]:
         assert int(env.ctx.read(e, "task")[3]) == elapsed[e], e
     synced = [(e, env.env_task_names[e], _oracle_synced_to(env.ctx, e, env.env_task_names[e])) for e in chosen]
+    before = {e: {c: env.ctx.read(e, c) for c in ("qpos", "qvel", "warm", "mocap", "ctrl", "reloc")} for e in chosen}
     env.ctx.debug("substeps", 5)
-    bad, errs = [], []
+    bad, errs, relaxed = [], [], []
     for e, name, (om, d) in synced:
         d.step(5)
         ic = env.ctx.read_int(e, "icount")
@@ -129,9 +147,19 @@ def test_bench_states_match_the_oracle(gpulib, bench_name, n):
         # 1e-12 to 1e-5 ... 1e-3 in ONE step (tests/test_ill_conditioning.py) get the limits their trace tests use
         lq, lv = (1e-3, 1e-1) if name in TOL else (1e-5, 1e-3)
         errs.append(eq)
+        if ncon_dev == ncon_orc and ic[1] == d.nefc and not (eq < lq and ev < lv):
+            # Over the limit: is THIS STATE ill-conditioned in the reference computation itself?  (Which states the sample holds
+            # depends on the last bit of 520 chaotic steps, so any change of the device code draws new ones; a contact sitting at its
+            # activation margin turns 1e-12 into 1e-6 ... 1e-5 within one env-step, tests/test_ill_conditioning.py.)  The oracle is
+            # re-run from the synchronised state with qpos perturbed by 1e-12: where its OWN answer moves by more than a tenth of the
+            # limit no implementation can hold the limit, and the device may deviate by 10x that response (at most 1e-3 / 1e-1).
+            rq, rv = _oracle_response(env.ctx, e, name, before[e])
+            relaxed.append((name, e, float(eq), float(rq)))
+            lq, lv = min(max(lq, 10 * rq), 1e-3), min(max(lv, 10 * rv), 1e-1)
         if not (ncon_dev == ncon_orc and ic[1] == d.nefc and eq < lq and ev < lv):
             bad.append((name, e, int(elapsed[e]), (int(ic[0]), d.ncon), (int(ic[1]), d.nefc), float(eq), float(ev)))
     assert not bad, bad
+    assert len(relaxed) <= max(2, len(synced) // 50), relaxed          # ill-conditioned states are the exception (<= 2 % of the sample)
     assert np.quantile(errs, 0.9) < 1e-7, np.quantile(errs, [0.5, 0.9, 0.99, 1.0])
     assert env.status()["flags"] == 0
     env.close()

@@ -14,7 +14,7 @@ from metaworld_amd.vector_env import MetaWorldGpuVectorEnv  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 warm = int(os.environ.get("MW_WARM", "10"))
 reps = 20
-names = ["kin", "crb", "coll", "cons", "smooth", "solve"]
+names = ["kin", "crb", "smooth", "coll", "cons", "solve"]          # the order of forward_dynamics (mw_phys.hpp)
 for task in sys.argv[2:]:
     env = MetaWorldGpuVectorEnv("MT1", task, num_envs=n, seed=0, precision="fp32")
     env.reset()
