@@ -242,9 +242,9 @@ struct Env {
     // BODY-LEVEL CHAINS IN THE SCRATCHPAD.  Kinematics, the composite inertias and the recursive Newton-Euler passes are chains
     // over the body tree in which every link reads what the previous one wrote: through the column store that is one L2 round
     // trip (~700 cycles) per link and array, through LDS ~100.  When the environment's share of the scratchpad is large enough
-    // (chain_lds), its first lds_perm = 7 nv slots hold cdof[6 nv] and a copy of qvel[nv] for the whole dynamics evaluation (read
-    // by the mass matrix, the bias forces and every constraint row), the constraint rows start behind them, and the slots of the
-    // rows -- dead until make_constraints fills them -- carry the chains' transients first (mw_phys.hpp: body frames + qpos in
+    // (chain_lds), its first lds_perm = 7 nv + nq slots hold cdof[6 nv] and copies of qvel[nv] and qpos[nq] for the whole dynamics
+    // evaluation (read by the mass matrix, the bias forces, the joint limits and every constraint row), the constraint rows start behind them, and the slots of the
+    // rows -- dead until make_constraints fills them -- carry the chains' transients first (mw_phys.hpp: body frames in
     // kinematics, composite inertias in crb, body velocities / accelerations / forces in smooth_forces).  Same values either way.
     int lds_perm;      // slots in front of the rows (0 without chain_lds)
     int chain_lds;     // 1 = the layout above is in force for this environment's workgroup
@@ -258,7 +258,7 @@ struct Env {
     }
 #endif
     // lpb = environments per workgroup of this environment's group; threads t, t + lpb, ... are its sub-lanes
-    MW_HD void set_scratchpad(Scratchpad sp, int thread, int lpb, int nv_, int nbody) {
+    MW_HD void set_scratchpad(Scratchpad sp, int thread, int lpb, int nv_, int nbody, int nq_) {
         const bool host = sp.host_nsub > 0;
         lds = (MW_LDS T*)sp.base + (host ? 0 : thread % lpb);
         lds_stride = host ? 1 : lpb;
@@ -267,8 +267,8 @@ struct Env {
         nsub = host ? sp.host_nsub : 64 / lpb;
         lds_w = SR_N + nv_;
         const int words = (int)((host ? sp.block_words : sp.block_words / lpb) * 4 / sizeof(T));          // slots of this environment
-        chain_lds = sp.chain != 0 && words >= 7 * nv_ + 18 * nbody + 2 * lds_w;
-        lds_perm = chain_lds ? 7 * nv_ : 0;
+        chain_lds = sp.chain != 0 && words >= 7 * nv_ + nq_ + 18 * nbody + 2 * lds_w;
+        lds_perm = chain_lds ? 7 * nv_ + nq_ : 0;
         lds_rows = (words - lds_perm) / lds_w;
         if (sp.max_rows > 0 && lds_rows > sp.max_rows) lds_rows = sp.max_rows;
     }

@@ -35,14 +35,28 @@ struct View {
     MW_HD Q4<T> get4(int i) const { return {get(i), get(i + 1), get(i + 2), get(i + 3)}; }
     MW_HD M3<T> get9(int i) const { M3<T> r; for (int k = 0; k < 9; k++) r.m[k] = get(i + k); return r; }
 };
-// cdof / qvel as the dynamics stages read them: the copies in front of the rows (scratchpad slots 0 .. 6 nv - 1 / 6 nv .. 7 nv - 1)
-// or the columns
+// dst[0 .. n) (a view) <- column-store elements src .. src + n - 1, in batches of 8 loads issued together: an element-wise loop
+// waits for every load before it can store it
+template <typename T, bool LM>
+MW_HD void stage_in(const Env<T> e, const View<T, LM>& dst, int src, int n, int dst_stride = 1, int src_stride = 1) {
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        T x[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = e.R(src + (i0 + q < n ? i0 + q : n - 1) * src_stride);
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (i0 + q < n) dst.set((i0 + q) * dst_stride, x[q]);
+    }
+}
+// cdof / qvel / qpos as the dynamics stages read them: the copies in front of the rows (scratchpad slots 0 .. 6 nv - 1,
+// 6 nv .. 7 nv - 1, 7 nv .. 7 nv + nq - 1) or the columns
 template <typename T, bool LM> MW_HD View<T, LM> cdof_view(const Env<T> e) { return View<T, LM>{e, LM ? 0 : e.lay().cdof}; }
 template <typename T, bool LM> MW_HD View<T, LM> qvel_view(const Env<T> e) { return View<T, LM>{e, LM ? 6 * e.nv : e.lay().qvel}; }
+template <typename T, bool LM> MW_HD View<T, LM> qpos_view(const Env<T> e) { return View<T, LM>{e, LM ? 7 * e.nv : e.lay().qpos}; }
 
 // ------------------------------------------------------------------ kinematics
-// LM: the body frames the tree walk reads back (xpos, xquat, xmat of the parent) and qpos live in the scratchpad while the walk
-// runs; everything is ALSO stored to the columns, where the later stages and the task layer read it.  cdof and qvel go to their
+// LM: the body frames the tree walk reads back (xpos, xquat, xmat of the parent) live in the scratchpad while the walk runs;
+// everything is ALSO stored to the columns, where the later stages and the task layer read it.  cdof, qvel and qpos go to their
 // slots in front of the rows.
 template <typename T, bool LM>
 MW_HD void kinematics_impl(const Env<T> e) {
@@ -50,11 +64,10 @@ MW_HD void kinematics_impl(const Env<T> e) {
     CLayout& L = e.lay();
     const int nb = m.sz.nbody, T0 = e.lds_perm;
     const View<T, LM> xpos{e, LM ? T0 : L.xpos}, xquat{e, LM ? T0 + 3 * nb : L.xquat}, xmat{e, LM ? T0 + 7 * nb : L.xmat};
-    const View<T, LM> qpos{e, LM ? T0 + 16 * nb : L.qpos}, cdof = cdof_view<T, LM>(e);
+    const View<T, LM> qpos = qpos_view<T, LM>(e), cdof = cdof_view<T, LM>(e);
     if (LM) {
-        for (int i = 0; i < m.sz.nq; i++) qpos.set(i, e.R(L.qpos + i));
-        const View<T, LM> qv = qvel_view<T, LM>(e);
-        for (int i = 0; i < e.nv; i++) qv.set(i, e.R(L.qvel + i));
+        stage_in(e, qpos, L.qpos, m.sz.nq);
+        stage_in(e, qvel_view<T, LM>(e), L.qvel, e.nv);
     }
     auto put = [&](const View<T, LM>& v, int col, int i, T x) { v.set(i, x); if (LM) e.R(col + i) = x; };   // scratchpad copy + column
     auto put3 = [&](const View<T, LM>& v, int col, int i, V3<T> x) { put(v, col, i, x.x); put(v, col, i + 1, x.y); put(v, col, i + 2, x.z); };
@@ -325,7 +338,7 @@ MW_HD void crb_impl(const Env<T> e) {
         // composite inertias: the leaf-to-root accumulation is a serial chain per component, the 10 components are
         // independent -> one (or two) per sub-lane; same order of additions as a serial sweep
         for (int k = sub; k < 10; k += e.nsub) {
-            for (int b = 0; b < nb; b++) crbv.set(10 * b + k, e.R(L.cinert + 10 * b + k));
+            stage_in(e, View<T, LM>{e, crbv.base + k}, L.cinert + k, nb, 10, 10);          // crb[b][k] <- cinert[b][k] for all b
             for (int b = nb - 1; b > 0; b--) {
                 const int p = m.body_parentid[b];
                 if (p > 0) crbv.set(10 * p + k, crbv.get(10 * p + k) + crbv.get(10 * b + k));
@@ -407,7 +420,7 @@ MW_HD void smooth_forces_impl(const Env<T> e) {
     CLayout& L = e.lay();
     const int nb = m.sz.nbody, nv = m.sz.nv, T0 = e.lds_perm;
     const View<T, LM> cvel{e, LM ? T0 : L.cvel}, cacc{e, LM ? T0 + 6 * nb : L.cacc}, cfrc{e, LM ? T0 + 12 * nb : L.cfrc};
-    const View<T, LM> cdof = cdof_view<T, LM>(e), qvel = qvel_view<T, LM>(e);
+    const View<T, LM> cdof = cdof_view<T, LM>(e), qvel = qvel_view<T, LM>(e), qpos = qpos_view<T, LM>(e);
     for (int k = 0; k < 6; k++) { cvel.set(k, T(0)); cfrc.set(k, T(0)); }
     cacc.set(0, T(0)); cacc.set(1, T(0)); cacc.set(2, T(0));
     cacc.set(3, -m.gravity[0]); cacc.set(4, -m.gravity[1]); cacc.set(5, -m.gravity[2]);
@@ -470,7 +483,7 @@ MW_HD void smooth_forces_impl(const Env<T> e) {
         T f = -m.dof_damping[i] * qvel.get(i) - bias;
         const int j = m.dof_jntid[i];
         if (m.jnt_type[j] != J_FREE && m.jnt_stiffness[j] != 0)
-            f -= m.jnt_stiffness[j] * (e.R(L.qpos + m.jnt_qposadr[j]) - m.jnt_springref[j]);
+            f -= m.jnt_stiffness[j] * (qpos.get(m.jnt_qposadr[j]) - m.jnt_springref[j]);
         e.R(L.smooth + i) = f;
     }
     MW_SYNC();
@@ -639,7 +652,7 @@ MW_HD void limit_row(const Env<T> e, int id, int r) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int j = id >> 1, side = (id & 1) ? 1 : -1, dof = m.jnt_dofadr[j];
-    const T q = e.R(L.qpos + m.jnt_qposadr[j]), margin = m.jnt_margin[j];
+    const T q = qpos_view<T, LM>(e).get(m.jnt_qposadr[j]), margin = m.jnt_margin[j];
     const T dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - q);
     for (int i = 0; i < e.nv; i++) ej_set(e, r, i, i == dof ? T(-side) : T(0));
     IEFC(e, r, 0) = C_LIMIT; IEFC(e, r, 1) = id;
@@ -721,7 +734,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
     // ---- joint limits ----
     for (int j = 0; j < m.sz.njnt; j++) {
         if (!m.jnt_limited[j] || m.jnt_type[j] == J_FREE) continue;
-        const T q = e.R(L.qpos + m.jnt_qposadr[j]), margin = m.jnt_margin[j];
+        const T q = e.chain_lds ? qpos_view<T, true>(e).get(m.jnt_qposadr[j]) : e.R(L.qpos + m.jnt_qposadr[j]), margin = m.jnt_margin[j];
         for (int side = -1; side <= 1; side += 2) {
             const T dist = side * (m.jnt_range[2 * j + (side + 1) / 2] - q);
             if (dist < margin) {
@@ -734,22 +747,35 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
         }
     }
     // ---- contacts (elliptic cones, condim 3 or 4) ----
+    // (eight contacts per trip: their three loads each are issued together; the walk itself -- row ranges in contact order -- is serial)
     const int ncon = e.I(L.icount);
-    for (int c = 0; c < ncon; c++) {
-        const T dist = CON(e, c, 0), inc = CON(e, c, 13);
-        const int dim = ICON(e, c, 2);
-        int adr = -1;
-        if (dist < inc) {
-            want += dim;
-            if (nefc + dim > maxefc) flags |= ST_ROW_OVERFLOW;
-            else {
-                adr = nefc;
-                work(C_CONTACT, c, nefc);
-                set_block_row(e, nblk, nefc);
-                nblk++; nefc += dim;
-            }
+    for (int c0 = 0; c0 < ncon; c0 += 8) {
+        T cdist[8], cinc[8];
+        int cdim[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int c = c0 + q < ncon ? c0 + q : ncon - 1;
+            cdist[q] = CON(e, c, 0); cinc[q] = CON(e, c, 13); cdim[q] = ICON(e, c, 2);
         }
-        ICON(e, c, 3) = adr;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int c = c0 + q;
+            if (c >= ncon) break;
+            const T dist = cdist[q], inc = cinc[q];
+            const int dim = cdim[q];
+            int adr = -1;
+            if (dist < inc) {
+                want += dim;
+                if (nefc + dim > maxefc) flags |= ST_ROW_OVERFLOW;
+                else {
+                    adr = nefc;
+                    work(C_CONTACT, c, nefc);
+                    set_block_row(e, nblk, nefc);
+                    nblk++; nefc += dim;
+                }
+            }
+            ICON(e, c, 3) = adr;
+        }
     }
     if (sub_disagree(e, nefc) || sub_disagree(e, (nblk << 12) ^ nwork) || sub_disagree(e, want)) flags |= ST_DIVERGED;   // canary (mw_common.hpp)
     e.I(L.icount + 1) = nefc;
@@ -881,8 +907,14 @@ MW_STAGE_FN T update_constraint(const Env<T> e_) {
     MW_SYNC();
     const T cost = sub_sum(e, cp);
     T gauss = 0;
-    for (int k = 0; k < nv; k++)
-        gauss += (e.R(L.Ma + k) - e.R(L.smooth + k)) * (e.R(L.qacc + k) - e.R(L.qacc_smooth + k));
+    {          // the four vectors in one batch of loads (a runtime loop waits for its four loads in every trip)
+        T ma[NV], sm[NV], qa[NV], qs[NV];
+        vec_load<T, NV>(e, L.Ma, nv, ma); vec_load<T, NV>(e, L.smooth, nv, sm);
+        vec_load<T, NV>(e, L.qacc, nv, qa); vec_load<T, NV>(e, L.qacc_smooth, nv, qs);
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+            if (k < nv) gauss += (ma[k] - sm[k]) * (qa[k] - qs[k]);
+    }
     T qf[MW_NSLOT][NV];
     MW_SUBS(e, sub) {
         T* q = qf[MW_SLOT(sub)];
@@ -1199,9 +1231,13 @@ MW_HD void solve_impl(const Env<T> e) {
         MW_TOCK(e, L, 4, t_g, t_h)
         MW_TADD(e, L, 6, nls)
         if (alpha == 0) break;
+        {          // qacc += alpha s, Ma += alpha Mv: all loads first, then the stores (see integrate_impl)
+            T qa[NV], ma[NV], mv[NV];
+            vec_load<T, NV>(e, L.qacc, nv, qa); vec_load<T, NV>(e, L.Ma, nv, ma); vec_load<T, NV>(e, L.Mv, nv, mv);
 #pragma unroll
-        for (int k = 0; k < NV; k++)
-            if (k < nv) { e.R(L.qacc + k) += alpha * sr[k]; e.R(L.Ma + k) += alpha * e.R(L.Mv + k); }
+            for (int k = 0; k < NV; k++) { qa[k] += alpha * sr[k]; ma[k] += alpha * mv[k]; }
+            vec_store<T, NV>(e, L.qacc, nv, qa); vec_store<T, NV>(e, L.Ma, nv, ma);
+        }
         MW_SUBS(e, sub) {
             for (int i = sub; i < nefc; i += e.nsub) sr_set(e, i, SR_JAR, sr_get(e, i, SR_JAR) + alpha * sr_get(e, i, SR_JV));
         }

@@ -222,7 +222,7 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Scratchpad sp, Env<T
     const int lin = host ? thread : thread % lpb;
     const int lane = (block - G.block0) * lpb + lin;
     if (lane >= G.nenv) return false;
-    e->set_scratchpad(sp, thread, lpb, G.m.sz.nv, G.m.sz.nbody);
+    e->set_scratchpad(sp, thread, lpb, G.m.sz.nv, G.m.sz.nbody, G.m.sz.nq);
     // element i of this environment: chunk base + i * lpb + (lane in chunk) -- consecutive elements of a workgroup's
     // environments are adjacent in memory (a Jacobian row of 8 environments is a few cache lines, not one line per entry)
     const size_t chunk = (size_t)(block - G.block0);
