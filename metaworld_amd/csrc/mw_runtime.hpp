@@ -626,6 +626,40 @@ public:
                 lpb_of[best] /= 2;
                 if (blocks() > budget) { lpb_of[best] *= 2; frozen.insert(best); }
             }
+            // Optional second pass (minimax exchange, MW_LPB_EXCHANGE=1): the greedy above stops when the grid is full; the slowest
+            // predicted group can still be halved if lighter groups give up waves by DOUBLING their lanes, as long as none of them
+            // comes within 3 % of the time that is being removed.  OFF by default: measured on MT50 @ 4096 fp64 (round 3) it moved 8
+            // light scenes to 16 lanes and one heavy scene to 2 and was 2 % SLOWER (817 k vs 835 k env-steps/s inside one GPU call);
+            // a table re-measured with 4 / 8 lanes everywhere was 3 % slower than the shipped one (1.04 M vs 1.07 M), 4 lanes
+            // everywhere 8 % slower.  The slowest waves are set by ONE environment's serial narrow phase or solver, which more
+            // sub-lanes do not shorten, while every doubled scene pays for the longer union of its lanes' iterations.
+            if (getenv("MW_LPB_EXCHANGE") && atoi(getenv("MW_LPB_EXCHANGE")) == 1) {
+                for (int round = 0; round < 64; round++) {
+                    int gmax = -1; double tmax = -1;
+                    for (auto& kv : by_model) {
+                        const double t = predicted(kv.first, lpb_of[kv.first]);
+                        if (t > tmax) { tmax = t; gmax = kv.first; }
+                    }
+                    if (gmax < 0 || lpb_of[gmax] <= 1) break;
+                    const double tnew = predicted(gmax, lpb_of[gmax] / 2), bound = 0.97 * tmax;
+                    std::map<int, int> trial = lpb_of;
+                    trial[gmax] /= 2;
+                    auto blocks_of = [&](const std::map<int, int>& l) { int nb = 0; for (auto& kv : by_model) nb += ((int)kv.second.size() + l.at(kv.first) - 1) / l.at(kv.first); return nb; };
+                    std::set<int> used;
+                    while (blocks_of(trial) > budget) {
+                        int donor = -1; double best = 1e300;
+                        for (auto& kv : by_model) {
+                            if (kv.first == gmax || used.count(kv.first) || trial[kv.first] >= BLOCK) continue;
+                            const double t = predicted(kv.first, trial[kv.first] * 2);
+                            if (t < bound && t < best) { best = t; donor = kv.first; }
+                        }
+                        if (donor < 0) break;
+                        trial[donor] *= 2; used.insert(donor);
+                    }
+                    if (blocks_of(trial) > budget || !(tnew < tmax)) break;
+                    lpb_of = trial;
+                }
+            }
             for (auto& kv : by_model) {          // an explicit per-model choice (model option "lanes_per_block") wins over the proxy
                 const int l = models[kv.first]->lanes_per_block;
                 if (l == 0) continue;
@@ -640,10 +674,11 @@ public:
         }
         if (getenv("MW_VERBOSE")) {
             std::map<int, int> hist;
-            for (auto& kv : by_model) hist[lpb_of[kv.first]]++;
+            int nb = 0;
+            for (auto& kv : by_model) { hist[lpb_of[kv.first]]++; nb += ((int)kv.second.size() + lpb_of[kv.first] - 1) / lpb_of[kv.first]; }
             fprintf(stderr, "[mwgpu] lanes per workgroup -> number of scenes:");
             for (auto& kv : hist) fprintf(stderr, " %d:%d", kv.first, kv.second);
-            fprintf(stderr, "\n");
+            fprintf(stderr, "  (%d workgroups)\n", nb);
         }
         int gi = 0, blk = 0;
         for (auto& kv : by_model) {

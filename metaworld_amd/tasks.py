@@ -210,7 +210,7 @@ def model_probes(model_name, v1=False):
     return probes, roles
 
 
-with open(os.path.join(_HERE, "data", "model_caps.json")) as _f:
+with open(os.environ.get("MW_MODEL_CAPS") or os.path.join(_HERE, "data", "model_caps.json")) as _f:          # (MW_MODEL_CAPS: experiments with another table)
     MODEL_CAPS = json.load(_f)     # per model: contact / constraint-row capacities = 2 x the demand measured on the GPU over whole episodes of random actions at MT50 @ 4096 (tools/measure_caps_gpu.py); step_ms_lpb4 = critical-path weight of the scene inside the MT50 @ 4096 bench workload at 4 lanes per workgroup (largest per-env cycle count of a step / 2.4e6, tools/mix_timing.py, max over the tasks sharing the scene), step_ms_lpb8 = the same scaled by the scene's isolated 8-lane / 4-lane step-time ratio (tools/per_task_timing.py)
 
 

@@ -24,6 +24,8 @@ d = (ic1 - ic0)[:, 4:18].astype(np.float64) / steps
 mid, narrow, ncand, rounds, coll = d[:, 0] * 16e-3, d[:, 1] * 16e-3, d[:, 2], d[:, 3], d[:, 10] * 16e-3
 br = d[:, 4:8] * 16e-3          # per-branch kcyc / step inside collide_pair: box-box, portal refinement, other closed forms, face upgrade
 tn = np.array(env.env_task_names)
+if os.environ.get("MW_COLL_NPZ"):          # raw per-env numbers (wave-level analysis offline)
+    np.savez_compressed(os.environ["MW_COLL_NPZ"], d=d, task=tn, ms=ms)
 print(f"{ms:.2f} ms/launch")
 rows = []
 for t in env.task_list:
