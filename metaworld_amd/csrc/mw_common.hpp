@@ -247,7 +247,7 @@ struct Env {
     // rows -- dead until make_constraints fills them -- carry the chains' transients first (mw_phys.hpp: body frames in
     // kinematics, composite inertias in crb, body velocities / accelerations / forces in smooth_forces).  Same values either way.
     int lds_perm;      // slots in front of the rows (0 without chain_lds)
-    int chain_lds;     // 1 = the layout above is in force for this environment's workgroup
+    int chain_lds;     // 0 = nothing of the above; 1 = the slots in front of the rows + the composite inertias (what fits a smaller share: 7 nv + nq + 10 nbody slots); 2 = all of it (+ 18 nbody slots)
 #if defined(MW_BOUNDS)   // debug build: every column-store access is range-checked; a violation is recorded and redirected to element 0
     unsigned nreal_b, nint_b;
     int* oob;          // context status word: [0] |= ST_OOB, [1] = kind (1 real, 2 int, 3 scratchpad), [2] = index, [3] = limit
@@ -267,7 +267,8 @@ struct Env {
         nsub = host ? sp.host_nsub : 64 / lpb;
         lds_w = SR_N + nv_;
         const int words = (int)((host ? sp.block_words : sp.block_words / lpb) * 4 / sizeof(T));          // slots of this environment
-        chain_lds = sp.chain != 0 && words >= 7 * nv_ + nq_ + 18 * nbody + 2 * lds_w;
+        chain_lds = sp.chain == 0 ? 0 : (words >= 7 * nv_ + nq_ + 18 * nbody + 2 * lds_w ? 2 : (words >= 7 * nv_ + nq_ + 10 * nbody + 2 * lds_w ? 1 : 0));
+        if (sp.chain > 0 && sp.chain < chain_lds) chain_lds = sp.chain;          // (tests / experiments: cap the level)
         lds_perm = chain_lds ? 7 * nv_ + nq_ : 0;
         lds_rows = (words - lds_perm) / lds_w;
         if (sp.max_rows > 0 && lds_rows > sp.max_rows) lds_rows = sp.max_rows;

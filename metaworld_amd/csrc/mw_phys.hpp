@@ -21,6 +21,7 @@ template <typename T> MW_STAGE_FN void collision(const Env<T> e);  // mw_collide
 // (Env::chain_lds, mw_common.hpp).  LM is a compile-time switch: every stage below exists in both forms and picks one per call.
 template <typename T, bool LM>
 struct View {
+    static constexpr bool is_lds = LM;
     Env<T> e;
     int base;          // LM: first scratchpad slot; else: first element in the column store
     MW_HD T get(int i) const {
@@ -58,19 +59,20 @@ template <typename T, bool LM> MW_HD View<T, LM> qpos_view(const Env<T> e) { ret
 // LM: the body frames the tree walk reads back (xpos, xquat, xmat of the parent) live in the scratchpad while the walk runs;
 // everything is ALSO stored to the columns, where the later stages and the task layer read it.  cdof, qvel and qpos go to their
 // slots in front of the rows.
-template <typename T, bool LM>
+// (LM = the slots in front of the rows are in use, Env::chain_lds >= 1; FR = the body frames too, chain_lds == 2)
+template <typename T, bool LM, bool FR>
 MW_HD void kinematics_impl(const Env<T> e) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nb = m.sz.nbody, T0 = e.lds_perm;
-    const View<T, LM> xpos{e, LM ? T0 : L.xpos}, xquat{e, LM ? T0 + 3 * nb : L.xquat}, xmat{e, LM ? T0 + 7 * nb : L.xmat};
+    const View<T, FR> xpos{e, FR ? T0 : L.xpos}, xquat{e, FR ? T0 + 3 * nb : L.xquat}, xmat{e, FR ? T0 + 7 * nb : L.xmat};
     const View<T, LM> qpos = qpos_view<T, LM>(e), cdof = cdof_view<T, LM>(e);
     if (LM) {
         stage_in(e, qpos, L.qpos, m.sz.nq);
         stage_in(e, qvel_view<T, LM>(e), L.qvel, e.nv);
     }
-    auto put = [&](const View<T, LM>& v, int col, int i, T x) { v.set(i, x); if (LM) e.R(col + i) = x; };   // scratchpad copy + column
-    auto put3 = [&](const View<T, LM>& v, int col, int i, V3<T> x) { put(v, col, i, x.x); put(v, col, i + 1, x.y); put(v, col, i + 2, x.z); };
+    auto put = [&](const auto& v, int col, int i, T x) { v.set(i, x); if (v.is_lds) e.R(col + i) = x; };   // scratchpad copy + column
+    auto put3 = [&](const auto& v, int col, int i, V3<T> x) { put(v, col, i, x.x); put(v, col, i + 1, x.y); put(v, col, i + 2, x.z); };
     put3(xpos, L.xpos, 0, v3<T>(0, 0, 0));
     { const T q0[4] = {1, 0, 0, 0}; for (int k = 0; k < 4; k++) put(xquat, L.xquat, k, q0[k]); }
     { const M3<T> R0 = q2mat(Q4<T>{1, 0, 0, 0}); for (int k = 0; k < 9; k++) put(xmat, L.xmat, k, R0.m[k]); }
@@ -170,8 +172,9 @@ MW_HD void kinematics_impl(const Env<T> e) {
 template <typename T>
 MW_STAGE_FN void kinematics(const Env<T> e_) {
     const Env<T> e = e_.uniform();
-    if (e.chain_lds) kinematics_impl<T, true>(e);
-    else kinematics_impl<T, false>(e);
+    if (e.chain_lds == 2) kinematics_impl<T, true, true>(e);
+    else if (e.chain_lds == 1) kinematics_impl<T, true, false>(e);
+    else kinematics_impl<T, false, false>(e);
 }
 
 // world pose of probe `p` (named body / geom / site frames the task layer reads)
@@ -414,12 +417,12 @@ MW_HD void smooth_tail(const Env<T> e) {
 
 // LM: body velocities / accelerations / forces (every body reads its parent's, then the forces are summed leaf to root) stay in
 // the scratchpad and are never written to the column store; cdof and qvel come from their slots in front of the rows.
-template <typename T, bool LM>
+template <typename T, bool LM, bool FR>
 MW_HD void smooth_forces_impl(const Env<T> e) {
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nb = m.sz.nbody, nv = m.sz.nv, T0 = e.lds_perm;
-    const View<T, LM> cvel{e, LM ? T0 : L.cvel}, cacc{e, LM ? T0 + 6 * nb : L.cacc}, cfrc{e, LM ? T0 + 12 * nb : L.cfrc};
+    const View<T, FR> cvel{e, FR ? T0 : L.cvel}, cacc{e, FR ? T0 + 6 * nb : L.cacc}, cfrc{e, FR ? T0 + 12 * nb : L.cfrc};
     const View<T, LM> cdof = cdof_view<T, LM>(e), qvel = qvel_view<T, LM>(e), qpos = qpos_view<T, LM>(e);
     for (int k = 0; k < 6; k++) { cvel.set(k, T(0)); cfrc.set(k, T(0)); }
     cacc.set(0, T(0)); cacc.set(1, T(0)); cacc.set(2, T(0));
@@ -492,8 +495,9 @@ MW_HD void smooth_forces_impl(const Env<T> e) {
 template <typename T>
 MW_STAGE_FN void smooth_forces(const Env<T> e_) {
     const Env<T> e = e_.uniform();
-    if (e.chain_lds) smooth_forces_impl<T, true>(e);
-    else smooth_forces_impl<T, false>(e);
+    if (e.chain_lds == 2) smooth_forces_impl<T, true, true>(e);
+    else if (e.chain_lds == 1) smooth_forces_impl<T, true, false>(e);
+    else smooth_forces_impl<T, false, false>(e);
 }
 
 // ------------------------------------------------------------------ constraint rows

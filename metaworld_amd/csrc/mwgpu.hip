@@ -141,7 +141,7 @@ struct Backend {
             hip_check(hipFuncSetAttribute((const void*)k_lanes<F>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute(LDS)");
             configured[cur()] = bytes;
         }
-        static const int chain = getenv("MW_CHAIN_LDS") ? atoi(getenv("MW_CHAIN_LDS")) : 1;   // experiments: 0 = body-level chains through the column store (Env::chain_lds)
+        static const int chain = getenv("MW_CHAIN_LDS") ? atoi(getenv("MW_CHAIN_LDS")) : 2;   // experiments: cap on Env::chain_lds (0 = body-level chains through the column store, 1 = only the slots in front of the rows + composite inertias)
         hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), bytes, stream(), f, bytes / 4, chain);
         hip_check(hipGetLastError(), "kernel launch");
     }
