@@ -101,7 +101,7 @@ def test_gpu_task_fp32_close_to_reference_trace(gpulib, task):
 
 
 @pytest.mark.parametrize("task,precision", [(t, "fp64") for t in ("box-close-v3", "door-unlock-v3", "shelf-place-v3", "sweep-into-v3", "hammer-v3",
-                                                               "plate-slide-v3", "stick-pull-v3", "reach-v3")]
+                                                               "plate-slide-v3", "stick-pull-v3", "reach-v3", "assembly-v3", "basketball-v3", "peg-insert-side-v3", "door-lock-v3")]
                          + [(t, "fp32") for t in ("box-close-v3", "hammer-v3", "stick-pull-v3")])
 def test_gpu_lanes_per_block_invariance(gpulib, task, precision, monkeypatch):
     """The mapping of environments to lanes (64 per wave, no sub-lanes ... 8 per wave, 8 cooperating sub-lanes each) must

@@ -84,7 +84,6 @@ def test_host_build_output_is_self_consistent(hostsim, task, precision):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp64", "fp32"])
-@pytest.mark.parametrize("task", TASKS)
+@pytest.mark.parametrize("task,precision", [(t, "fp64") for t in T.supported_tasks()] + [(t, "fp32") for t in TASKS])          # (round 2: 12 tasks)
 def test_gpu_output_is_self_consistent(gpulib, task, precision):
     check_invariants(gpulib, task, precision, every=32, n_read=1)          # (column reads cross the bus element by element)

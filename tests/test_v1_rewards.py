@@ -65,15 +65,20 @@ def test_v2_library_refuses_nothing_and_v1_is_a_separate_build():
     assert os.path.basename(native.LIB_PATH_V1) == "libmwgpu_v1.so" and native.LIB_PATH_V1 != native.LIB_PATH
 
 
+V1_GPU_FP32 = ["reach-v3", "button-press-v3", "door-open-v3", "push-v3", "pick-place-v3", "assembly-v3", "bin-picking-v3", "hammer-v3", "stick-pull-v3",
+               "basketball-v3"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("task", ["reach-v3", "button-press-v3", "door-open-v3", "push-v3", "pick-place-v3", "assembly-v3", "bin-picking-v3",
-                                  "hammer-v3", "stick-pull-v3", "basketball-v3"])
+@pytest.mark.parametrize("task", T.ALL_V3)
 def test_gpu_v1_reward_matches_reference_v1(task):
-    """the same transitions through libmwgpu_v1.so on the GPU, both precisions (fp32: success flags and coarse agreement)"""
+    """the same transitions through libmwgpu_v1.so on the GPU: all 50 tasks in fp64 (round 2: 10), ten of them also in fp32 (success
+    flags and coarse agreement)"""
     from metaworld_amd import native
     assert os.path.exists(native.LIB_PATH_V1), "libmwgpu_v1.so not built: run __graft_entry__.build()"
     lib = native.load("mw_", native.LIB_PATH_V1)
     dr, di, ns, _ = replay_v1(lib, task, "fp64")
     assert dr < REL_TOL.get(task, 1e-3) * 3 and ns <= 1, (task, dr, di, ns)
-    dr32, di32, ns32, G = replay_v1(lib, task, "fp32")
-    assert np.isfinite(dr32) and ns32 <= max(2, len(G["reward"]) // 20), (task, dr32, ns32)
+    if task in V1_GPU_FP32:
+        dr32, di32, ns32, G = replay_v1(lib, task, "fp32")
+        assert np.isfinite(dr32) and ns32 <= max(2, len(G["reward"]) // 20), (task, dr32, ns32)
