@@ -14,6 +14,7 @@ MW_VERBOSE=1 MW_MIX_NPZ=$O/mix_timing_fp64.npz MW_LIB=libmwgpu_timing.so timeout
 MW_MAX_ENVS=32768 timeout 900 python tools/experiments/config_table.py fp64 > $O/config_table_fp64.txt 2>&1
 MW_MAX_ENVS=16384 timeout 600 python tools/experiments/config_table.py fp32 > $O/config_table_fp32.txt 2>&1
 timeout 900 python tools/policy_gate_gpu.py fp64 > $O/policy_gate_gpu_fp64.txt 2>&1
+timeout 900 python tools/policy_gate_gpu.py fp32 > $O/policy_gate_gpu_fp32.txt 2>&1
 tail -n 3 $O/pytest_gpu.txt
 grep -h -o '"value": [0-9.]*' $O/bench_default.txt | head -3
 tail -n 12 $O/config_table_fp64.txt
