@@ -257,34 +257,59 @@ MW_HD int capsule_capsule(const Shape<T>& a, const Shape<T>& b, T margin, Hit<T>
     return hit_sphere_sphere(a.pos + ua * s, a.size[0], b.pos + ub * t, b.size[0], margin, h);
 }
 
-// keep the part of the polygon with pn.x <= pd
+// Two polygons (source / destination of a clipping pass) of up to POLY_CAP vertices.  The vertex indices are run-time values, so
+// plain arrays live in scratch memory, and a clipping pass is a chain of dependent scratch round trips (~40 per box-box call:
+// the stage's per-branch clocks put a box-box call at 50-60 k cycles, and most waves have one in every dynamics evaluation).
+// With a thread-private scratchpad slice (Env::tls) the polygons live in LDS instead; same values in the same order.
+constexpr int POLY_CAP = 10;
 template <typename T>
-MW_HD int clip_poly(V3<T>* poly, int n, V3<T> pn, T pd) {
-    V3<T> out[16];
+struct PolyStore {
+    MW_LDS T* p;          // null: the local arrays
+    int stride;
+    V3<T> loc[2][16];
+    MW_HD V3<T> get(int w, int i) const {
+        if (p) { const int o = (w * POLY_CAP + i) * 3; return {p[o * stride], p[(o + 1) * stride], p[(o + 2) * stride]}; }
+        return loc[w][i];
+    }
+    MW_HD void set(int w, int i, V3<T> v) {
+        if (p) { const int o = (w * POLY_CAP + i) * 3; p[o * stride] = v.x; p[(o + 1) * stride] = v.y; p[(o + 2) * stride] = v.z; }
+        else loc[w][i] = v;
+    }
+};
+// keep the part of polygon `src` with pn.x <= pd; the result goes to polygon 1 - src
+template <typename T>
+MW_HD int clip_poly(PolyStore<T>& ps, int src, int n, V3<T> pn, T pd) {
+    const int cap = ps.p ? POLY_CAP : 16;
     int mcount = 0;
     for (int i = 0; i < n; i++) {
-        const V3<T> a = poly[i], b = poly[(i + 1) % n];
+        const V3<T> a = ps.get(src, i), b = ps.get(src, (i + 1) % n);
         const T da = dot(pn, a) - pd, db = dot(pn, b) - pd;
-        if (da <= 0) out[mcount++] = a;
-        if ((da < 0 && db > 0) || (da > 0 && db < 0)) { out[mcount++] = a + (b - a) * (da / (da - db)); }
-        if (mcount >= 15) break;
+        if (da <= 0) ps.set(1 - src, mcount++, a);
+        if ((da < 0 && db > 0) || (da > 0 && db < 0)) { ps.set(1 - src, mcount++, a + (b - a) * (da / (da - db))); }
+        if (mcount >= cap - 1) break;          // (a quadrilateral clipped by four half planes has at most eight vertices)
     }
-    for (int i = 0; i < mcount; i++) poly[i] = out[i];
     return mcount;
 }
 
+// element k of a 3-array held in registers (k is a run-time value: a dynamically indexed ARRAY would be placed in scratch memory)
+template <typename V> MW_HD V sel3(const V& a0, const V& a1, const V& a2, int k) { return k == 0 ? a0 : (k == 1 ? a1 : a2); }
+
 template <typename T>
-MW_HD int box_box(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, int maxh) {
-    V3<T> axA[3], axB[3];
-    for (int k = 0; k < 3; k++) { axA[k] = col(A.mat, k); axB[k] = col(B.mat, k); }
+MW_HD int box_box(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, int maxh, MW_LDS T* tls, int tls_stride) {
+    // (every small array below is only ever indexed by compile-time constants after unrolling, or read through sel3: the axes,
+    //  half sizes and the reference / incident box then stay in registers)
+    const V3<T> axA[3] = {col(A.mat, 0), col(A.mat, 1), col(A.mat, 2)}, axB[3] = {col(B.mat, 0), col(B.mat, 1), col(B.mat, 2)};
+    const T szA[3] = {A.size[0], A.size[1], A.size[2]}, szB[3] = {B.size[0], B.size[1], B.size[2]};
     const V3<T> t = B.pos - A.pos;
     T bestsep = T(-1e30);
     V3<T> bestn{1, 0, 0};
     int bestcode = -1;
+#pragma unroll
     for (int i = 0; i < 6; i++) {
-        const V3<T> Lx = i < 3 ? axA[i] : axB[i - 3];
+        const V3<T> Lx = i < 3 ? axA[i < 3 ? i : 0] : axB[i < 3 ? 0 : i - 3];
         T ra = 0, rb = 0;
-        for (int k = 0; k < 3; k++) { ra += A.size[k] * mw_abs(dot(axA[k], Lx)); rb += B.size[k] * mw_abs(dot(axB[k], Lx)); }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { ra += szA[k] * mw_abs(dot(axA[k], Lx)); rb += szB[k] * mw_abs(dot(axB[k], Lx)); }
         const T tl = dot(t, Lx), sep = mw_abs(tl) - ra - rb;
         if (sep > margin) return 0;
         if (sep > bestsep) { bestsep = sep; bestcode = i; bestn = Lx * (tl >= 0 ? T(1) : T(-1)); }
@@ -292,62 +317,80 @@ MW_HD int box_box(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, int
     T edgesep = T(-1e30);
     V3<T> edgen{1, 0, 0};
     int ei = -1, ej = -1;
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) {
             V3<T> Lx = cross(axA[i], axB[j]);
             const T len = norm(Lx);
             if (len < T(1e-6)) continue;
             Lx = Lx * (1 / len);
             T ra = 0, rb = 0;
-            for (int k = 0; k < 3; k++) { ra += A.size[k] * mw_abs(dot(axA[k], Lx)); rb += B.size[k] * mw_abs(dot(axB[k], Lx)); }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { ra += szA[k] * mw_abs(dot(axA[k], Lx)); rb += szB[k] * mw_abs(dot(axB[k], Lx)); }
             const T tl = dot(t, Lx), sep = mw_abs(tl) - ra - rb;
             if (sep > margin) return 0;
             if (sep > edgesep) { edgesep = sep; ei = i; ej = j; edgen = Lx * (tl >= 0 ? T(1) : T(-1)); }
         }
     if (ei >= 0 && edgesep > bestsep + T(1e-6) + T(0.05) * mw_abs(bestsep)) {
         V3<T> pa = A.pos, pb = B.pos;
+#pragma unroll
         for (int k = 0; k < 3; k++) {
-            if (k != ei) pa = pa + axA[k] * ((dot(axA[k], edgen) > 0 ? T(1) : T(-1)) * A.size[k]);
-            if (k != ej) pb = pb + axB[k] * ((dot(axB[k], edgen) > 0 ? T(-1) : T(1)) * B.size[k]);
+            if (k != ei) pa = pa + axA[k] * ((dot(axA[k], edgen) > 0 ? T(1) : T(-1)) * szA[k]);
+            if (k != ej) pb = pb + axB[k] * ((dot(axB[k], edgen) > 0 ? T(-1) : T(1)) * szB[k]);
         }
-        const V3<T> ua = axA[ei], ub = axB[ej], w = pa - pb;
+        const V3<T> ua = sel3(axA[0], axA[1], axA[2], ei), ub = sel3(axB[0], axB[1], axB[2], ej), w = pa - pb;
+        const T sa = sel3(szA[0], szA[1], szA[2], ei), sb = sel3(szB[0], szB[1], szB[2], ej);
         const T ab = dot(ua, ub), aw = dot(ua, w), bw = dot(ub, w), det = 1 - ab * ab;
-        const T s = mw_clamp((ab * bw - aw) / det, -A.size[ei], A.size[ei]);
-        const T u = mw_clamp((bw - ab * aw) / det, -B.size[ej], B.size[ej]);
+        const T s = mw_clamp((ab * bw - aw) / det, -sa, sa);
+        const T u = mw_clamp((bw - ab * aw) / det, -sb, sb);
         h->dist = edgesep; h->normal = edgen; h->pos = ((pa + ua * s) + (pb + ub * u)) * T(0.5);
         return 1;
     }
     const bool refA = bestcode < 3;
-    const Shape<T>& Rf = refA ? A : B;
-    const Shape<T>& In = refA ? B : A;
-    const V3<T>* axR = refA ? axA : axB;
-    const V3<T>* axI = refA ? axB : axA;
+    // reference (R) and incident (I) box by value
+    V3<T> axR[3], axI[3];
+    T szR[3], szI[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        axR[k] = refA ? axA[k] : axB[k]; axI[k] = refA ? axB[k] : axA[k];
+        szR[k] = refA ? szA[k] : szB[k]; szI[k] = refA ? szB[k] : szA[k];
+    }
+    const V3<T> posR = refA ? A.pos : B.pos, posI = refA ? B.pos : A.pos;
     const int ra_ = bestcode % 3;
     const V3<T> n = refA ? bestn : -bestn;   // reference-face normal toward the incident box
     int ia = 0;
     T bd = 0;
+#pragma unroll
     for (int k = 0; k < 3; k++) { const T dd = mw_abs(dot(axI[k], n)); if (dd > bd) { bd = dd; ia = k; } }
-    const T sgn = dot(axI[ia], n) > 0 ? T(-1) : T(1);
-    const V3<T> fc = In.pos + axI[ia] * (sgn * In.size[ia]);
+    const V3<T> axIa = sel3(axI[0], axI[1], axI[2], ia);
+    const T sgn = dot(axIa, n) > 0 ? T(-1) : T(1);
+    const V3<T> fc = posI + axIa * (sgn * sel3(szI[0], szI[1], szI[2], ia));
     const int i1 = (ia + 1) % 3, i2 = (ia + 2) % 3;
-    V3<T> poly[16];
+    const V3<T> axI1 = sel3(axI[0], axI[1], axI[2], i1), axI2 = sel3(axI[0], axI[1], axI[2], i2);
+    const T szI1 = sel3(szI[0], szI[1], szI[2], i1), szI2 = sel3(szI[0], szI[1], szI[2], i2);
+    PolyStore<T> ps;
+    ps.p = tls; ps.stride = tls_stride;
+    int src = 0;
     for (int c = 0; c < 4; c++) {
         const T s1 = (c == 0 || c == 3) ? T(-1) : T(1), s2 = c < 2 ? T(-1) : T(1);
-        poly[c] = fc + axI[i1] * (s1 * In.size[i1]) + axI[i2] * (s2 * In.size[i2]);
+        ps.set(src, c, fc + axI1 * (s1 * szI1) + axI2 * (s2 * szI2));
     }
     int np = 4;
     const int r1 = (ra_ + 1) % 3, r2 = (ra_ + 2) % 3;
     for (int side = 0; side < 4 && np > 0; side++) {
         const int ax = side < 2 ? r1 : r2;
-        const V3<T> pn = axR[ax] * ((side & 1) ? T(-1) : T(1));
-        np = clip_poly(poly, np, pn, dot(pn, Rf.pos) + Rf.size[ax]);
+        const V3<T> pn = sel3(axR[0], axR[1], axR[2], ax) * ((side & 1) ? T(-1) : T(1));
+        np = clip_poly(ps, src, np, pn, dot(pn, posR) + sel3(szR[0], szR[1], szR[2], ax));
+        src = 1 - src;
     }
-    const V3<T> rc = Rf.pos + n * Rf.size[ra_];
+    const V3<T> rc = posR + n * sel3(szR[0], szR[1], szR[2], ra_);
     int cnt = 0;
     for (int i = 0; i < np && cnt < maxh; i++) {
-        const T dist = dot(poly[i] - rc, n);
+        const V3<T> pt = ps.get(src, i);
+        const T dist = dot(pt - rc, n);
         if (dist > margin) continue;
-        h[cnt].dist = dist; h[cnt].normal = refA ? n : -n; h[cnt].pos = poly[i] - n * (T(0.5) * dist);
+        h[cnt].dist = dist; h[cnt].normal = refA ? n : -n; h[cnt].pos = pt - n * (T(0.5) * dist);
         cnt++;
     }
     return cnt;
@@ -726,9 +769,9 @@ MW_HD int box_face_sat(const Shape<T>& A, const Shape<T>& box, bool box_first, T
         const V3<T> v = col(box.mat, k) * T((f & 1) ? 1 : -1);
         const V3<T> p = support(A, -v);
         const T delta = dot(p - box.pos, v) - box.size[k];
+        if (delta > margin) return 0;          // a separating face axis: the answer is "no contact" whatever the other faces say (same result as completing the loop, up to five support evaluations fewer)
         if (delta > best) { best = delta; bk = k; bp = p; bv = v; }
     }
-    if (best > margin) return 0;
     const V3<T> locv = mulT(box.mat, bp - box.pos);
     const T loc[3] = {locv.x, locv.y, locv.z}, inset = best < 0 ? -best : T(0);
     for (int j = 0; j < 3; j++)
@@ -744,7 +787,7 @@ MW_HD int box_face_sat(const Shape<T>& A, const Shape<T>& box, bool box_first, T
 // `active`: the call itself is made by EVERY live lane of the wave (see collision()); lanes without a pair to test pass false
 // and leave through a branch inside this function.
 template <typename T, bool UNIFORM>
-MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h, bool active MW_CP_EXTRA) {
+MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, Hit<T>* h, bool active, MW_LDS T* tls, int tls_stride MW_CP_EXTRA) {
     if (!active) return 0;
     const Shape<T> ua = UNIFORM ? a_.uniform() : a_, ub = UNIFORM ? b_.uniform() : b_;
     if (UNIFORM) margin = mw_uniform(margin);
@@ -757,7 +800,7 @@ MW_STAGE_FN int collide_pair(const Shape<T>& a_, const Shape<T>& b_, T margin, H
     else if (t1 == G_SPHERE) n = sphere_x(ua, ub, margin, h);
     else if (t1 == G_CAPSULE && t2 == G_CAPSULE) n = capsule_capsule(ua, ub, margin, h);
     MW_CTICK(tp1)
-    if (t1 == G_BOX && t2 == G_BOX) { n = box_box(ua, ub, margin, h, 8); MW_CTICK(tp2) MW_CSTAT(0, tp1, tp2) }
+    if (t1 == G_BOX && t2 == G_BOX) { n = box_box(ua, ub, margin, h, 8, tls, tls_stride); MW_CTICK(tp2) MW_CSTAT(0, tp1, tp2) }
     MW_CTICK(tp3)
     const bool on_box = (t1 == G_CYLINDER || t1 == G_CAPSULE) && t2 == G_BOX;
     if (t1 == G_CAPSULE && t2 == G_BOX) n = capsule_box(ua, ub, margin, h);
@@ -899,7 +942,7 @@ MW_STAGE_FN void collision(const Env<T> e_) {
             const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
             const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
             Hit<T> h[16];
-            const int cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h, near MW_CP_PASS(tstat));
+            const int cnt = collide_pair<T, true>(make_shape(e, g1), make_shape(e, g2), margin, h, near, e.tls, e.tls_stride MW_CP_PASS(tstat));
             if (cnt <= 0) continue;
             append_contacts(e, p, cnt, h, ncon, maxcon);
             ncon += cnt;
@@ -966,7 +1009,7 @@ MW_STAGE_FN void collision(const Env<T> e_) {
                 const int p = act ? e.I(L.ipair + c0 + sub) : 0;           // (an idle sub-lane builds the shapes of pair 0 and discards them)
                 const int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
                 const T margin = mw_max(m.geom_margin[g1], m.geom_margin[g2]);
-                int cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)], act MW_CP_PASS(tstat));
+                int cnt = collide_pair<T, false>(make_shape(e, g1), make_shape(e, g2), margin, h[MW_SLOT(sub)], act, e.tls, e.tls_stride MW_CP_PASS(tstat));
                 if (cnt < 0) cnt = 0;
                 n[MW_SLOT(sub)] = cnt; pp[MW_SLOT(sub)] = p;
             }

@@ -125,6 +125,7 @@ constexpr int CON_STRIDE = 26;   // reals per contact record
 constexpr int CON_ISTRIDE = 4;   // ints per contact record
 constexpr int EFC_EXTRA = 11;    // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv, fri, info, state
 constexpr int SR_N = 9;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force, block list, aref; the row's Jacobian follows them
+constexpr int TLS_SLOTS = 60;    // thread-private scratchpad slots of the narrow phase: two polygons of up to 10 vertices (box-box face clipping)
 constexpr int IC_NBLK = 18;      // icount slot: number of constraint blocks (single rows / contact cones)
 constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand, 23 solver stalls
 constexpr int IC_DYN_VALID = 19;  // icount slot: 1 = contacts / constraint rows / solver output belong to the CURRENT qpos (see env_step)
@@ -247,6 +248,11 @@ struct Env {
     // rows -- dead until make_constraints fills them -- carry the chains' transients first (mw_phys.hpp: body frames in
     // kinematics, composite inertias in crb, body velocities / accelerations / forces in smooth_forces).  Same values either way.
     int lds_perm;      // slots in front of the rows (0 without chain_lds)
+    // THREAD-private scratchpad slice (slot k at tls[k * tls_stride]) for the narrow phase's polygon clipping, whose dynamically
+    // indexed arrays would otherwise live in scratch memory (one L2 round trip per access); it overlays the rows' slots, which are
+    // dead while the collision stage runs.  Null when the workgroup's scratchpad is too small (the arrays stay local then).
+    MW_LDS T* tls;
+    int tls_stride;
     int chain_lds;     // 0 = nothing of the above; 1 = the slots in front of the rows + the composite inertias (what fits a smaller share: 7 nv + nq + 10 nbody slots); 2 = all of it (+ 18 nbody slots)
 #if defined(MW_BOUNDS)   // debug build: every column-store access is range-checked; a violation is recorded and redirected to element 0
     unsigned nreal_b, nint_b;
@@ -272,6 +278,11 @@ struct Env {
         lds_perm = chain_lds ? 7 * nv_ + nq_ : 0;
         lds_rows = (words - lds_perm) / lds_w;
         if (sp.max_rows > 0 && lds_rows > sp.max_rows) lds_rows = sp.max_rows;
+        const int wave_words = (int)(sp.block_words * 4 / sizeof(T));          // slots of the whole workgroup
+        tls_stride = host ? 1 : 64;
+        tls = nullptr;
+        if (host ? words >= lds_perm + TLS_SLOTS : wave_words >= lds_perm * lpb + TLS_SLOTS * 64)
+            tls = (MW_LDS T*)sp.base + (host ? lds_perm : lds_perm * lpb + thread);
     }
     MW_HD void cache_layout(const Layout& L, int nv_) {
         nv = nv_; o_efcJ = L.efcJ; o_efcX = L.efcX; o_con = L.con; o_icon = L.icon; o_iefc = L.iefc; o_icount = L.icount; o_task = L.task;
@@ -283,7 +294,7 @@ struct Env {
         u.nv = mw_uniform(nv); u.o_efcJ = mw_uniform(o_efcJ); u.o_efcX = mw_uniform(o_efcX); u.o_con = mw_uniform(o_con);
         u.o_icon = mw_uniform(o_icon); u.o_iefc = mw_uniform(o_iefc); u.o_icount = mw_uniform(o_icount); u.o_task = mw_uniform(o_task);
         u.lds_rows = mw_uniform(lds_rows); u.lds_w = mw_uniform(lds_w); u.lds_stride = mw_uniform(lds_stride); u.nsub = mw_uniform(nsub);
-        u.lds_perm = mw_uniform(lds_perm); u.chain_lds = mw_uniform(chain_lds);
+        u.lds_perm = mw_uniform(lds_perm); u.chain_lds = mw_uniform(chain_lds); u.tls_stride = mw_uniform(tls_stride);
         return u;
     }
     MW_HD CModel<T>& model() const { return *(CModel<T>*)(unsigned long long)m; }

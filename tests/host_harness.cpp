@@ -141,7 +141,7 @@ struct Backend {
         // room for `rows` rows of the widest scene (Scratchpad::max_rows caps narrower ones) + the slots in front of the rows and the
         // chain transients of the widest scene (Env::chain_lds; MW_CHAIN_LDS=0: body-level chains through the column store)
         static const int chain = std::getenv("MW_CHAIN_LDS") ? std::atoi(std::getenv("MW_CHAIN_LDS")) : 2;
-        const size_t slots = (size_t)rows * (mw::SR_N + mw::MAX_NV) + 8 * mw::MAX_NV + 2 + 18 * 64;
+        const size_t slots = (size_t)rows * (mw::SR_N + mw::MAX_NV) + 8 * mw::MAX_NV + 2 + 18 * 64 + mw::TLS_SLOTS;
         const int words = (int)slots * 2;
 #pragma omp parallel
         {
