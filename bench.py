@@ -247,6 +247,13 @@ def main(argv=None):
         env.ctx.comm_init(uid.cpu().numpy(), rank, world)
         gather_mode = "RCCL all-gather inside the library, per step, side stream (mw_step_resident_gather)" if on_gpu else \
             "host-harness shared-memory all-gather, per step (TEST)"
+    use_gather = world > 1
+    if world == 1 and on_gpu and os.environ.get("MW_COMM_FORCE_RCCL"):
+        # single-GPU box: a REAL one-rank RCCL communicator, so that the timed loop contains ncclAllGather per step on the side stream
+        # (what every rank does at N > 1); `config.comm` shows what RCCL reports for it
+        env.ctx.comm_init(env.ctx.comm_unique_id(), 0, 1)
+        use_gather = True
+        gather_mode = "RCCL all-gather inside the library, per step, side stream, ONE-rank communicator (MW_COMM_FORCE_RCCL)"
     prepare(env, args, rank)
 
     def barrier():
@@ -260,7 +267,7 @@ def main(argv=None):
     barrier()
     t0 = time.perf_counter()
     # K launches on the library's stream bracketed by HIP events; with > 1 rank the per-step all-gather is inside the loop
-    kernel_ms = env.ctx.step_resident_gather(args.steps) if world > 1 else env.ctx.step_resident(args.steps)
+    kernel_ms = env.ctx.step_resident_gather(args.steps) if use_gather else env.ctx.step_resident(args.steps)
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:

@@ -46,7 +46,7 @@ def test_scripted_policy_succeeds_on_device_code(hostsim, task):
     """Closed loop: the reference's scripted policies (metaworld/policies, unmodified) drive the DEVICE lane programs
     (host build, fp32 = the throughput precision) through the VectorEnv boundary, 5 goals per task; the reference's own
     gate is 80 % success (tests/metaworld/test_scripted_policies.py).  basketball is the one task whose policy also
-    fails on the oracle engine (profiles/r01_policy_gate_oracle.txt) and is only required to run."""
+    fails on the oracle engine (profiles/r02_policy_gate_oracle_50goals.txt) and is only required to run."""
     import warnings
     warnings.filterwarnings("ignore")
     from oracle import refshim
