@@ -127,6 +127,24 @@ def cpu_baseline(task_names, seconds=10.0):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ profile lookup
+def matching_profile(precision, workload, src_hash, profiles_dir=None):
+    """(summary dict, path) of the newest committed rocprofv3 PMC summary (tools/profile_bench.sh -> profiles/r*_mt50_<precision>_pmc.json)
+    that was taken on THIS workload with THESE device sources (content hash of csrc/ + include/mwgpu.h), or (None, None): counters of
+    another kernel are never quoted."""
+    import glob
+    d = profiles_dir or os.path.join(ROOT, "profiles")
+    for prof in sorted(glob.glob(os.path.join(d, f"r*_mt50_{precision}_pmc.json")), reverse=True):
+        try:
+            with open(prof) as f:
+                cand = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if cand.get("workload") == workload and cand.get("source_hash") == src_hash:
+            return cand, prof
+    return None, None
+
+
 # ------------------------------------------------------------------------------------------------ launcher
 def _free_port():
     s = socket.socket()
@@ -294,15 +312,9 @@ def main(argv=None):
         from metaworld_amd import native as _native
         src_hash = _native.source_hash()
         roofline["source_hash"] = src_hash
-        pj = None
-        import glob
-        for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_mt50_{args.precision}_pmc.json")), reverse=True):
-            with open(prof) as f:
-                cand = json.load(f)
-            if cand.get("workload") == workload and cand.get("source_hash") == src_hash:
-                pj = cand
-                roofline["profile"] = os.path.relpath(prof, ROOT)
-                break
+        pj, prof_path = matching_profile(args.precision, workload, src_hash)
+        if pj is not None:
+            roofline["profile"] = os.path.relpath(prof_path, ROOT)
         if pj is None:
             roofline["note"] += "; NO committed PMC profile matches these sources (source_hash): traffic / alu_issue not quoted"
         if pj is not None and world == 1:

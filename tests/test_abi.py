@@ -45,3 +45,27 @@ def test_every_entry_point_is_mapped_to_the_reference_in_integration_md():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     declared = set(re.findall(r"\b(mw_[a-z_]+)\s*\(", hdr))
     assert not [s for s in sorted(declared) if s not in doc]
+
+
+def test_bench_quotes_counters_only_from_a_profile_of_the_same_sources(tmp_path):
+    """bench.py's roofline.traffic / alu_issue come from a committed rocprofv3 summary ONLY if it was taken on the same workload with
+    the same device sources (content hash); anything else gives traffic = null (round 2 replayed a stale profile keyed by the
+    workload string)"""
+    import json
+    import bench
+    from metaworld_amd import native
+    h = native.source_hash()
+    assert len(h) == 16 and h == native.source_hash()
+    wl = "MT50 sync-vector, 4096 envs/GPU, fp64, random actions"
+    (tmp_path / "r02_mt50_fp64_pmc.json").write_text(json.dumps({"workload": wl, "fetch_bytes_per_launch": 1.0}))                      # no hash at all
+    (tmp_path / "r03_mt50_fp64_pmc.json").write_text(json.dumps({"workload": wl, "source_hash": "0" * 16}))                            # another tree
+    assert bench.matching_profile("fp64", wl, h, str(tmp_path)) == (None, None)
+    (tmp_path / "r03b_mt50_fp64_pmc.json").write_text(json.dumps({"workload": "other", "source_hash": h}))                            # another workload
+    assert bench.matching_profile("fp64", wl, h, str(tmp_path))[0] is None
+    (tmp_path / "r03a_mt50_fp64_pmc.json").write_text(json.dumps({"workload": wl, "source_hash": h, "fetch_bytes_per_launch": 2.0}))
+    pj, path = bench.matching_profile("fp64", wl, h, str(tmp_path))
+    assert pj["fetch_bytes_per_launch"] == 2.0 and path.endswith("r03a_mt50_fp64_pmc.json")
+    assert bench.matching_profile("fp32", wl, h, str(tmp_path)) == (None, None)
+    # the committed profiles of this tree: whichever matches must belong to these sources
+    real, _ = bench.matching_profile("fp64", wl, h)
+    assert real is None or real["source_hash"] == h
