@@ -21,9 +21,6 @@
 
 typedef struct {
     int type; const double *pos, *mat, *size; const double* vert; int nvert; double margin;
-    /* hill-climbing support for big hulls (metaworld_amd/mjcf.py add_mesh_graph): CSR adjacency of this mesh's
-       vertices (local ids), start candidates, and the vertex the previous support call on this shape ended at */
-    const int *nbradr, *nbr, *start; int hill, hint;
 } Shape;
 typedef struct { double dist, pos[3], normal[3]; } Hit;
 
@@ -38,22 +35,6 @@ static inline void addscl3(double* r, const double* a, const double* b, double s
 static inline void copy3(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
 static inline void scl3(double* r, const double* a, double s) { r[0] = a[0] * s; r[1] = a[1] * s; r[2] = a[2] * s; }
 static inline double norm3(const double* a) { return sqrt(dot3(a, a)); }
-/* cube-map cell of a direction (start vertex table of the hill-climbing support, metaworld_amd/mjcf.py add_mesh_graph):
-   face = 2 * (major axis) + (negative side), (u, v) = the two other components over |major|, HILL_GRID intervals each */
-#define HILL_GRID 8
-static inline int hill_cell(double x, double y, double z) {
-    double ax = fabs(x), ay = fabs(y), az = fabs(z), m, u, v, c;
-    int axis;
-    if (ax >= ay && ax >= az) { axis = 0; m = ax; c = x; u = y; v = z; }
-    else if (ay >= az) { axis = 1; m = ay; c = y; u = x; v = z; }
-    else { axis = 2; m = az; c = z; u = x; v = y; }
-    if (!(m > 0)) return 0;
-    double s = 0.5 * HILL_GRID / m;
-    int iu = (int)((u + m) * s), iv = (int)((v + m) * s);
-    iu = iu < 0 ? 0 : (iu > HILL_GRID - 1 ? HILL_GRID - 1 : iu);
-    iv = iv < 0 ? 0 : (iv > HILL_GRID - 1 ? HILL_GRID - 1 : iv);
-    return ((2 * axis + (c < 0 ? 1 : 0)) * HILL_GRID + iu) * HILL_GRID + iv;
-}
 static inline double normalize3(double* a) {
     double n = norm3(a);
     if (n < MINVAL) { a[0] = 1; a[1] = a[2] = 0; return 0; }
@@ -516,34 +497,20 @@ static void support(const Shape* s, const double* dir, double* out) {
         for (int k = 0; k < 3; k++) pl[k] = dl[k] >= -TIE ? s->size[k] : -s->size[k];
         break;
     case MJL_MESH: {
+        /* THE DEFINITION of a hull's support point, for every hull size: the vertices are scanned in index order and a vertex
+           replaces the best so far only if it is higher by more than TIE -- exact and near ties (a direction perpendicular to a
+           flat face or an edge, common: box faces against the flat faces of the arm's hulls) go to the LOWEST vertex index,
+           independent of any search path.  (Until round 4 hulls with more than 64 vertices were searched by a steepest-ascent
+           walk over the hull graph from a cube-map start vertex / the previous support vertex: its answer among tied vertices
+           depended on the path -- measured on the host build of the lane programs, 0.2-0.6 % of the support calls of
+           door-unlock / coffee-button / stick-pull end on another vertex of the same support VALUE than a scan.  The product
+           accelerates this definition with per-direction-cell vertex lists, metaworld_amd/mjcf.py add_mesh_cands; the oracle
+           needs no acceleration structure and shares none with it.) */
         int best = 0;
         double bd = -1e30;
-        if (s->hill) {
-            /* steepest-ascent walk over the hull graph, from the direction's cube-map cell (metaworld_amd/mjcf.py
-               add_mesh_graph) or the previous result on this shape, whichever is higher; strict improvement only (same rule as
-               csrc/mw_collide.hpp) */
-            int cur = s->start[hill_cell(dl[0], dl[1], dl[2])];
-            bd = dot3(s->vert + 3 * cur, dl);
-            if (s->hint >= 0) {
-                double hd = dot3(s->vert + 3 * s->hint, dl);
-                if (hd > bd) { bd = hd; cur = s->hint; }
-            }
-            for (int it = 0; it < s->nvert; it++) {
-                int nxt = cur;
-                for (int j = s->nbradr[cur]; j < s->nbradr[cur + 1]; j++) {
-                    double dd = dot3(s->vert + 3 * s->nbr[j], dl);
-                    if (dd > bd) { bd = dd; nxt = s->nbr[j]; }
-                }
-                if (nxt == cur) break;
-                cur = nxt;
-            }
-            ((Shape*)s)->hint = cur;
-            best = cur;
-        } else {
-            for (int i = 0; i < s->nvert; i++) {
-                double dd = dot3(s->vert + 3 * i, dl);
-                if (dd > bd + TIE) { bd = dd; best = i; }
-            }
+        for (int i = 0; i < s->nvert; i++) {
+            double dd = dot3(s->vert + 3 * i, dl);
+            if (dd > bd + TIE) { bd = dd; best = i; }
         }
         copy3(pl, s->vert + 3 * best);
         break;
@@ -826,17 +793,10 @@ static void make_shape(const MjlModel* m, const MjlData* d, int g, Shape* s) {
     s->size = m->geom_size + 3 * g;
     s->margin = 0;
     s->vert = NULL; s->nvert = 0;
-    s->nbradr = s->nbr = s->start = NULL; s->hill = 0; s->hint = -1;
     if (s->type == MJL_MESH) {
         int mi = m->geom_meshid[g];
         s->vert = m->mesh_vert + 3 * m->mesh_vertadr[mi];
         s->nvert = m->mesh_vertnum[mi];
-        if (m->mesh_hill && m->mesh_hill[mi]) {
-            s->hill = 1;
-            s->nbradr = m->mesh_nbradr + m->mesh_vertadr[mi];
-            s->nbr = m->mesh_nbr;
-            s->start = m->mesh_start + 6 * HILL_GRID * HILL_GRID * mi;
-        }
     }
 }
 

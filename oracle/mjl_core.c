@@ -83,7 +83,7 @@ static const Field FIELDS[] = {
     FR(dof_damping), FR(dof_invweight0), FR(qpos0), FI(geom_type), FI(geom_bodyid), FI(geom_meshid),
     FI(geom_contype), FI(geom_conaffinity), FI(geom_condim), FI(geom_priority), FR(geom_size), FR(geom_pos),
     FR(geom_quat), FR(geom_friction), FR(geom_solref), FR(geom_solimp), FR(geom_solmix), FR(geom_margin),
-    FR(geom_gap), FR(geom_rbound), FI(mesh_vertadr), FI(mesh_vertnum), FI(mesh_nbradr), FI(mesh_nbr), FI(mesh_start), FI(mesh_hill), FR(mesh_vert), FI(pair_geom),
+    FR(geom_gap), FR(geom_rbound), FI(mesh_vertadr), FI(mesh_vertnum), FR(mesh_vert), FI(pair_geom),
     FI(site_bodyid), FR(site_pos), FR(site_quat), FI(act_dofid), FI(act_qposid), FR(act_kp), FR(act_ctrlrange),
     FI(eq_body1), FI(eq_body2), FR(eq_solref), FR(eq_solimp), FR(eq_data),
 };

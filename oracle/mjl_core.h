@@ -52,7 +52,7 @@ typedef struct {
     int *geom_type, *geom_bodyid, *geom_meshid, *geom_contype, *geom_conaffinity, *geom_condim, *geom_priority;
     double *geom_size, *geom_pos, *geom_quat, *geom_friction, *geom_solref, *geom_solimp, *geom_solmix,
         *geom_margin, *geom_gap, *geom_rbound;
-    int *mesh_vertadr, *mesh_vertnum, *mesh_nbradr, *mesh_nbr, *mesh_start, *mesh_hill;
+    int *mesh_vertadr, *mesh_vertnum;
     double *mesh_vert;
     int *pair_geom;
     /* sites */

@@ -61,6 +61,11 @@ def lib():
     return _lib
 
 
+# acceleration tables of the product's hull support function (hull graph, start cube map, support cells: metaworld_amd/mjcf.py
+# add_mesh_graph / add_mesh_cands).  The oracle scans every hull vertex (mjl_collide.c support()) and takes none of them.
+PRODUCT_ONLY_ARRAYS = {"mesh_nbradr", "mesh_nbr", "mesh_start", "mesh_hill", "mesh_candadr", "mesh_cand"}
+
+
 class OracleModel:
     """Holds a C MjlModel built from a metaworld_amd.mjcf.Model."""
 
@@ -69,6 +74,8 @@ class OracleModel:
         self.src = model
         self.ptr = L.mjl_model_new()
         for k, v in model.arrays.items():
+            if k in PRODUCT_ONLY_ARRAYS:
+                continue
             if v.dtype.kind in "iu":
                 a = np.ascontiguousarray(v, dtype=np.int32)
                 rc = L.mjl_model_set_int(self.ptr, k.encode(), a.ctypes.data, a.size)
