@@ -20,24 +20,19 @@ struct Shape {
     V3<T> pos;
     M3<T> mat;
     T size[3];
-    CP<T> vert;
+    CP<T> vert;               // hull vertices (only plane_x scans them)
     int nvert;
     T margin;
-    // hill-climbing support for big hulls (metaworld_amd/mjcf.py add_mesh_graph): CSR adjacency of this mesh's vertices
-    // (local ids), the direction cube map of start vertices, and the vertex the previous support call on this shape ended at
-    CP<int> nbradr, nbr, start, nb8;
-    CP<T> nb8xyz, startxyz;   // first 8 neighbours of every vertex (ids / coordinates), coordinates of the start vertices
-    int hill;
-    mutable int hint;
+    // hull (G_MESH): the support cells of this mesh (Model::mesh_cellxyz / mesh_cellovf / mesh_ovfxyz, see mw_common.hpp)
+    CP<T> cellxyz, ovfxyz;
+    CP<int> cellovf;
     // everything except pos / mat is a model constant of the (wave-uniform) geom pair being tested
     MW_HD Shape uniform() const {
         Shape u = *this;
         u.type = mw_uniform(type); u.nvert = mw_uniform(nvert); u.margin = mw_uniform(margin);
         u.vert = (CP<T>)mw_uniform((unsigned long long)vert);
-        u.nbradr = (CP<int>)mw_uniform((unsigned long long)nbradr); u.nbr = (CP<int>)mw_uniform((unsigned long long)nbr);
-        u.start = (CP<int>)mw_uniform((unsigned long long)start); u.hill = mw_uniform(hill);
-        u.nb8 = (CP<int>)mw_uniform((unsigned long long)nb8); u.nb8xyz = (CP<T>)mw_uniform((unsigned long long)nb8xyz);
-        u.startxyz = (CP<T>)mw_uniform((unsigned long long)startxyz);
+        u.cellxyz = (CP<T>)mw_uniform((unsigned long long)cellxyz); u.ovfxyz = (CP<T>)mw_uniform((unsigned long long)ovfxyz);
+        u.cellovf = (CP<int>)mw_uniform((unsigned long long)cellovf);
         for (int k = 0; k < 3; k++) u.size[k] = mw_uniform(size[k]);
         return u;
     }
@@ -397,22 +392,24 @@ MW_HD int box_box(const Shape<T>& A, const Shape<T>& B, T margin, Hit<T>* h, int
 }
 
 // cube-map cell of a direction: face = 2 * (major axis) + (negative side), (u, v) = the two other components over |major|,
-// each cut into HILL_GRID intervals -- the same rule in metaworld_amd/mjcf.py (table build) and oracle/mjl_collide.c
-constexpr int HILL_GRID = 8;
+// each cut into CELL_GRID intervals (metaworld_amd/hullcells.py cell_of).  Computed in SINGLE precision in both contexts (one
+// v_rcp_f32 instead of a double-precision division): the lists of neighbouring cells overlap by far more than this rounding
+// (hullcells.py CELL_SLACK), so a direction on a cell border gets the same support point from either cell.
 template <typename T>
-MW_HD int hill_cell(T x, T y, T z) {
-    const T ax = mw_abs(x), ay = mw_abs(y), az = mw_abs(z);
+MW_HD int support_cell(T x_, T y_, T z_) {
+    const float x = (float)x_, y = (float)y_, z = (float)z_;
+    const float ax = mw_abs(x), ay = mw_abs(y), az = mw_abs(z);
     int axis;
-    T m, u, v, c;
+    float m, u, v, c;
     if (ax >= ay && ax >= az) { axis = 0; m = ax; c = x; u = y; v = z; }
     else if (ay >= az) { axis = 1; m = ay; c = y; u = x; v = z; }
     else { axis = 2; m = az; c = z; u = x; v = y; }
     if (!(m > 0)) return 0;
-    const T s = T(0.5) * HILL_GRID / m;
+    const float s = (0.5f * CELL_GRID) * mw_rcp_f32(m);
     int iu = (int)((u + m) * s), iv = (int)((v + m) * s);
-    iu = iu < 0 ? 0 : (iu > HILL_GRID - 1 ? HILL_GRID - 1 : iu);
-    iv = iv < 0 ? 0 : (iv > HILL_GRID - 1 ? HILL_GRID - 1 : iv);
-    return ((2 * axis + (c < 0 ? 1 : 0)) * HILL_GRID + iu) * HILL_GRID + iv;
+    iu = iu < 0 ? 0 : (iu > CELL_GRID - 1 ? CELL_GRID - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > CELL_GRID - 1 ? CELL_GRID - 1 : iv);
+    return ((2 * axis + (c < 0 ? 1 : 0)) * CELL_GRID + iu) * CELL_GRID + iv;
 }
 
 // ------------------------------------------------------------ MPR on support functions
@@ -436,81 +433,46 @@ MW_HD V3<T> support(const Shape<T>& s, V3<T> dir) {
         pl = v3(dl.x >= -tie ? s.size[0] : -s.size[0], dl.y >= -tie ? s.size[1] : -s.size[1], dl.z >= -tie ? s.size[2] : -s.size[2]);
         break;
     case G_MESH: {
-        T bd = T(-1e30);
-        // (the coordinates of the best vertex so far travel with its index: they were loaded to compute its dot product, and
-        //  fetching them again at the end was one more dependent memory round trip per support call)
-        T bx = 0, by = 0, bz = 0;
-        if (s.hill) {
-            MW_COUNT(3)
-            // steepest-ascent walk over the hull graph (MuJoCo's mesh-graph support): from the previous result on this
-            // shape, else from the best of the fixed start candidates; strict improvement only.  An exhaustive scan
-            // of the 884-vertex gripper hull cost ~20k cycles per call; the walk visits a few dozen vertices.
-            // start: the cube-map cell of the direction (mjcf.py add_mesh_graph), or the previous call's result if that is higher
-            // One round trip per step: the start vertex comes with its coordinates (startxyz), and a vertex's first 8 neighbours
-            // with theirs (nb8 / nb8xyz, built at upload from the adjacency); only the ~7 % of vertices with more than 8
-            // neighbours go on through the adjacency lists.  Same comparisons in the same order as a walk over the lists.
-            const int cell = hill_cell(dl.x, dl.y, dl.z);
-            int cur = s.start[cell];
-            bx = s.startxyz[3 * cell]; by = s.startxyz[3 * cell + 1]; bz = s.startxyz[3 * cell + 2];
-            bd = bx * dl.x + by * dl.y + bz * dl.z;
-            if (s.hint >= 0) {
-                const int hv = s.hint;
-                const T hx = s.vert[3 * hv], hy = s.vert[3 * hv + 1], hz = s.vert[3 * hv + 2];
-                const T hd = hx * dl.x + hy * dl.y + hz * dl.z;
-                if (hd > bd) { bd = hd; cur = hv; bx = hx; by = hy; bz = hz; }
-            }
-            for (int it = 0; it < s.nvert; it++) {
-                MW_COUNT(4)
-                MW_PAIR_ADD(2, 1)
-                int nxt = cur;
-                const int j0 = s.nbradr[cur], j1 = s.nbradr[cur + 1];
-                {
-                    int id[8];
-                    T xx[8], yy[8], zz[8], dd[8];
+        // THE DEFINITION (oracle/mjl_collide.c support()): m = max over ALL hull vertices of v . dl, answer = the lowest vertex
+        // index within `tie` of m.  The list of the direction's cell holds, in ascending index order, every vertex that can be
+        // within tie of the maximum for any direction of the cell (metaworld_amd/hullcells.py), so the maximum over the list
+        // and the first list entry within tie of it are that answer.  The first CELL_K entries sit at a place computed from the
+        // direction alone (padded with copies of the last one, which change neither the maximum nor the first entry within
+        // tie): 3 CELL_K + 1 loads issued together, one round trip.  (Rounds 1-3: a steepest-ascent walk over the hull graph,
+        // 2-3 dependent round trips and ~700 instructions per call, with a path-dependent answer among tied vertices.)
+        MW_COUNT(3)
+        const int cell = support_cell(dl.x, dl.y, dl.z);
+        const int ovf = s.cellovf[cell];
+        CP<T> p = s.cellxyz + cell * (3 * CELL_K);
+        T xx[CELL_K], yy[CELL_K], zz[CELL_K], dd[CELL_K];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) id[q] = s.nb8[8 * cur + q];
+        for (int q = 0; q < CELL_K; q++) { xx[q] = p[3 * q]; yy[q] = p[3 * q + 1]; zz[q] = p[3 * q + 2]; }
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        xx[q] = s.nb8xyz[24 * cur + 3 * q]; yy[q] = s.nb8xyz[24 * cur + 3 * q + 1]; zz[q] = s.nb8xyz[24 * cur + 3 * q + 2];
-                        dd[q] = xx[q] * dl.x + yy[q] * dl.y + zz[q] * dl.z;
-                    }
+        for (int q = 0; q < CELL_K; q++) dd[q] = xx[q] * dl.x + yy[q] * dl.y + zz[q] * dl.z;
+        T m = dd[0];
 #pragma unroll
-                    for (int q = 0; q < 8; q++)
-                        if (j0 + q < j1 && dd[q] > bd) { bd = dd[q]; nxt = id[q]; bx = xx[q]; by = yy[q]; bz = zz[q]; }
+        for (int q = 1; q < CELL_K; q++) m = mw_max(m, dd[q]);
+        if (ovf >= 0) {                                   // a long list (a few % of the cells): maximum over its further batches first
+            MW_COUNT(4)
+            CP<T> o = s.ovfxyz + (ovf >> 4) * (3 * CELL_K);
+            for (int b = 0; b < (ovf & 15); b++)
+#pragma unroll
+                for (int q = 0; q < CELL_K; q++) {
+                    const int k = 3 * (b * CELL_K + q);
+                    m = mw_max(m, o[k] * dl.x + o[k + 1] * dl.y + o[k + 2] * dl.z);
                 }
-                for (int jb = j0 + 8; jb < j1; jb += 8) {        // further neighbours in batches of 8: ids, then coordinates, issued together
-                    int id[8];
-                    T xx[8], yy[8], zz[8], dd[8];
+        }
+        const T thr = m - tie;
+        bool found = false;
+        T bx = xx[CELL_K - 1], by = yy[CELL_K - 1], bz = zz[CELL_K - 1];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) id[q] = s.nbr[jb + q < j1 ? jb + q : j1 - 1];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        xx[q] = s.vert[3 * id[q]]; yy[q] = s.vert[3 * id[q] + 1]; zz[q] = s.vert[3 * id[q] + 2];
-                        dd[q] = xx[q] * dl.x + yy[q] * dl.y + zz[q] * dl.z;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; q++)
-                        if (jb + q < j1 && dd[q] > bd) { bd = dd[q]; nxt = id[q]; bx = xx[q]; by = yy[q]; bz = zz[q]; }
-                }
-                if (nxt == cur) break;
-                cur = nxt;
-            }
-            s.hint = cur;
-        } else {
-            // exhaustive scan of a small hull (<= 64 vertices) in batches of 16: the 48 coordinate loads of a batch are issued
-            // back to back and waited for once (a 4-vertex batch spent most of a support call in 16 dependent round trips)
-            bx = s.vert[0]; by = s.vert[1]; bz = s.vert[2];          // (vertex 0 is the answer if no vertex beats -1e30 + tie: never, but keeps the old default)
-            for (int i0 = 0; i0 < s.nvert; i0 += 16) {
-                T xx[16], yy[16], zz[16], dd[16];
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int i = i0 + q < s.nvert ? i0 + q : s.nvert - 1;
-                    xx[q] = s.vert[3 * i]; yy[q] = s.vert[3 * i + 1]; zz[q] = s.vert[3 * i + 2];
-                    dd[q] = xx[q] * dl.x + yy[q] * dl.y + zz[q] * dl.z;
-                }
-#pragma unroll
-                for (int q = 0; q < 16; q++)
-                    if (i0 + q < s.nvert && dd[q] > bd + tie) { bd = dd[q]; bx = xx[q]; by = yy[q]; bz = zz[q]; }
+        for (int q = CELL_K - 1; q >= 0; q--)             // downwards, so that the FIRST entry within tie of the maximum is kept
+            if (dd[q] >= thr) { bx = xx[q]; by = yy[q]; bz = zz[q]; found = true; }
+        if (ovf >= 0 && !found) {
+            CP<T> o = s.ovfxyz + (ovf >> 4) * (3 * CELL_K);
+            for (int k = 0; k < 3 * CELL_K * (ovf & 15); k += 3) {
+                const T ox = o[k], oy = o[k + 1], oz = o[k + 2];
+                if (ox * dl.x + oy * dl.y + oz * dl.z >= thr) { bx = ox; by = oy; bz = oz; break; }
             }
         }
         pl = v3(bx, by, bz);
@@ -669,7 +631,7 @@ MW_HD int face_upgrade(const Shape<T>& c, const Shape<T>& box, Hit<T>* h, T marg
     pl.mat.m[3] = fy.y; pl.mat.m[4] = fz.y; pl.mat.m[5] = nf.y;
     pl.mat.m[6] = fy.z; pl.mat.m[7] = fz.z; pl.mat.m[8] = nf.z;
     pl.size[0] = pl.size[1] = pl.size[2] = 0; pl.vert = nullptr; pl.nvert = 0; pl.margin = 0;
-    pl.nbradr = nullptr; pl.nbr = nullptr; pl.start = nullptr; pl.nb8 = nullptr; pl.nb8xyz = nullptr; pl.startxyz = nullptr; pl.hill = 0; pl.hint = -1;
+    pl.cellxyz = nullptr; pl.ovfxyz = nullptr; pl.cellovf = nullptr;
     Hit<T> t[8];
     int cnt = 0;
     V3<T> cax = col(c.mat, 2);
@@ -733,20 +695,14 @@ MW_HD Shape<T> make_shape(const Env<T> e, int g) {
     s.mat = ld9(e, e.lay().geom_xmat + 9 * g);
     for (int k = 0; k < 3; k++) s.size[k] = m.geom_size[3 * g + k];
     s.margin = 0; s.vert = nullptr; s.nvert = 0;
-    s.nbradr = nullptr; s.nbr = nullptr; s.start = nullptr; s.nb8 = nullptr; s.nb8xyz = nullptr; s.startxyz = nullptr; s.hill = 0; s.hint = -1;
+    s.cellxyz = nullptr; s.ovfxyz = nullptr; s.cellovf = nullptr;
     if (s.type == G_MESH) {
         const int mi = m.geom_meshid[g];
         s.vert = m.mesh_vert + 3 * m.mesh_vertadr[mi];
         s.nvert = m.mesh_vertnum[mi];
-        if (m.mesh_hill[mi]) {
-            s.hill = 1;
-            s.nbradr = m.mesh_nbradr + m.mesh_vertadr[mi];
-            s.nbr = m.mesh_nbr;
-            s.start = m.mesh_start + 6 * HILL_GRID * HILL_GRID * mi;
-            s.startxyz = m.mesh_startxyz + 3 * 6 * HILL_GRID * HILL_GRID * mi;
-            s.nb8 = m.mesh_nb8 + 8 * m.mesh_vertadr[mi];
-            s.nb8xyz = m.mesh_nb8xyz + 24 * m.mesh_vertadr[mi];
-        }
+        s.cellxyz = m.mesh_cellxyz + mi * (CELL_N * 3 * CELL_K);
+        s.cellovf = m.mesh_cellovf + mi * CELL_N;
+        s.ovfxyz = m.mesh_ovfxyz;
     }
     return s;
 }

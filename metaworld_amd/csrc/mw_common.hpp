@@ -125,6 +125,9 @@ constexpr int CON_STRIDE = 26;   // reals per contact record
 constexpr int CON_ISTRIDE = 4;   // ints per contact record
 constexpr int EFC_EXTRA = 11;    // reals per constraint row besides J: pos, margin, R, D, aref, force, jar, Jv, fri, info, state
 constexpr int SR_N = 9;          // solver row scalars kept in the LDS scratchpad: D, jar, Jv, fri, info, state, force, block list, aref; the row's Jacobian follows them
+constexpr int CELL_GRID = 16;     // support cells of a hull: cube map of directions, 6 faces x CELL_GRID x CELL_GRID (metaworld_amd/hullcells.py GRID)
+constexpr int CELL_N = 6 * CELL_GRID * CELL_GRID;
+constexpr int CELL_K = 8;         // vertices of a cell's list stored at the cell's fixed place (Model::mesh_cellxyz); longer lists continue in Model::mesh_ovfxyz
 constexpr int TLS_SLOTS = 60;    // thread-private scratchpad slots of the narrow phase: two polygons of up to 10 vertices (box-box face clipping)
 constexpr int IC_NBLK = 18;      // icount slot: number of constraint blocks (single rows / contact cones)
 constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand, 23 solver stalls
@@ -172,7 +175,7 @@ struct Model {
     CP<int> jnt_type, jnt_bodyid, jnt_qposadr, jnt_dofadr, jnt_limited;
     CP<int> dof_bodyid, dof_jntid, dof_parentid;
     CP<int> geom_type, geom_bodyid, geom_meshid, geom_condim;
-    CP<int> mesh_vertadr, mesh_vertnum, mesh_nbradr, mesh_nbr, mesh_start, mesh_hill, pair_geom;
+    CP<int> mesh_vertadr, mesh_vertnum, pair_geom;
     CP<int> act_dofid, act_qposid, eq_body1, eq_body2, probe_body;
     // reals
     CP<T> body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia;
@@ -182,10 +185,14 @@ struct Model {
     CP<T> geom_margin, geom_gap, geom_rbound, geom_invweight0, geom_aabb;
     CP<T> mesh_vert, act_kp, act_ctrlrange, eq_solref, eq_solimp, eq_data, eq_invweight0;
     CP<T> probe_pos, probe_quat;
-    // derived at upload (DeviceModel): per hull vertex its first 8 neighbours (ids, coordinates) and the coordinates of the
-    // cube-map start vertices, so that one hill-climbing step is ONE round trip instead of three (adjacency -> ids -> coordinates)
-    CP<int> mesh_nb8;
-    CP<T> mesh_nb8xyz, mesh_startxyz;
+    // derived at upload (DeviceModel) from the support cells of the hulls (metaworld_amd/hullcells.py: per cube-map cell of
+    // directions, the ascending list of the vertices that can be the support vertex for a direction of the cell): the
+    // COORDINATES of the first CELL_K vertices of every list at a fixed place, mesh_cellxyz[(mesh * CELL_N + cell) * 3 CELL_K ...]
+    // (a short list is padded with copies of its last vertex), so that a support call is ONE memory round trip at an address
+    // computed from the direction alone.  The few longer lists continue in mesh_ovfxyz in batches of CELL_K (padded likewise):
+    // mesh_cellovf[mesh * CELL_N + cell] = -1 or (first batch) * 16 + (number of batches).
+    CP<int> mesh_cellovf;
+    CP<T> mesh_cellxyz, mesh_ovfxyz;
     CP<int> body_dofmask;   // derived at upload: bit i = dof i lies on the chain from body b to the root (nv <= 31)
     CP<int> dof_qposadr;    // derived at upload: the qpos element that dof i integrates into by qpos += h * qvel (slide / hinge joints, the three translational dofs of a free joint); -1 for the rotational dofs of a free joint
     Layout L;        // make_layout(sz)
@@ -421,6 +428,14 @@ inline void sub_sum_n(const Env<T>& e, U (*p)[N]) {
 // ----------------------------------------------------------------------------- small math
 template <typename T> MW_HD T mw_sqrt(T x) { return sqrt(x); }
 template <typename T> MW_HD T mw_abs(T x) { return x < 0 ? -x : x; }
+// approximate single-precision reciprocal (v_rcp_f32, 1 ulp); only where the result is binned, never in the dynamics
+MW_HD float mw_rcp_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
 template <typename T> MW_HD T mw_min(T a, T b) { return a < b ? a : b; }
 template <typename T> MW_HD T mw_max(T a, T b) { return a > b ? a : b; }
 template <typename T> MW_HD T mw_clamp(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }

@@ -80,7 +80,6 @@ struct DeviceModel {
             {"dof_bodyid", &Model<T>::dof_bodyid}, {"dof_jntid", &Model<T>::dof_jntid}, {"dof_parentid", &Model<T>::dof_parentid},
             {"geom_type", &Model<T>::geom_type}, {"geom_bodyid", &Model<T>::geom_bodyid}, {"geom_meshid", &Model<T>::geom_meshid},
             {"geom_condim", &Model<T>::geom_condim}, {"mesh_vertadr", &Model<T>::mesh_vertadr}, {"mesh_vertnum", &Model<T>::mesh_vertnum},
-            {"mesh_nbradr", &Model<T>::mesh_nbradr}, {"mesh_nbr", &Model<T>::mesh_nbr}, {"mesh_start", &Model<T>::mesh_start}, {"mesh_hill", &Model<T>::mesh_hill},
             {"pair_geom", &Model<T>::pair_geom}, {"act_dofid", &Model<T>::act_dofid}, {"act_qposid", &Model<T>::act_qposid},
             {"eq_body1", &Model<T>::eq_body1}, {"eq_body2", &Model<T>::eq_body2}, {"probe_body", &Model<T>::probe_body}};
         const RF rfs[] = {{"body_pos", &Model<T>::body_pos}, {"body_quat", &Model<T>::body_quat}, {"body_ipos", &Model<T>::body_ipos},
@@ -101,32 +100,36 @@ struct DeviceModel {
         std::vector<size_t> ioff, roff;
         for (auto& f : ifs) { ioff.push_back(ib.size()); const auto& v = d.I(f.name); ib.insert(ib.end(), v.begin(), v.end()); ib.push_back(0); }
         for (auto& f : rfs) { roff.push_back(rb.size()); const auto& v = d.Rr(f.name); for (double x : v) rb.push_back((T)x); rb.push_back(0); }
-        // derived hull tables (see Model::mesh_nb8): neighbour q < 8 of vertex v, padded with the last neighbour exactly like the
-        // batched walk in support() pads a short batch, so the walk compares the same values in the same order
-        size_t o_nb8, o_nb8xyz, o_startxyz, o_dofmask, o_dofqpos;
+        // derived hull tables (see Model::mesh_cellxyz): the coordinates of every support cell's vertex list at a fixed place
+        size_t o_cellovf, o_cellxyz, o_ovfxyz, o_dofmask, o_dofqpos;
         {
-            const auto &vadr = d.I("mesh_vertadr"), &vnum = d.I("mesh_vertnum"), &nadr = d.I("mesh_nbradr"), &nbr = d.I("mesh_nbr"),
-                       &hill = d.I("mesh_hill"), &start = d.I("mesh_start");
+            const auto &vadr = d.I("mesh_vertadr"), &vnum = d.I("mesh_vertnum"), &cadr = d.I("mesh_celladr"), &cid = d.I("mesh_cellid");
             const auto& vert = d.Rr("mesh_vert");
-            const size_t V = vert.size() / 3, nmesh = hill.size();
-            const size_t ncell = nmesh ? start.size() / nmesh : 0;
-            std::vector<int> nb8(V * 8 + 1, 0);
-            std::vector<T> nb8xyz(V * 24 + 1, T(0)), sxyz(nmesh * ncell * 3 + 1, T(0));
-            for (size_t mi = 0; mi < nmesh && mi < vadr.size(); mi++) {
-                if (!hill[mi]) continue;
-                const int va = vadr[mi];
-                for (int v = 0; v < vnum[mi]; v++) {
-                    const int j0 = nadr[va + v], j1 = nadr[va + v + 1];
-                    for (int q = 0; q < 8; q++) {
-                        const int id = j1 > j0 ? nbr[j0 + q < j1 ? j0 + q : j1 - 1] : v;
-                        nb8[(size_t)(va + v) * 8 + q] = id;
-                        for (int k = 0; k < 3; k++) nb8xyz[((size_t)(va + v) * 8 + q) * 3 + k] = (T)vert[3 * (size_t)(va + id) + k];
+            const size_t nmesh = vnum.size();
+            if (cadr.size() != nmesh * CELL_N + 1) throw std::runtime_error("mesh_celladr: expected nmesh * CELL_N + 1 entries (metaworld_amd/hullcells.py GRID != CELL_GRID?)");
+            std::vector<int> covf(nmesh * CELL_N + 1, -1);
+            std::vector<T> cxyz(nmesh * CELL_N * 3 * CELL_K + 1, T(0)), oxyz;
+            for (size_t mi = 0; mi < nmesh; mi++)
+                for (size_t c = 0; c < (size_t)CELL_N; c++) {
+                    const int j0 = cadr[mi * CELL_N + c], j1 = cadr[mi * CELL_N + c + 1];
+                    if (j1 <= j0) throw std::runtime_error("mesh_celladr: empty support cell");
+                    auto put = [&](T* dst, int j) {          // entry j of the list, the last entry beyond its end
+                        const int id = cid[j < j1 ? j : j1 - 1];
+                        if (id < 0 || id >= vnum[mi]) throw std::runtime_error("mesh_cellid: vertex id out of range");
+                        for (int k = 0; k < 3; k++) dst[k] = (T)vert[3 * (size_t)(vadr[mi] + id) + k];
+                    };
+                    for (int q = 0; q < CELL_K; q++) put(&cxyz[((mi * CELL_N + c) * CELL_K + q) * 3], j0 + q);
+                    if (j1 - j0 > CELL_K) {
+                        const int nb = (j1 - j0 - 1) / CELL_K;          // further batches
+                        if (nb > 15) throw std::runtime_error("support cell list longer than 16 batches");
+                        const size_t b0 = oxyz.size() / (3 * CELL_K);
+                        covf[mi * CELL_N + c] = (int)(b0 * 16 + nb);
+                        oxyz.resize(oxyz.size() + (size_t)nb * 3 * CELL_K);
+                        for (int q = 0; q < nb * CELL_K; q++) put(&oxyz[(b0 * CELL_K + q) * 3], j0 + CELL_K + q);
                     }
                 }
-                for (size_t c = 0; c < ncell; c++)
-                    for (int k = 0; k < 3; k++) sxyz[(mi * ncell + c) * 3 + k] = (T)vert[3 * (size_t)(va + start[mi * ncell + c]) + k];
-            }
-            o_nb8 = ib.size(); ib.insert(ib.end(), nb8.begin(), nb8.end());
+            oxyz.push_back(T(0));
+            o_cellovf = ib.size(); ib.insert(ib.end(), covf.begin(), covf.end());
             // chain mask of every body (see Model::body_dofmask): the Jacobian rows are then filled dof by dof without walking
             // dof_parentid (a chain of dependent loads per row and body)
             const auto &lastdof = d.I("body_lastdof"), &dpar = d.I("dof_parentid");
@@ -143,8 +146,8 @@ struct DeviceModel {
                 dq[i] = jtype[j] == J_FREE ? (k < 3 ? jqa[j] + k : -1) : jqa[j];
             }
             o_dofqpos = ib.size(); ib.insert(ib.end(), dq.begin(), dq.end());
-            o_nb8xyz = rb.size(); rb.insert(rb.end(), nb8xyz.begin(), nb8xyz.end());
-            o_startxyz = rb.size(); rb.insert(rb.end(), sxyz.begin(), sxyz.end());
+            o_cellxyz = rb.size(); rb.insert(rb.end(), cxyz.begin(), cxyz.end());
+            o_ovfxyz = rb.size(); rb.insert(rb.end(), oxyz.begin(), oxyz.end());
         }
         iblob = (int*)Backend::alloc(ib.size() * sizeof(int));
         rblob = (T*)Backend::alloc(rb.size() * sizeof(T));
@@ -155,11 +158,11 @@ struct DeviceModel {
         for (auto& f : ifs) { const int* q = iblob + ioff[k++]; ::memcpy(&(m.*(f.p)), &q, sizeof(q)); }
         k = 0;
         for (auto& f : rfs) { const T* q = rblob + roff[k++]; ::memcpy(&(m.*(f.p)), &q, sizeof(q)); }
-        { const int* q = iblob + o_nb8; ::memcpy(&m.mesh_nb8, &q, sizeof(q)); }
+        { const int* q = iblob + o_cellovf; ::memcpy(&m.mesh_cellovf, &q, sizeof(q)); }
         { const int* q = iblob + o_dofmask; ::memcpy(&m.body_dofmask, &q, sizeof(q)); }
         { const int* q = iblob + o_dofqpos; ::memcpy(&m.dof_qposadr, &q, sizeof(q)); }
-        { const T* q = rblob + o_nb8xyz; ::memcpy(&m.mesh_nb8xyz, &q, sizeof(q)); }
-        { const T* q = rblob + o_startxyz; ::memcpy(&m.mesh_startxyz, &q, sizeof(q)); }
+        { const T* q = rblob + o_cellxyz; ::memcpy(&m.mesh_cellxyz, &q, sizeof(q)); }
+        { const T* q = rblob + o_ovfxyz; ::memcpy(&m.mesh_ovfxyz, &q, sizeof(q)); }
         m.sz = d.sz;
         m.L = make_layout(d.sz);
         m.timestep = (T)d.timestep; m.tolerance = (T)d.tolerance; m.meaninertia = (T)d.meaninertia;
@@ -319,9 +322,9 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     int flags = e.I(e.lay().icount + 3);
     // canary (mw_common.hpp, sub_disagree): the sub-lanes of an environment must arrive here with bit-identical results
     {
-        int sig = canary_bits(reward) ^ canary_bits(success);
-        for (int k = 0; k < 18; k++) sig = sig * 31 + canary_bits(obs[k]);
-        if (sub_disagree(e, sig) || sub_disagree(e, flags)) flags |= ST_DIVERGED;
+        unsigned sig = (unsigned)(canary_bits(reward) ^ canary_bits(success));          // (unsigned: the hash wraps around)
+        for (int k = 0; k < 18; k++) sig = sig * 31u + (unsigned)canary_bits(obs[k]);
+        if (sub_disagree(e, (int)sig) || sub_disagree(e, flags)) flags |= ST_DIVERGED;
     }
     const int nstall = e.I(e.lay().icount + IC_SOLVER_STALL);
     bool bad = !mw_finite((double)reward);

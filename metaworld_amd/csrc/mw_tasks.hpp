@@ -184,9 +184,21 @@ enum { G_OBJ = 0, G_LPAD = 1, G_RPAD = 2 };
 
 // touching_object (sawyer_xyz_env.py:401-440): both pads have positive summed normal force against the geom.
 // Faithful to the reference's `efc_force[contact.efc_address]` including efc_address == -1 reading the LAST row.
+// the tasks (MT50 one-hot ids) whose evaluate_state calls touching_object: push 40, pick-place 30, push-back 42, push-wall 41,
+// pick-place-wall 28, sweep 47 / sweep-into 46 / soccer 37 / hand-insert 17 (sweepfam_eval), coffee-pull 9 / coffee-push 10,
+// shelf-place 45, stick-push 38 / stick-pull 39
+MW_HD bool task_touches(int kind) {
+    const unsigned long long m = (1ull << 40) | (1ull << 30) | (1ull << 42) | (1ull << 41) | (1ull << 28) | (1ull << 47) | (1ull << 46) |
+                                 (1ull << 37) | (1ull << 17) | (1ull << 9) | (1ull << 10) | (1ull << 45) | (1ull << 38) | (1ull << 39);
+    return kind >= 0 && kind < 64 && ((m >> kind) & 1ull);
+}
 template <typename T>
 MW_HD bool touching_object(const Env<T> e, const TaskDesc<T>& td, int objgeom) {
-    if (!e.I(e.lay().icount + IC_DYN_VALID)) forward_dynamics(e);   // env_step stopped its final mj_forward after the kinematics
+    // env_step stopped its final mj_forward after the kinematics and ran the second half for the whole wave iff some lane's task
+    // is listed in task_touches().  Arriving here without it means the list is missing this task: the result is still computed,
+    // but forward_dynamics (whose narrow phase is a non-inlined 256-VGPR callee) is then entered under a partial EXEC mask --
+    // the condition DESIGN.md 5 "register hazard" removes -- so the execution-model flag is raised and every test fails on it.
+    if (!e.I(e.lay().icount + IC_DYN_VALID)) { e.I(e.lay().icount + 3) |= ST_DIVERGED; forward_dynamics(e); }
     const int ncon = e.I(e.lay().icount), nefc = e.I(e.lay().icount + 1);
     T fl = 0, fr = 0;
     for (int c = 0; c < ncon; c++) {
@@ -1295,7 +1307,11 @@ MW_HD void env_step(const Env<T> e, const TaskDesc<T>& td, const T* act, T* obs3
     TK(e, TK_PATHLEN) += 1;
     kinematics(e);
     e.I(e.lay().icount + IC_DYN_VALID) = 0;
-    if (full_forward) forward_dynamics(e);
+    // WAVE-UNIFORM decision (ballot): a workgroup holds the environments of one SCENE, which several tasks can share (coffee-button
+    // next to coffee-pull / -push, ...); the lanes whose reward does not read contact forces run the second half along with the
+    // ones whose reward does (same wave time: the wave executes it anyway; no persistent state is touched), so that its
+    // non-inlined stages are entered by every live lane of the wave or by none.
+    if (mw_any(full_forward || task_touches(td.kind))) forward_dynamics(e);
     get_obs(e, td, obs39);
     clip_obs(td, obs39);
 #if defined(MW_REWARD_V1)

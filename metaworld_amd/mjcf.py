@@ -688,7 +688,7 @@ def compile_mjcf(path) -> Model:
     A["eq_solimp"] = np.array(eq_solimp).reshape(-1, 5)
     m.names = names
     _set_const(m)
-    add_mesh_graph(m.arrays)
+    add_mesh_cells(m.arrays)
     return m
 
 
@@ -829,68 +829,26 @@ def save_model(m: Model, path):
     np.savez_compressed(path, __meta__=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **m.arrays)
 
 
-HILL_MIN_VERTS = 64     # meshes with more hull vertices use hill-climbing support (like MuJoCo's mesh graphs)
-HILL_GRID = 8           # start table: a cube map of directions, 6 faces x HILL_GRID x HILL_GRID cells
-HILL_NSTART = 6 * HILL_GRID * HILL_GRID     # entry = the support vertex of the cell-centre direction (csrc/mw_collide.hpp hill_cell)
-
-
-def _hill_dirs():
-    """cell-centre directions of the start cube map.  Cell (face, iu, iv): face = 2 * (major axis) + (negative side); u, v = the two
-    other components (in x, y, z order) divided by |major component|, each cut into HILL_GRID intervals over [-1, 1]"""
-    dirs = []
-    for face in range(6):
-        ax, sg = face // 2, -1.0 if face % 2 else 1.0
-        o = [c for c in range(3) if c != ax]
-        for iu in range(HILL_GRID):
-            for iv in range(HILL_GRID):
-                d = np.zeros(3)
-                d[ax] = sg; d[o[0]] = (iu + 0.5) * 2.0 / HILL_GRID - 1.0; d[o[1]] = (iv + 0.5) * 2.0 / HILL_GRID - 1.0
-                dirs.append(d)
-    return np.array(dirs)
-
-
-def add_mesh_starts(A):
-    """the direction cube map of start vertices (mesh_start[mesh][cell]) for the hill-climbing hulls"""
-    dirs = _hill_dirs()
-    start = []
-    for mi in range(len(A["mesh_vertnum"])):
-        a, n = int(A["mesh_vertadr"][mi]), int(A["mesh_vertnum"][mi])
-        v = A["mesh_vert"][a:a + n]
-        start += [int(i) for i in np.argmax(v @ dirs.T, axis=0)] if A["mesh_hill"][mi] else [0] * HILL_NSTART
-    A["mesh_start"] = np.array(start if start else [0], dtype=np.int32)
-
-
-def add_mesh_graph(A):
-    """Hull-vertex adjacency (CSR over the global vertex index) + the direction cube map of start vertices for hill-climbing
-    support functions (a support call looks its direction's cell up and climbs from that vertex or from the previous call's
-    result, whichever is higher: 1-3 steps instead of ~10 from one of 32 coarse candidates).
-    Derived from the stored hull vertices, so it is identical wherever the compiled model is loaded."""
-    if "mesh_nbradr" in A:
-        if len(A["mesh_start"]) != HILL_NSTART * max(1, len(A["mesh_vertnum"])):          # a model file written with an older start table
-            add_mesh_starts(A)
-        return
-    from scipy.spatial import ConvexHull
+def add_mesh_cells(A):
+    """Support cells of every mesh hull (metaworld_amd/hullcells.py): per cube-map cell of directions the ascending list of hull
+    vertices that can be the support vertex -- within the tie tolerance -- for some direction of the cell; CSR over
+    (mesh, cell): `mesh_celladr[mesh * NCELL + cell]` .. `[+ 1]` into `mesh_cellid` (local vertex ids).  The narrow phase's hull
+    support function (csrc/mw_collide.hpp) scans its direction's list instead of all vertices: the same answer as the scan that
+    DEFINES the support point (oracle/mjl_collide.c support()), by construction.  Derived from the stored hull vertices."""
+    from .hullcells import NCELL, support_cells
     nmesh = len(A["mesh_vertnum"])
-    adr, nbr, hill = [0], [], []
+    if "mesh_celladr" in A and len(A["mesh_celladr"]) == nmesh * NCELL + 1:
+        return
+    adr, ids = [0], []
     for mi in range(nmesh):
         a, n = int(A["mesh_vertadr"][mi]), int(A["mesh_vertnum"][mi])
-        v = A["mesh_vert"][a:a + n]
-        adj = [set() for _ in range(n)]
-        if n > HILL_MIN_VERTS:
-            for t in ConvexHull(v).simplices:
-                for i in range(3):
-                    x, y = int(t[i]), int(t[(i + 1) % 3])
-                    adj[x].add(y); adj[y].add(x)
-        ok = np.array([len(s) > 0 for s in adj])
-        use = n > HILL_MIN_VERTS and ok.all()
-        hill.append(1 if use else 0)
-        for sset in adj:
-            nbr += sorted(sset) if use else []
-            adr.append(len(nbr))
-    A["mesh_nbradr"] = np.array(adr, dtype=np.int32)
-    A["mesh_nbr"] = np.array(nbr if nbr else [0], dtype=np.int32)
-    A["mesh_hill"] = np.array(hill if hill else [0], dtype=np.int32)
-    add_mesh_starts(A)
+        cadr, cid = support_cells(A["mesh_vert"][a:a + n])
+        adr += [len(ids) + int(x) for x in cadr[1:]]
+        ids += [int(x) for x in cid]
+    A["mesh_celladr"] = np.array(adr, dtype=np.int32)
+    A["mesh_cellid"] = np.array(ids if ids else [0], dtype=np.int32)
+    for k in ("mesh_nbradr", "mesh_nbr", "mesh_start", "mesh_hill"):        # tables of the hill-climbing support of rounds 1-3
+        A.pop(k, None)
 
 
 def load_model(path) -> Model:
@@ -903,5 +861,5 @@ def load_model(path) -> Model:
     for k in z.files:
         if k != "__meta__":
             m.arrays[k] = z[k]
-    add_mesh_graph(m.arrays)
+    add_mesh_cells(m.arrays)
     return m

@@ -8,8 +8,8 @@ from .mjcf import Model
 
 INT_FIELDS = ["body_parentid", "body_mocap", "body_jntadr", "body_jntnum", "body_lastdof", "jnt_type", "jnt_bodyid",
               "jnt_qposadr", "jnt_dofadr", "jnt_limited", "dof_bodyid", "dof_jntid", "dof_parentid", "geom_type",
-              "geom_bodyid", "geom_meshid", "geom_condim", "mesh_vertadr", "mesh_vertnum", "mesh_nbradr", "mesh_nbr",
-              "mesh_start", "mesh_hill", "pair_geom", "act_dofid",
+              "geom_bodyid", "geom_meshid", "geom_condim", "mesh_vertadr", "mesh_vertnum", "mesh_celladr", "mesh_cellid",
+              "pair_geom", "act_dofid",
               "act_qposid", "eq_body1", "eq_body2"]
 REAL_FIELDS = ["body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_inertia", "jnt_pos", "jnt_axis",
                "jnt_range", "jnt_stiffness", "jnt_springref", "jnt_solref", "jnt_solimp", "jnt_margin", "dof_armature",

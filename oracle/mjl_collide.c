@@ -497,21 +497,25 @@ static void support(const Shape* s, const double* dir, double* out) {
         for (int k = 0; k < 3; k++) pl[k] = dl[k] >= -TIE ? s->size[k] : -s->size[k];
         break;
     case MJL_MESH: {
-        /* THE DEFINITION of a hull's support point, for every hull size: the vertices are scanned in index order and a vertex
-           replaces the best so far only if it is higher by more than TIE -- exact and near ties (a direction perpendicular to a
-           flat face or an edge, common: box faces against the flat faces of the arm's hulls) go to the LOWEST vertex index,
-           independent of any search path.  (Until round 4 hulls with more than 64 vertices were searched by a steepest-ascent
-           walk over the hull graph from a cube-map start vertex / the previous support vertex: its answer among tied vertices
-           depended on the path -- measured on the host build of the lane programs, 0.2-0.6 % of the support calls of
-           door-unlock / coffee-button / stick-pull end on another vertex of the same support VALUE than a scan.  The product
-           accelerates this definition with per-direction-cell vertex lists, metaworld_amd/mjcf.py add_mesh_cands; the oracle
-           needs no acceleration structure and shares none with it.) */
+        /* THE DEFINITION of a hull's support point, for every hull size, in two passes over ALL vertices: m = the largest
+           v_i . d; the answer is the LOWEST vertex index with v_i . d >= m - TIE.  Exact and near ties (a direction
+           perpendicular to a flat face or an edge -- common: box faces against the flat faces of the arm's hulls) go to the
+           lowest index; the answer depends on nothing but the vertex set and the direction (no search path, no scan-order
+           chain: any subset of the vertices that contains every vertex within TIE of the maximum gives the same answer).
+           Until round 4 hulls with more than 64 vertices were searched by a steepest-ascent walk over the hull graph from a
+           cube-map start vertex / the previous support vertex, whose answer among tied vertices depended on the path --
+           measured on the host build of the lane programs, 0.2-0.6 % of the support calls of door-unlock / coffee-button /
+           stick-pull ended on another vertex of the same support VALUE than a scan.  The product accelerates this definition
+           with per-direction-cell vertex lists (metaworld_amd/hullcells.py); the oracle needs no acceleration structure and
+           shares none with it. */
         int best = 0;
-        double bd = -1e30;
+        double m = -1e30;
         for (int i = 0; i < s->nvert; i++) {
             double dd = dot3(s->vert + 3 * i, dl);
-            if (dd > bd + TIE) { bd = dd; best = i; }
+            if (dd > m) m = dd;
         }
+        for (int i = 0; i < s->nvert; i++)
+            if (dot3(s->vert + 3 * i, dl) >= m - TIE) { best = i; break; }
         copy3(pl, s->vert + 3 * best);
         break;
     }

@@ -61,9 +61,10 @@ def lib():
     return _lib
 
 
-# acceleration tables of the product's hull support function (hull graph, start cube map, support cells: metaworld_amd/mjcf.py
-# add_mesh_graph / add_mesh_cands).  The oracle scans every hull vertex (mjl_collide.c support()) and takes none of them.
-PRODUCT_ONLY_ARRAYS = {"mesh_nbradr", "mesh_nbr", "mesh_start", "mesh_hill", "mesh_candadr", "mesh_cand"}
+# acceleration tables of the product's hull support function (support cells: metaworld_amd/hullcells.py, mjcf.py add_mesh_cells;
+# the hull graph / start cube map of model files written before round 4).  The oracle scans every hull vertex
+# (mjl_collide.c support()) and takes none of them.
+PRODUCT_ONLY_ARRAYS = {"mesh_nbradr", "mesh_nbr", "mesh_start", "mesh_hill", "mesh_celladr", "mesh_cellid"}
 
 
 class OracleModel:

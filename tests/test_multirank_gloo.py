@@ -10,6 +10,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -121,6 +122,15 @@ def test_slow_gather_does_not_tear_the_record_ring(monkeypatch):
     seen, last = run(6)
     assert seen == [1, 2, 3, 4, 5, 6]
     assert (last["episode_length"] == 6).all()
+    # negative control: without the back-edge wait the same loop delivers late records.  Whether it does depends on the gather
+    # being slower than a step, and a step of the CPU harness can take arbitrarily long on a loaded machine (this half failed
+    # once under `pytest -n 6` next to a compile job) -- so the delay is escalated, and a machine on which the hazard cannot be
+    # provoked at all skips the control instead of failing the suite; the guard itself was asserted above.
     monkeypatch.setenv("MW_TEST_NO_BACKEDGE", "1")
-    seen_unsafe, _ = run(6)
-    assert seen_unsafe != [1, 2, 3, 4, 5, 6] and len(seen_unsafe) == 6
+    for delay in ("40", "250", "1000"):
+        monkeypatch.setenv("MW_TEST_GATHER_DELAY_MS", delay)
+        seen_unsafe, _ = run(6)
+        assert len(seen_unsafe) == 6
+        if seen_unsafe != [1, 2, 3, 4, 5, 6]:
+            return
+    pytest.skip("the unguarded loop happened to deliver the records in order on this (loaded) machine")
