@@ -38,7 +38,10 @@ sys.path.insert(0, ROOT)
 # (200 B) = 1.1 KB; fp64: 1.6 KB + the one-hot as float64 (400 B) = 2.0 KB.  Without one-hot (MT1): 0.9 / 1.6 KB.
 ALGO_BYTES_PER_ENV_STEP = {("fp32", True): 1100.0, ("fp64", True): 2000.0, ("fp32", False): 900.0, ("fp64", False): 1600.0}
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md
-N_SIMD, F_CLK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs of 16 lanes; a wave64 VALU instruction occupies its SIMD for 4 cycles
+N_SIMD, F_CLK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs
+# issue cost of one wave64 VALU instruction on its SIMD (MI355X_MICROARCH.md "Wave scheduling" + constants table): 2 cycles for
+# single-precision / integer / moves (v_fma_f32: 2), 4 for double precision (78.6 TFLOP/s fp64 = half rate)
+VALU_CYCLES_F64, VALU_CYCLES_OTHER = 4.0, 2.0
 HORIZON = 500                   # SawyerXYZEnv.max_path_length (sawyer_xyz_env.py:153) = TimeLimit default
 
 
@@ -174,6 +177,10 @@ def parse_args(argv=None):
     ap.add_argument("--allow-status", action="store_true", help="do not abort on capacity overflow / instability flags")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the launcher path (gloo: CPU test of the launcher)")
     ap.add_argument("--host-harness", action="store_true", help="TEST ONLY: drive the CPU harness instead of the GPU library")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive rates (VectorEnv.step with host numpy / device tensors) at N=1")
+    ap.add_argument("--no-saturation", action="store_true", help="skip the extra short run at 4x the envs at N=1")
+    ap.add_argument("--fixed-goals", action="store_true", help="auto-resets inside the timed loop re-use each env's look-ahead goal "
+                    "(rounds 1-3) instead of drawing a new task per reset like RandomTaskSelectWrapper")
     return ap.parse_args(argv)
 
 
@@ -195,12 +202,61 @@ def prepare(env, args, rank):
     env.ctx.upload_actions(acts)
     if not args.no_stagger:
         env.ctx.set_episode_phase((np.arange(N, dtype=np.int64) * 7919 % HORIZON).astype(np.int32))
-        env.ctx.step_resident(HORIZON)
-    env.ctx.step_resident(args.warmup)
+        resident(env, args, HORIZON)
+    resident(env, args, args.warmup)
     st = env.ctx.status(clear=True)
     if st["flags"] and not args.allow_status:          # the timed region continues from this state: an overflow here counts too
         raise RuntimeError(f"bench: the step kernel raised status flags {st} during the untimed pre-roll / warm-up (1/2 = constraint-row / "
                            "contact capacity exceeded, 4 = non-finite state)")
+
+
+def resident(env, args, nsteps, gather=False):
+    """nsteps launches on the resident actions; every auto-reset inside draws a new task from the sub-env's selection stream
+    (RandomTaskSelectWrapper.reset, metaworld/wrappers.py:116-119) through the device goal schedule -> kernel ms"""
+    if args.fixed_goals:
+        return env.ctx.step_resident_gather(nsteps) if gather else env.ctx.step_resident(nsteps)
+    return env.step_resident(nsteps, gather=gather)
+
+
+def boundary_rates(args, lib, local_rank, steps=40):
+    """env-steps/s THROUGH the boundary, same workload and batch as `value` (which leaves actions and outputs in HBM): fresh random
+    actions every step, everything `VectorEnv.step` returns materialised (obs, reward, flags, the dict of infos, final_obs /
+    final_info where an episode ended, the host-side task selection).  host_numpy = MetaWorldGpuVectorEnv.step (numpy in / out:
+    H2D actions + D2H of every output per step); torch_device = MetaWorldTorchVectorEnv.step (tensors in / out, only the done row
+    visits the host)."""
+    import torch
+    from metaworld_amd.torch_env import MetaWorldTorchVectorEnv
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    out = {}
+    for key, cls in (("host_numpy", MetaWorldGpuVectorEnv), ("torch_device", MetaWorldTorchVectorEnv)):
+        kw = dict(num_envs=args.envs, seed=42, use_one_hot=True, precision=args.precision, device_id=local_rank, lib=lib)
+        env = cls("MT1", "reach-v3", **{**kw, "use_one_hot": False}) if args.benchmark == "MT1" else cls(args.benchmark, **kw)
+        N = env.num_envs
+        env.reset()
+        env.ctx.upload_actions(np.random.default_rng(0).uniform(-1, 1, (64, N, 4)).astype(np.float32))
+        if not args.no_stagger:
+            env.ctx.set_episode_phase((np.arange(N, dtype=np.int64) * 7919 % HORIZON).astype(np.int32))
+            env.step_resident(HORIZON)
+        rng = np.random.default_rng(1)
+        acts = rng.uniform(-1, 1, (8, N, 4)).astype(np.float32)
+        if key == "torch_device":
+            acts = torch.from_numpy(acts).to(env.device)
+        for t in range(3):
+            env.step(acts[t % 8])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(steps):
+            o, r, te, tr, info = env.step(acts[t % 8])
+        if key == "torch_device":
+            float(r.sum().item())          # the learner reads what it got
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = env.ctx.status(clear=True)
+        env.close()
+        out[key] = {"value": N * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "status_flags": st["flags"]}
+    out["note"] = ("the same batch through VectorEnv.step instead of the resident loop: host_numpy = numpy actions in, every output + infos dict "
+                   "on the host (MetaWorldGpuVectorEnv); torch_device = CUDA tensors in / out (MetaWorldTorchVectorEnv); `value` itself is the resident loop")
+    return out
 
 
 def check_outputs(env, allow):
@@ -272,6 +328,13 @@ def main(argv=None):
         env.ctx.comm_init(env.ctx.comm_unique_id(), 0, 1)
         use_gather = True
         gather_mode = "RCCL all-gather inside the library, per step, side stream, ONE-rank communicator (MW_COMM_FORCE_RCCL)"
+    if use_gather:
+        # every rank must see a communicator that spans the job before anything is timed (a rank that silently fell back to a
+        # one-rank communicator would still produce a number)
+        ci = env.ctx.comm_info()
+        expect = world if (world > 1 or os.environ.get("MW_COMM_FORCE_RCCL")) else 1
+        if on_gpu and ci.get("comm_count") != expect:
+            raise RuntimeError(f"bench: rank {rank}: the RCCL communicator reports {ci} but the job has {world} ranks")
     prepare(env, args, rank)
 
     def barrier():
@@ -285,13 +348,18 @@ def main(argv=None):
     barrier()
     t0 = time.perf_counter()
     # K launches on the library's stream bracketed by HIP events; with > 1 rank the per-step all-gather is inside the loop
-    kernel_ms = env.ctx.step_resident_gather(args.steps) if use_gather else env.ctx.step_resident(args.steps)
+    kernel_ms = resident(env, args, args.steps, gather=use_gather)
     barrier()
     wall = time.perf_counter() - t0
+    per_rank_kernel_ms = [kernel_ms / args.steps]
     if dist is not None:
         tw = torch.tensor([wall], device="cuda" if on_gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
+        tk = torch.zeros(world, device="cuda" if on_gpu else "cpu", dtype=torch.float64)
+        tk[rank] = kernel_ms / args.steps
+        dist.all_reduce(tk, op=dist.ReduceOp.SUM)          # every rank's kernel ms per launch: an imbalance shows in the line
+        per_rank_kernel_ms = [float(x) for x in tk.cpu()]
     status = check_outputs(env, args.allow_status)
     book = env.ctx.gather_bookkeeping()          # [world, N] records of the last step on every rank
     assert book.shape == (world, N)
@@ -319,22 +387,26 @@ def main(argv=None):
             roofline["note"] += "; NO committed PMC profile matches these sources (source_hash): traffic / alu_issue not quoted"
         if pj is not None and world == 1:
                 roofline["traffic"] = pj["fetch_bytes_per_launch"] + pj["write_bytes_per_launch"]
-                # the bound that actually moves: VALU issue.  The SIMD is 16 lanes wide: a wave64 VALU instruction
-                # occupies it for 4 cycles (fp64 and unpacked fp32 alike; 78.6 TFLOP/s fp64 = 1024 SIMDs x 16 lanes x 2 x 2.4 GHz),
-                # so the chip issues at most N_SIMD x f_clk / 4 such wave-instructions per second.
+                # the bound that actually moves: VALU issue.  Per MI355X_MICROARCH.md a wave64 VALU instruction
+                # occupies its SIMD for 2 cycles, a double-precision one for 4; the SIMD-cycles the launch NEEDED for its VALU
+                # instructions over the SIMD-cycles it HAD (1024 SIMDs x kernel time x 2.4 GHz) is the issue fraction.
                 valu = pj["valu_wave_instr_per_launch"]
-                slots = N_SIMD * F_CLK_HZ / 4
+                f64 = pj.get("valu_f64_wave_instr_per_launch")
+                have = N_SIMD * F_CLK_HZ * per_launch_s
+                need = (f64 * VALU_CYCLES_F64 + (valu - f64) * VALU_CYCLES_OTHER) if f64 is not None else None
                 roofline["alu_issue"] = {
-                    "valu_wave_instr_per_env_step": valu / N, "achieved_wave_instr_per_s": valu / per_launch_s,
-                    "peak_wave_instr_per_s": slots, "frac": valu / per_launch_s / slots,
-                    "valu_f64_share": (pj["valu_f64_wave_instr_per_launch"] / valu) if pj.get("valu_f64_wave_instr_per_launch") else None,
+                    "valu_wave_instr_per_env_step": valu / N, "valu_wave_instr_per_launch": valu, "valu_f64_wave_instr_per_launch": f64,
+                    "simd_cycles_needed": need, "simd_cycles_available": have, "frac": (need / have) if need is not None else None,
+                    "cycles_per_wave64_valu": {"f64": VALU_CYCLES_F64, "other": VALU_CYCLES_OTHER},
+                    "valu_f64_share": (f64 / valu) if f64 else None,
                     "valu_active_frac_of_wave_cycles": pj.get("valu_active_frac"),
                     "lane_utilisation": pj.get("lane_utilisation"), "wave_slot_occupancy": pj.get("wave_slot_occupancy"),
                     "wait_frac": pj.get("wait_frac"),
-                    "note": "VALU wave-instructions per launch from the PMC pass of the same sources (SQ_INSTS_VALU) / this run's kernel time vs "
-                            "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction; valu_f64_share = SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 / SQ_INSTS_VALU; "
-                            "valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; lane_utilisation = envs / (waves x 64); "
-                            "wave_slot_occupancy = SQ_WAVE_CYCLES x 4 / (1024 SIMDs x kernel cycles); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
+                    "note": "frac = (f64 VALU wave-instructions x 4 + the other VALU wave-instructions x 2 cycles, MI355X_MICROARCH.md) / "
+                            "(1024 SIMDs x this run's kernel time x 2.4 GHz); counts from the PMC pass of the same sources (SQ_INSTS_VALU, "
+                            "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64); valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; "
+                            "lane_utilisation = envs / (waves x 64); wave_slot_occupancy = SQ_WAVE_CYCLES x 4 / (1024 SIMDs x kernel cycles); "
+                            "wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
         out = {"metric": "env-steps/sec (whole node) MT50 @4096 envs/GPU; achieved HBM GB/s vs peak", "value": value,
                "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -343,8 +415,11 @@ def main(argv=None):
                           "episode_phase": "all envs start together (early-episode window)" if args.no_stagger else
                           f"staggered uniformly over the {HORIZON}-step horizon (mw_set_episode_phase + untimed {HORIZON}-step pre-roll): "
                           "every window samples whole episodes incl. auto-resets",
+                          "task_resampling": "none: auto-resets re-use the env's look-ahead goal (--fixed-goals)" if args.fixed_goals else
+                          "every auto-reset inside the timed loop draws a new task from the sub-env's selection stream (RandomTaskSelectWrapper.reset, "
+                          "metaworld/wrappers.py:116-119) through the device goal schedule (mw_set_goal_schedule)",
                           "parallelism": f"dp{world} (independent env shards, no data-path collective)", "bookkeeping_gather": gather_mode,
-                          "comm": env.ctx.comm_info(),
+                          "comm": env.ctx.comm_info(), "per_rank_kernel_ms": per_rank_kernel_ms,
                           "status_flags": status},
                "roofline": roofline}
         if world == 1 and not args.no_extra_precision and on_gpu:
@@ -354,7 +429,7 @@ def main(argv=None):
             prepare(env2, args, rank)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            k2 = env2.ctx.step_resident(args.steps)
+            k2 = resident(env2, args, args.steps)
             torch.cuda.synchronize()
             w2 = time.perf_counter() - t1
             st2 = check_outputs(env2, args.allow_status)
@@ -364,6 +439,26 @@ def main(argv=None):
                         "note": "fp32 state and arithmetic: success flags exact, obs / reward within the single-precision contact-geometry "
                                 "floor (not 1e-5 on every task, DESIGN.md 6)" if other == "fp32" else "fp64 state and arithmetic"}
             env2.close()
+        if world == 1 and on_gpu and not args.no_boundary:
+            if not env.closed:
+                env.close()
+            out["boundary"] = boundary_rates(args, lib, local_rank)
+        if world == 1 and on_gpu and not args.no_saturation:
+            # does the chip saturate?  the same workload at 4x the batch, a short window (value stays the configuration of the metric)
+            if not env.closed:
+                env.close()
+            sat_args = argparse.Namespace(**{**vars(args), "envs": 4 * args.envs, "warmup": 10})
+            env3 = build_env(sat_args, args.precision, rank, world, local_rank, lib)
+            prepare(env3, sat_args, rank)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            k3 = resident(env3, sat_args, 100)
+            torch.cuda.synchronize()
+            w3 = time.perf_counter() - t3
+            st3 = check_outputs(env3, args.allow_status)
+            out["saturation"] = {"envs": env3.num_envs, "value": env3.num_envs * 100 / w3, "unit": "env-steps/s", "steps": 100,
+                                 "kernel_ms_per_launch": k3 / 100, "status_flags": st3}
+            env3.close()
         if world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl_task)
         print(json.dumps(out), flush=True)

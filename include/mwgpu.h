@@ -101,6 +101,13 @@ int mw_step_resident(mw_ctx* c, int nsteps, int action_steps, float* kernel_ms /
 /* the same loop with the per-step cross-rank bookkeeping gather inside it (mw_comm_init first when world_size > 1): launch k+1
  * overlaps the all-gather of step k on the side stream; returns after both streams have drained */
 int mw_step_resident_gather(mw_ctx* c, int nsteps, int action_steps, float* kernel_ms);
+/* RandomTaskSelectWrapper.reset (metaworld/wrappers.py:116-119: every reset of a sub-env draws a new task) INSIDE the resident
+ * loop: once a schedule is set, the k-th auto-reset of env i that happens in mw_step_resident / mw_step_resident_gather takes goal
+ * goal_schedule[min(k, K-1)][i] (k counts from 0 since this call) instead of the look-ahead goal of the last mw_step / mw_reset.
+ * The host draws the rows from the sub-envs' task-selection streams (metaworld_amd/vector_env.py step_resident) and, afterwards,
+ * reads how many rows every env consumed with mw_goal_schedule_pos to advance those streams.  NULL / K = 0 clears the schedule. */
+int mw_set_goal_schedule(mw_ctx* c, const int32_t* goal_schedule /*[K][N] or NULL*/, int K);
+int mw_goal_schedule_pos(mw_ctx* c, int32_t* consumed /*[N] out: auto-resets of env i since mw_set_goal_schedule*/);
 
 /* ---- device-resident boundary (SURVEY.md 8b "outputs_on_device"): the learner's policy runs on the same GPU, so actions and
  *      outputs never visit the host.  Every pointer is a DEVICE pointer the caller owns (a torch tensor's data_ptr()); a NULL

@@ -128,6 +128,8 @@ int MW_API(comm_init)(mw_ctx* c, const uint8_t* id, int rank, int world) {
 int MW_API(comm_info)(mw_ctx* c, int32_t* out) { MW_TRY(c, { MW_NEED_IMPL(c); if (!out) throw std::invalid_argument("comm_info: null output"); c->impl->comm_info(out); }); }
 int MW_API(gather_bookkeeping)(mw_ctx* c, mw_bookkeeping* out, int out_on_device) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->gather_bookkeeping(out, out_on_device); }); }
 int MW_API(set_episode_phase)(mw_ctx* c, const int32_t* elapsed) { MW_TRY(c, { MW_NEED_IMPL(c); if (!elapsed) throw std::invalid_argument("set_episode_phase: null argument"); c->impl->set_episode_phase(elapsed); }); }
+int MW_API(set_goal_schedule)(mw_ctx* c, const int32_t* schedule, int K) { MW_TRY(c, { MW_NEED_IMPL(c); if (K < 0 || (K > 0 && !schedule)) throw std::invalid_argument("set_goal_schedule: K rows need a schedule"); c->impl->set_goal_schedule(schedule, K); }); }
+int MW_API(goal_schedule_pos)(mw_ctx* c, int32_t* out) { MW_TRY(c, { MW_NEED_IMPL(c); if (!out) throw std::invalid_argument("goal_schedule_pos: null output"); c->impl->goal_schedule_pos(out); }); }
 int MW_API(status)(mw_ctx* c, int32_t* out, int clear) { MW_TRY(c, { MW_NEED_IMPL(c); if (!out) throw std::invalid_argument("status: null output"); c->impl->status(out, clear); }); }
 int MW_API(column_size)(mw_ctx* c, int env, const char* what) {
     try { MW_NEED_IMPL(c); return c->impl->layout_size(env, what); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }

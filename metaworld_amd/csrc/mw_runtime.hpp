@@ -197,6 +197,11 @@ struct IOPtrs {
     mw_bookkeeping* book;    // [N] packed per-step record for the cross-rank gather, or null
     int* status;             // [MW_STATUS_WORDS] context status: OR of the per-env flags, env-steps with row overflow / contact overflow / instability / sub-lane divergence, solver stalls
     int D;
+    // goal schedule of the resident loop (mw_set_goal_schedule; RandomTaskSelectWrapper.reset, wrappers.py:116-119, inside the kernel):
+    // the k-th auto-reset of env i since the schedule was set takes sched[min(k, sched_K - 1)][i]; null = next_goal[i]
+    const int* sched;        // [sched_K][N]
+    int* sched_pos;          // [N] auto-resets of env i since the schedule was set
+    int sched_K, N;
 };
 
 // (per-env status bits of one step: mw_common.hpp, ST_*; sticky in the context status word until mw_status clears it)
@@ -384,7 +389,13 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
             if (io.final_obs) write_obs(w, td, io.final_obs + (size_t)gid * io.D, obs, oh);
             io.ep_ret[gid] = ep_ret; io.ep_len[gid] = ep_len;
         }
-        load_snapshot(w, e, task, io.next_goal[gid], obs);
+        int goal = io.next_goal[gid];
+        if (io.sched) {          // (the sub-lanes of an environment read the position before its writer advances it: one wave, in lockstep)
+            const int k = io.sched_pos[gid];
+            goal = io.sched[(size_t)(k < io.sched_K ? k : io.sched_K - 1) * io.N + gid];
+            if (writer) io.sched_pos[gid] = k + 1;
+        }
+        load_snapshot(w, e, task, goal, obs);
     }
     if (writer) write_obs(w, td, io.obs + (size_t)gid * io.D, obs, oh);
 }
@@ -448,6 +459,8 @@ public:
     virtual void gather_bookkeeping(mw_bookkeeping* out, int out_on_device) = 0;
     virtual void status(int* out /*[MW_STATUS_WORDS]*/, int clear) = 0;
     virtual void set_episode_phase(const int* elapsed) = 0;
+    virtual void set_goal_schedule(const int* schedule, int K) = 0;
+    virtual void goal_schedule_pos(int* out) = 0;
     virtual void read_col(int gid, const char* what, int n, double* out) = 0;
     virtual void write_col(int gid, const char* what, int n, const double* in) = 0;
     virtual void read_icol(int gid, const char* what, int n, int* out) = 0;
@@ -488,6 +501,8 @@ class Context : public ContextBase {
     // io buffers (device) + host staging
     float* d_act_ = nullptr; size_t act_capacity_steps_ = 0;
     int* d_next_goal_ = nullptr;
+    int *d_sched_ = nullptr, *d_sched_pos_ = nullptr;   // goal schedule of the resident loop (set_goal_schedule)
+    int sched_K_ = 0;
     uint8_t* d_mask_ = nullptr;
     double *d_obs_ = nullptr, *d_reward_ = nullptr, *d_final_ = nullptr, *d_epret_ = nullptr;
     uint8_t* d_flags_ = nullptr;   // terminated, truncated, success, done : 4 x N
@@ -516,6 +531,7 @@ class Context : public ContextBase {
             w.io.terminated = d_flags_; w.io.truncated = d_flags_ + N_; w.io.success = d_flags_ + 2 * N_; w.io.done = d_flags_ + 3 * N_;
             w.io.info = d_info_; w.io.final_obs = d_final_; w.io.ep_ret = d_epret_; w.io.ep_len = d_eplen_; w.io.D = obs_dim();
             w.io.status = d_status_; w.io.book = d_book_ ? d_book_ + (size_t)book_slot_ * N_ : nullptr;
+            w.io.N = N_;          // (io.sched stays null: only the resident loop hands the goal schedule to the kernel)
         }
         return w;
     }
@@ -564,6 +580,7 @@ public:
     ~Context() override {
         for (auto& g : groups_) free_group(g);
         Backend::free(d_groups_); Backend::free(d_tasks_); Backend::free(d_snap_); Backend::free(d_snap_off_); Backend::free(d_snap_stride_);
+        Backend::free(d_sched_); Backend::free(d_sched_pos_);
         Backend::free(d_act_); Backend::free(d_next_goal_); Backend::free(d_mask_); Backend::free(d_obs_); Backend::free(d_reward_);
         Backend::free(d_final_); Backend::free(d_epret_); Backend::free(d_flags_); Backend::free(d_info_); Backend::free(d_eplen_);
         Backend::free(d_snap_ngoal_); Backend::free(d_status_); Backend::free(d_book_); Backend::free(d_book_all_);
@@ -985,6 +1002,7 @@ public:
             if (gather) Backend::wait_gather_done(book_slot_);
             World<T> w = world();
             w.io.act = base + (size_t)(act_steps > 0 ? s % act_steps : 0) * 4 * N_;
+            if (d_sched_) { w.io.sched = d_sched_; w.io.sched_pos = d_sched_pos_; w.io.sched_K = sched_K_; }
             Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
             if (gather) gather_async();
         }
@@ -1027,6 +1045,24 @@ public:
             set_task_field(groups_[env_group_[i]], env_lane_[i], TK_ELAPSED, elapsed[i]);
             set_task_field(groups_[env_group_[i]], env_lane_[i], TK_PATHLEN, elapsed[i]);
         }
+    }
+    // goal schedule of the resident loop (IOPtrs::sched): K rows of N goal indices, or null / K = 0 to go back to next_goal
+    void set_goal_schedule(const int* schedule, int K) override {
+        Backend::sync();
+        Backend::free(d_sched_); d_sched_ = nullptr; sched_K_ = 0;
+        if (!schedule || K <= 0) return;
+        for (int k = 0; k < K; k++) check_goals(schedule + (size_t)k * N_, nullptr, "set_goal_schedule");
+        d_sched_ = (int*)Backend::alloc(sizeof(int) * (size_t)N_ * K);
+        Backend::h2d(d_sched_, schedule, sizeof(int) * (size_t)N_ * K);
+        if (!d_sched_pos_) d_sched_pos_ = (int*)Backend::alloc(sizeof(int) * N_);
+        Backend::zero(d_sched_pos_, sizeof(int) * N_);
+        Backend::sync();
+        sched_K_ = K;
+    }
+    void goal_schedule_pos(int* out) override {
+        if (!d_sched_pos_) { for (int i = 0; i < N_; i++) out[i] = 0; return; }
+        Backend::sync();
+        Backend::d2h(out, d_sched_pos_, sizeof(int) * N_);
     }
     void status(int* out, int clear) override {
         Backend::d2h(out, d_status_, sizeof(int) * MW_STATUS_WORDS);

@@ -104,6 +104,8 @@ class Lib:
         f("gather_bookkeeping", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
         f("status", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
         f("set_episode_phase", C.c_int, C.c_void_p, C.c_void_p)
+        f("set_goal_schedule", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+        f("goal_schedule_pos", C.c_int, C.c_void_p, C.c_void_p)
         f("column_size", C.c_int, C.c_void_p, C.c_int, C.c_char_p)
         f("read", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
         f("write", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
@@ -132,7 +134,7 @@ def load(prefix="mw_", path=None) -> Lib:
 
 EXPORTED_SYMBOLS = ["model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
                     "add_model", "add_task", "set_envs", "finalize", "set_terminate_on_success", "destroy", "last_error", "num_envs", "obs_dim",
-                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "upload_actions", "step_resident", "step_resident_gather", "comm_unique_id", "comm_init", "comm_info", "gather_bookkeeping", "status", "set_episode_phase", "column_size", "read", "write", "read_int",
+                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "upload_actions", "step_resident", "step_resident_gather", "comm_unique_id", "comm_init", "comm_info", "gather_bookkeeping", "status", "set_episode_phase", "set_goal_schedule", "goal_schedule_pos", "column_size", "read", "write", "read_int",
                     "debug"]
 
 
@@ -271,6 +273,21 @@ class Context:
         e = np.ascontiguousarray(elapsed, dtype=np.int32)
         assert e.shape == (self.N,)
         self._check(self.lib.set_episode_phase(self.ptr, e.ctypes.data))
+
+    def set_goal_schedule(self, schedule):
+        """mw_set_goal_schedule: [K, N] goal indices for the auto-resets inside step_resident / step_resident_gather (None clears)"""
+        if schedule is None:
+            self._check(self.lib.set_goal_schedule(self.ptr, None, 0))
+            return
+        g = np.ascontiguousarray(schedule, dtype=np.int32)
+        assert g.ndim == 2 and g.shape[1] == self.N and g.shape[0] >= 1
+        self._check(self.lib.set_goal_schedule(self.ptr, g.ctypes.data, g.shape[0]))
+
+    def goal_schedule_pos(self):
+        """mw_goal_schedule_pos -> [N] auto-resets of every env since set_goal_schedule"""
+        out = np.zeros(self.N, dtype=np.int32)
+        self._check(self.lib.goal_schedule_pos(self.ptr, out.ctypes.data))
+        return out
 
     def status(self, clear=False):
         """mw_status -> dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps, diverged_steps, solver_stalls); flags: 1 / 2 capacity exceeded, 4 non-finite state, 8 sub-lane divergence canary (include/mwgpu.h)"""

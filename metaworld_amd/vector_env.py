@@ -227,6 +227,14 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
         self._env_seed = [None if seed is None else (seed + names.index(n) if benchmark == "custom-mt" and seed else seed) for n in env_task_names]
         self.task_select = task_select
         self._stream, self._shuffles = {}, {}
+        # envs grouped by (goal-list length, seed): one cached selection stream serves a whole group (_random_goals)
+        self._groups, self._group_of = [], []
+        for e in range(self.num_envs):
+            k = (len(self._goal_lists[e]), self._env_seed[e])
+            if k not in self._groups:
+                self._groups.append(k)
+            self._group_of.append(self._groups.index(k))
+        self._lists_are_ranges = all(np.array_equal(l, np.arange(len(l))) for l in self._goal_lists)
         self._reset_count = np.zeros(self.num_envs, dtype=np.int64)    # random: draws made; pseudorandom: shuffles made
         self._task_idx = np.full(self.num_envs, -1, dtype=np.int64)     # pseudorandom: current_task_idx (wrappers.py:180)
         self._cur_goal = np.full(self.num_envs, -1, dtype=np.int32)     # goal of the running episode (-1 = no task set yet)
@@ -306,19 +314,79 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
             self._task_idx[e] = idx
         return int(lst[idx])
 
+    def _random_goals(self, idx, ahead=0):
+        """`_select` of the "random" selection for MANY envs at once, without committing: the goal of draw number
+        `_reset_count[e] + ahead` of every env in idx.  One numpy gather per (list length, seed) group -- a synchronised reset of
+        4096 sub-envs is not 4096 Python iterations."""
+        idx = np.asarray(idx, dtype=np.int64)
+        out = np.empty(len(idx), dtype=np.int64)
+        if not len(idx):
+            return out
+        key = np.array([self._group_of[e] for e in idx]) if len(self._groups) > 1 else np.zeros(len(idx), dtype=np.int64)
+        for g, (n_goals, seed) in enumerate(self._groups):
+            sel = np.flatnonzero(key == g)
+            if not len(sel):
+                continue
+            k = self._reset_count[idx[sel]] + ahead
+            self._draw(n_goals, int(k.max()), seed)                      # extends the cached stream
+            draws = np.asarray(self._stream[n_goals, seed][1], dtype=np.int64)[k]
+            if self._lists_are_ranges:
+                out[sel] = draws
+            else:
+                out[sel] = [self._goal_lists[e][d] for e, d in zip(idx[sel], draws)]
+        return out
+
     def _begin_episodes(self, mask, force=False):
         """what `reset()` of the task-select wrapper does to the envs in mask (a new task iff sample_tasks_on_reset, or always
         for `sample_tasks`), then the look-ahead for their next auto-reset"""
         sample = self.sample_tasks_on_reset or force
-        for e in np.flatnonzero(mask):
+        idx = np.flatnonzero(mask)
+        if self.task_select == "random":
             if sample:
-                self._cur_goal[e] = self._select(e, commit=True)
-            assert self._cur_goal[e] >= 0, "no task set: call('sample_tasks') first (sawyer_xyz_env.py:699-701)"
+                self._cur_goal[idx] = self._random_goals(idx)
+                self._reset_count[idx] += 1
+        else:
+            for e in idx:
+                if sample:
+                    self._cur_goal[e] = self._select(e, commit=True)
+        assert (self._cur_goal[idx] >= 0).all(), "no task set: call('sample_tasks') first (sawyer_xyz_env.py:699-701)"
         self._look_ahead(mask)
 
     def _look_ahead(self, mask):
-        for e in np.flatnonzero(mask):
-            self._next_goal[e] = self._select(e, commit=False) if self.sample_tasks_on_reset else self._cur_goal[e]
+        idx = np.flatnonzero(mask)
+        if not self.sample_tasks_on_reset:
+            self._next_goal[idx] = self._cur_goal[idx]
+        elif self.task_select == "random":
+            self._next_goal[idx] = self._random_goals(idx)
+        else:
+            for e in idx:
+                self._next_goal[e] = self._select(e, commit=False)
+
+    # ---- the resident loop (mw_step_resident): K steps on pre-uploaded actions, outputs left in HBM ----
+    def step_resident(self, nsteps, gather=False, schedule_rows=None):
+        """`nsteps` steps of the whole batch on the actions uploaded with `ctx.upload_actions`, no host round trip in between;
+        returns the HIP-event kernel time in ms.  The auto-resets that happen inside draw a NEW task per reset like
+        `RandomTaskSelectWrapper.reset` (metaworld/wrappers.py:116-119): the next `schedule_rows` selections of every sub-env are
+        taken from its task-selection stream and handed to the kernel (mw_set_goal_schedule), the consumed counts are read back
+        and the streams advanced by them, so that a following `step()` / `reset()` continues exactly where the reference's
+        wrappers would be.  (Row K-1 repeats if an env resets more than K times: only with episodes of a few steps.)"""
+        if (self._cur_goal < 0).any():
+            raise RuntimeError("step_resident() called before reset(): no task has been set for some sub-envs")
+        sched = None
+        if self.sample_tasks_on_reset and self.task_select == "random":
+            K = int(schedule_rows or max(2, min(64, nsteps // 50 + 2)))
+            every = np.arange(self.num_envs)
+            sched = np.stack([self._random_goals(every, ahead=k) for k in range(K)]).astype(np.int32)
+            self.ctx.set_goal_schedule(sched)
+        ms = self.ctx.step_resident_gather(nsteps) if gather else self.ctx.step_resident(nsteps)
+        if sched is not None:
+            used = self.ctx.goal_schedule_pos().astype(np.int64)
+            self.ctx.set_goal_schedule(None)
+            hit = np.flatnonzero(used > 0)
+            self._cur_goal[hit] = sched[np.minimum(used[hit], len(sched)) - 1, hit]
+            self._reset_count += used
+            self._look_ahead(np.ones(self.num_envs, dtype=bool))
+        return ms
 
     # ---- the observation / reward wrappers between the env and the vectoriser (metaworld/__init__.py:438-449) ----
     def _wrap_reset_obs(self, obs, mask):
@@ -479,6 +547,7 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
             assert ck["task_select"] == self.task_select and ck["seed"] == self.seed_value
             self._reset_count[:] = ck["reset_count"]; self._cur_goal[:] = ck["cur_goal"]; self._task_idx[:] = ck["task_idx"]
             self._goal_lists = [l.copy() for l in ck["goal_lists"]]
+            self._lists_are_ranges = all(np.array_equal(l, np.arange(len(l))) for l in self._goal_lists)
             self.sample_tasks_on_reset = ck["sample_tasks_on_reset"]
             nz = ck["normalizers"]
             self._rew_mean, self._rew_var, self._disc_ret = nz["rew_mean"].copy(), nz["rew_var"].copy(), nz["disc_ret"].copy()
