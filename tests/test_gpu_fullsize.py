@@ -158,6 +158,18 @@ def test_bench_states_match_the_oracle(gpulib, bench_name, n):
             lq, lv = min(max(lq, 10 * rq), 1e-3), min(max(lv, 10 * rv), 1e-1)
         if not (ncon_dev == ncon_orc and ic[1] == d.nefc and eq < lq and ev < lv):
             bad.append((name, e, int(elapsed[e]), (int(ic[0]), d.ncon), (int(ic[1]), d.nefc), float(eq), float(ev)))
+    # the states whose limit followed the oracle's own conditioning are REPORTED even when the test passes (a self-adjusting
+    # tolerance must not be silent: VERDICT r3): stdout (pytest -rA) and gpurun_out/bench_states_relaxed.txt, committed under profiles/
+    report = [f"{len(relaxed)} of {len(synced)} sampled states got a relaxed limit (task, env, |dq| device vs oracle, oracle's own response to 1e-12)"]
+    report += [f"  {n:28s} env {e:5d}  dq {q:.3e}  oracle response {r:.3e}" for n, e, q, r in relaxed]
+    report.append("error quantiles 0.5 / 0.9 / 0.99 / 1.0: " + " ".join(f"{x:.2e}" for x in np.quantile(errs, [0.5, 0.9, 0.99, 1.0])))
+    print("\n".join(report))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_states_relaxed.txt"), "w") as f:
+            f.write("\n".join(report) + "\n")
+    except OSError:
+        pass
     assert not bad, bad
     assert len(relaxed) <= max(2, len(synced) // 50), relaxed          # ill-conditioned states are the exception (<= 2 % of the sample)
     assert np.quantile(errs, 0.9) < 1e-7, np.quantile(errs, [0.5, 0.9, 0.99, 1.0])

@@ -38,7 +38,7 @@ def pick_envs(env, elapsed):
 
 def dump(bench_name, n, out_dir, lib=None):
     env = MetaWorldGpuVectorEnv(bench_name, num_envs=n, seed=42, use_one_hot=True, precision="fp64", lib=lib)
-    args = SimpleNamespace(no_stagger=False, warmup=20, allow_status=False)
+    args = SimpleNamespace(no_stagger=False, warmup=20, allow_status=False, fixed_goals=False)
     bench.prepare(env, args, 0)
     ctx = env.ctx
     # TimeLimit phase of every env now: prepare() gave env i the phase 7919 i mod 500 and ran 500 + warm-up steps
@@ -52,7 +52,9 @@ def dump(bench_name, n, out_dir, lib=None):
     assert st["flags"] == 0, st
     post = {c: [ctx.read(e, c) for e in chosen] for c in ("qpos", "qvel", "mocap")}
     names = [env.env_task_names[e] for e in chosen]
+    from metaworld_amd import native
     res = dict(bench=bench_name, n=n, env=np.array(chosen), task=np.array(names), action=acts[chosen],
+               source_hash=np.array(native.source_hash()),          # the device sources this recording belongs to (checked by the test)
                obs=o[chosen].copy(), reward=r[chosen].copy(), terminated=te[chosen].copy(), truncated=tr[chosen].copy(),
                success=su[chosen].copy(), info=info[chosen].copy(), final_obs=ctx.final_obs[chosen].copy())
     for c in COLS:          # ragged over scenes: padded with NaN, true lengths beside
