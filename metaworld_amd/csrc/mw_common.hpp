@@ -245,6 +245,12 @@ struct Env {
     int lds_stride;
     int sub, nsub;     // sub-lane of this thread and sub-lanes per environment (cooperative row sweeps, see below)
     int thr;           // thread index inside the workgroup
+    // slot = which of the workgroup's environments this thread works for; nslot = how many the workgroup really holds.  The last
+    // workgroup of a group can hold fewer than lpb: its surplus threads do not leave the kernel, they run as GHOSTS -- exact
+    // duplicates of the threads of the last real environment (same slot, same sub-lane index, same values, same stores), so that
+    // EVERY lane of every wave stays alive: the wave-cooperative sections (newton_direction_wave: matrix instructions and
+    // lane-role loads that need all 64 lanes) and every non-inlined stage function then run under a full EXEC mask.
+    int slot, nslot, ghost;
     int lds_rows;      // constraint rows that fit in the scratchpad: scalars + Jacobian row (the rest stay in the column store)
     int lds_w;         // scratchpad slots per row = SR_N + nv
     // BODY-LEVEL CHAINS IN THE SCRATCHPAD.  Kinematics, the composite inertias and the recursive Newton-Euler passes are chains
@@ -271,9 +277,9 @@ struct Env {
     }
 #endif
     // lpb = environments per workgroup of this environment's group; threads t, t + lpb, ... are its sub-lanes
-    MW_HD void set_scratchpad(Scratchpad sp, int thread, int lpb, int nv_, int nbody, int nq_) {
+    MW_HD void set_scratchpad(Scratchpad sp, int thread, int lpb, int nv_, int nbody, int nq_, int env_slot) {
         const bool host = sp.host_nsub > 0;
-        lds = (MW_LDS T*)sp.base + (host ? 0 : thread % lpb);
+        lds = (MW_LDS T*)sp.base + (host ? 0 : env_slot);
         lds_stride = host ? 1 : lpb;
         sub = host ? 0 : thread / lpb;
         thr = thread;

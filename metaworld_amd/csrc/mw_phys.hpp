@@ -1119,6 +1119,166 @@ MW_STAGE_FN void newton_direction(const Env<T> e_) {
     MW_TOCK(e, L, 2, t_bfly, t_end)
 }
 
+// ------------------------------------------------------------------ Newton direction, wave-cooperative (device only)
+// The same s = -H^-1 g, H = M + J' D J (+ cone blocks), in single precision, computed by the WHOLE WAVE for the workgroup's
+// environments four at a time instead of by every sub-lane of an environment redundantly:
+//  * lane role: lane 16 b + i works for environment (group start + b) and dof i (any lane can address any environment's columns
+//    and scratchpad slice: env_view);
+//  * H is accumulated by v_mfma_f32_16x16x1_4b_f32 -- four independent 16 x 16 rank-1 updates per instruction, one per
+//    environment: A = the term's coefficient vector (D j for a quadratic row, sum_r Hc[r][c] j_r for column c of a cone block),
+//    B = the row's Jacobian, both ONE scratchpad read per lane.  (Rounds 1-3: every sub-lane zeroed a 120-153-entry triangle,
+//    added its rows with 120-153 FMAs each, and a 4-stage butterfly summed the triangles: ~4 k wave-instructions per iteration
+//    whatever the number of rows.)  Exact f32 products and sums (the 4-block f32 MFMA is an fmaf chain);
+//  * right-looking Cholesky in the accumulator layout: step k fetches row k of the current matrix (five lane permutes), scales it
+//    and removes its outer product with one more matrix instruction; lane 16 b + n ends up with row n of the factor;
+//  * the two triangular solves run on that distribution (forward: a broadcast + one FMA per step; backward: a 16-lane sum per step);
+//  * nv = 17 (the stick scenes): the 17th dof is a border -- H = [H16 h; h' eta], factor = [L16 0; l' lam], l = L16^-1 h.
+// Results go to L.search of every active environment.  Called by EVERY lane of the wave (ghost lanes included, Env::ghost) with
+// its environment's `active` flag; environments that are not active are skipped (their lanes help with the others).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float mw_f16v __attribute__((ext_vector_type(16)));
+__device__ inline float blk_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
+template <typename T>
+__device__ inline Env<T> env_view(const Env<T>& e, int slot) {          // the same workgroup's environment `slot`, seen from this thread
+    Env<T> r = e;
+    const int d = slot - e.slot;
+    r.col = e.col + d; r.icol = e.icol + d; r.lds = e.lds + d; r.slot = slot;
+    return r;
+}
+template <typename T, bool BORDER>          // BORDER: nv = 17
+MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
+    typedef float HT;
+    const Env<T> e = e_.uniform();
+    CLayout& L = e.lay();
+    const int nv = e.nv, nv16 = nv < 16 ? nv : 16, lpb = e.lds_stride;
+    const int lane = e.thr & 63, rb = lane >> 4, ri = lane & 15, l48 = lane & 48;
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);          // bit s (s < lpb) = sub-lane 0 of the environment in slot s
+    for (int g0 = 0; g0 < lpb; g0 += 4) {
+        if (((act >> g0) & 15ull) == 0ull) continue;                              // (wave-uniform)
+        const int slot = g0 + rb;
+        const bool on = slot < e.nslot && ((act >> slot) & 1ull) != 0ull;
+        const Env<T> rv = env_view(e, on ? slot : e.slot);                       // (an idle role lane looks at its own environment and contributes zeros)
+        // ---- H <- M in the accumulator layout: lane (rb, ri), register 4 blk + v  =  H_blk[4 rb + v][ri]
+        mw_f16v acc;
+#pragma unroll
+        for (int blk = 0; blk < 4; blk++) {
+            const int s2 = g0 + blk;
+            const bool on2 = s2 < e.nslot && ((act >> s2) & 1ull) != 0ull;
+            const Env<T> r2 = env_view(e, on2 ? s2 : e.slot);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int mrow = 4 * rb + v, hi = mrow > ri ? mrow : ri, lo = mrow > ri ? ri : mrow;
+                const bool inside = on2 && hi < nv16;
+                const T val = r2.R(L.qM + (inside ? hi * nv + lo : 0));
+                acc[4 * blk + v] = inside ? (HT)val : (mrow == ri ? HT(1) : HT(0));
+            }
+        }
+        HT hb = 0, eta = 1;                                                        // border (nv = 17): H[16][ri], H[16][16]
+        if (BORDER) {
+            const T v1 = rv.R(L.qM + 16 * nv + ri), v2 = rv.R(L.qM + 16 * nv + 16);
+            hb = on ? (HT)v1 : HT(0); eta = on ? (HT)v2 : HT(1);
+        }
+        const int nb = on ? rv.I(L.icount + IC_NBLK) : 0;
+        int nbmax = __builtin_amdgcn_readlane(nb, 0);
+        { const int n1 = __builtin_amdgcn_readlane(nb, 16), n2 = __builtin_amdgcn_readlane(nb, 32), n3 = __builtin_amdgcn_readlane(nb, 48);
+          nbmax = nbmax > n1 ? nbmax : n1; nbmax = nbmax > n2 ? nbmax : n2; nbmax = nbmax > n3 ? nbmax : n3; }
+        // ---- + J' D J: the constraint blocks of the four environments side by side, up to four rank-1 terms per block
+        for (int kb = 0; kb < nbmax; kb++) {
+            const bool in = on && kb < nb;
+            int i = 0, st = S_SATISFIED, info = 0;
+            if (in) { i = block_row(rv, kb); st = (int)sr_get(rv, i, SR_STATE); info = (int)sr_get(rv, i, SR_INFO); }
+            const int dim = (info >> 4) & 15, type = info & 15;
+            const int nterm = (!in || st == S_SATISFIED) ? 0 : (type == C_CONTACT ? dim : 1);
+            if (!mw_any(nterm > 0)) continue;
+            HT jv[4], a[4], j16[4], a16[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const bool rowon = c < nterm;
+                jv[c] = (rowon && ri < nv16) ? (HT)ej_get(rv, i + c, ri) : HT(0);
+                j16[c] = (BORDER && rowon) ? (HT)ej_get(rv, i + c, 16) : HT(0);
+                a[c] = 0; a16[c] = 0;
+            }
+            if (nterm > 0 && st == S_CONE) {
+                ConeEval<T> z = cone_eval<T>(Rows<T, false>{rv}, i, dim, T(0));
+                const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu));
+                const T scl = z.mu * z.N / (z.Tn * z.Tn * z.Tn), dg = z.mu * z.mu - z.mu * z.N / z.Tn;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        T v;
+                        if (r == 0 && c == 0) v = 1;
+                        else if (r == 0) v = -z.mu * z.U[c] / z.Tn;
+                        else if (c == 0) v = -z.mu * z.U[r] / z.Tn;
+                        else v = scl * z.U[r] * z.U[c] + (r == c ? dg : T(0));
+                        const HT hc = (r < dim && c < dim) ? HT(v * Dm * z.fri[r] * z.fri[c]) : HT(0);
+                        a[c] += jv[r] * hc; a16[c] += j16[r] * hc;
+                    }
+            } else if (nterm > 0) {
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (c < nterm) { const HT D = (HT)sr_get(rv, i + c, SR_D); a[c] = D * jv[c]; a16[c] = D * j16[c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (!mw_any(c < nterm)) break;
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[c], jv[c], acc, 0, 0, 0);
+                if (BORDER) { hb += a[c] * j16[c]; eta += a16[c] * j16[c]; }
+            }
+        }
+        MW_TICK(t_rows)
+        // ---- Cholesky: lane (rb, ri) collects row ri of the factor of ITS environment, Lr[k] = L[ri][k]
+        HT Lr[16], invd = 1;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int src = 16 * (k / 4) + ri;          // row k of every block sits in lanes 16 (k / 4) .. + 15, register 4 blk + k % 4
+            const HT h0 = __shfl(acc[0 + k % 4], src), h1 = __shfl(acc[4 + k % 4], src), h2 = __shfl(acc[8 + k % 4], src), h3 = __shfl(acc[12 + k % 4], src);
+            const HT hk = rb == 0 ? h0 : (rb == 1 ? h1 : (rb == 2 ? h2 : h3));
+            HT d = __shfl(hk, l48 | k);
+            d = d < HT(1e-15) ? HT(1e-15) : d;
+            const HT sd = sqrtf(d), rs = HT(1) / sd;
+            const HT l = ri < k ? HT(0) : (ri == k ? sd : hk * rs);
+            Lr[k] = l;
+            if (ri == k) invd = rs;
+            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(-l, l, acc, 0, 0, 0);
+        }
+        // ---- forward substitution, right-hand sides g (and the border column h)
+        const T gval = rv.R(L.grad + (ri < nv16 ? ri : 0));
+        HT yg = (on && ri < nv16) ? (HT)gval : HT(0), yh = hb;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const HT bg = __shfl(yg * invd, l48 | k);
+            yg = ri == k ? bg : (ri > k ? yg - Lr[k] * bg : yg);
+            if (BORDER) {
+                const HT bh = __shfl(yh * invd, l48 | k);
+                yh = ri == k ? bh : (ri > k ? yh - Lr[k] * bh : yh);
+            }
+        }
+        HT x17 = 0;
+        if (BORDER) {
+            HT lam2 = eta - blk_sum(yh * yh);
+            lam2 = lam2 < HT(1e-15) ? HT(1e-15) : lam2;
+            const HT il = HT(1) / sqrtf(lam2);
+            const T g17 = rv.R(L.grad + 16);
+            const HT y17 = ((on ? (HT)g17 : HT(0)) - blk_sum(yh * yg)) * il;
+            x17 = y17 * il;
+            yg -= yh * x17;
+        }
+        // ---- backward substitution with the transposed factor: x_k = (y_k - sum_{n > k} L[n][k] x_n) / L[k][k]
+        HT x = 0;
+#pragma unroll
+        for (int k = 15; k >= 0; k--) {
+            const HT sum = blk_sum(ri > k ? Lr[k] * x : HT(0));
+            if (ri == k) x = (yg - sum) * invd;
+        }
+        if (on && ri < nv16) rv.R(L.search + ri) = (T)x;
+        if (BORDER && on && ri == 0) rv.R(L.search + 16) = (T)x17;
+        MW_TICK(t_end)
+        MW_TOCK(e, L, 2, t_rows, t_end)      // timing builds: slot 2 ("chol") = factorisation + solves (charged to this thread's own environment)
+    }
+}
+#endif
+
 template <typename T, int NV>
 MW_HD void solve_impl(const Env<T> e) {
     CModel<T>& m = e.model();
@@ -1152,23 +1312,49 @@ MW_HD void solve_impl(const Env<T> e) {
     MW_TICK(t_b)
     MW_TOCK(e, L, 0, t_a, t_b)
     MW_COUNT(2)
+    // The loop is WAVE-UNIFORM: an environment that has converged (or abandoned its search) goes inactive and waits; the wave
+    // leaves when all its environments have.  That is what SIMT did with the per-environment `break`s anyway -- but now the
+    // Newton direction is computed by all 64 lanes together for the active environments (newton_direction_wave), a call that is
+    // made under a full EXEC mask.  One-environment-per-lane layouts (fewer than four sub-lanes) and the host build keep the
+    // per-environment routine.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MW_NO_WAVE_NEWTON)
+    const bool wave_newton = e.nsub >= 4;
+#else
+    const bool wave_newton = false;
+#endif
+    bool active = true;
     for (int iter = 0; iter < m.sz.iterations; iter++) {
-        MW_COUNT(1)
-        T gn = 0, sr[NV];             // sr: gradient, then the search direction
+        T sr[NV];             // gradient, then the search direction
+        if (active) {
+            MW_COUNT(1)
+            T gn = 0;
 #pragma unroll
-        for (int k = 0; k < NV; k++) {
-            const int kk = k < nv ? k : 0;
-            const T g = e.R(L.Ma + kk) - e.R(L.smooth + kk) - e.R(L.qfrc_c + kk);
-            sr[k] = k < nv ? -g : T(0);
-            if (k < nv) gn += g * g;
+            for (int k = 0; k < NV; k++) {
+                const int kk = k < nv ? k : 0;
+                const T g = e.R(L.Ma + kk) - e.R(L.smooth + kk) - e.R(L.qfrc_c + kk);
+                sr[k] = k < nv ? -g : T(0);
+                if (k < nv) gn += g * g;
+            }
+            if (scale * mw_sqrt(gn) < m.tolerance) active = false;
+            // Newton direction: -g goes through the column store (L.grad) and the direction comes back in L.search
+            else vec_store<T, NV>(e, L.grad, nv, sr);
         }
-        if (scale * mw_sqrt(gn) < m.tolerance) break;
         MW_TICK(t_c)
-        // Newton direction: -g goes through the column store (L.grad) into its own non-inlined function and the direction comes
-        // back in L.search, so that the register allocation of the Hessian (nv (nv + 1) / 2 accumulators + up to four Jacobian
-        // rows) is not mixed with everything that is live in this loop
-        vec_store<T, NV>(e, L.grad, nv, sr);
-        newton_direction<T, typename HessType<T>::type, NV>(e);
+        if (wave_newton) {
+            if (!mw_any(active)) break;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MW_NO_WAVE_NEWTON)
+            MW_SYNC();
+            newton_direction_wave<T, (NV > 16)>(e, active);
+            MW_SYNC();
+#endif
+        } else {
+            if (!active) break;
+            // (its own non-inlined function, so that the register allocation of the Hessian -- nv (nv + 1) / 2 accumulators + up to
+            //  four Jacobian rows -- is not mixed with everything that is live in this loop)
+            newton_direction<T, typename HessType<T>::type, NV>(e);
+        }
+        if (!active) continue;
+        active = [&]() -> bool {
         vec_load<T, NV>(e, L.search, nv, sr);
         MW_TICK(t_e)
         MW_TOCK(e, L, 1, t_c, t_e)
@@ -1193,7 +1379,7 @@ MW_HD void solve_impl(const Env<T> e) {
             }
         }
         snorm = mw_sqrt(snorm);
-        if (snorm < T(1e-15)) break;
+        if (snorm < T(1e-15)) return false;
         MW_SUBS(e, sub) {
             for (int i = sub; i < nefc; i += e.nsub) {
                 T j[NV], s = 0;
@@ -1209,7 +1395,7 @@ MW_HD void solve_impl(const Env<T> e) {
         MW_TOCK(e, L, 3, t_f, t_g)
         T c0, d1, d2;
         line_eval(e, nblk, T(0), quadGauss, &c0, &d1, &d2);
-        if (d1 >= 0 || d2 <= 0) { e.I(L.icount + IC_SOLVER_STALL) += 1; break; }   // not a descent direction (single-precision factor of an ill-conditioned H, or rounding at the optimum): the search is abandoned like in the reference solver, and counted (mw_status)
+        if (d1 >= 0 || d2 <= 0) { e.I(L.icount + IC_SOLVER_STALL) += 1; return false; }   // not a descent direction (single-precision factor of an ill-conditioned H, or rounding at the optimum): the search is abandoned like in the reference solver, and counted (mw_status)
         T lo = 0, hi = -1, alpha = -d1 / d2;
         int nls = 0;
         for (int it = 0; it < m.sz.ls_iterations; it++) {
@@ -1234,7 +1420,7 @@ MW_HD void solve_impl(const Env<T> e) {
         MW_TICK(t_h)
         MW_TOCK(e, L, 4, t_g, t_h)
         MW_TADD(e, L, 6, nls)
-        if (alpha == 0) break;
+        if (alpha == 0) return false;
         {          // qacc += alpha s, Ma += alpha Mv: all loads first, then the stores (see integrate_impl)
             T qa[NV], ma[NV], mv[NV];
             vec_load<T, NV>(e, L.qacc, nv, qa); vec_load<T, NV>(e, L.Ma, nv, ma); vec_load<T, NV>(e, L.Mv, nv, mv);
@@ -1252,7 +1438,8 @@ MW_HD void solve_impl(const Env<T> e) {
         MW_TOCK(e, L, 5, t_h, t_i)
         MW_TADD(e, L, 7, 1)
         e.I(L.icount + 2) = iter + 1;
-        if (scale * (old - cost) < m.tolerance) break;
+        return !(scale * (old - cost) < m.tolerance);
+        }();
     }
     MW_HIST(0, e.I(L.icount + 2))
     // efc_force of the rows kept in the scratchpad -> efcX (read by touching_object and through the ABI); fallback rows already are there

@@ -227,10 +227,16 @@ MW_HD bool locate(const World<T>& w, int block, int thread, Scratchpad sp, Env<T
     const int lpb = G.lpb;                    // environments per workgroup of this group (64, or fewer + sub-lanes)
     const bool host = sp.host_nsub > 0;       // host harness: one call per environment
     if (host && thread >= lpb) return false;
-    const int lin = host ? thread : thread % lpb;
+    int lin = host ? thread : thread % lpb;
+    const int nin = G.nenv - (block - G.block0) * lpb < lpb ? G.nenv - (block - G.block0) * lpb : lpb;   // environments this workgroup really holds
+    e->ghost = 0;
+    if (lin >= nin) {
+        if (host) return false;
+        lin = nin - 1; e->ghost = 1;          // device: the surplus threads of a group's last workgroup duplicate its last environment (Env::ghost)
+    }
     const int lane = (block - G.block0) * lpb + lin;
-    if (lane >= G.nenv) return false;
-    e->set_scratchpad(sp, thread, lpb, G.m.sz.nv, G.m.sz.nbody, G.m.sz.nq);
+    e->slot = lin; e->nslot = nin;
+    e->set_scratchpad(sp, thread, lpb, G.m.sz.nv, G.m.sz.nbody, G.m.sz.nq, lin);
     // element i of this environment: chunk base + i * lpb + (lane in chunk) -- consecutive elements of a workgroup's
     // environments are adjacent in memory (a Jacobian row of 8 environments is a few cache lines, not one line per entry)
     const size_t chunk = (size_t)(block - G.block0);
@@ -346,7 +352,7 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     const bool terminated = w.terminate_on_success && success == T(1);
     const bool done = terminated || truncated;
     const IOPtrs& io = w.io;
-    const bool writer = e.sub == 0;          // the sub-lanes of an environment hold identical values: one of them stores
+    const bool writer = e.sub == 0 && !e.ghost;          // the sub-lanes of an environment hold identical values: one of them stores (and counts)
     const int ep_len = (int)TK(e, TK_EPLEN);
     if (writer) {
         io.reward[gid] = (double)reward;
