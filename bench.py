@@ -213,7 +213,7 @@ def prepare(env, args, rank):
 def resident(env, args, nsteps, gather=False):
     """nsteps launches on the resident actions; every auto-reset inside draws a new task from the sub-env's selection stream
     (RandomTaskSelectWrapper.reset, metaworld/wrappers.py:116-119) through the device goal schedule -> kernel ms"""
-    if args.fixed_goals:
+    if getattr(args, "fixed_goals", False):
         return env.ctx.step_resident_gather(nsteps) if gather else env.ctx.step_resident(nsteps)
     return env.step_resident(nsteps, gather=gather)
 

@@ -11,6 +11,7 @@
 // All arrays are addressed through Env<T>::R(i) (column store, one lane = one env); the sweeps over constraint rows,
 // dofs and bodies' independent components are split over the environment's sub-lanes (mw_common.hpp, MW_SUBS).
 #pragma once
+#include <type_traits>
 #include "mw_common.hpp"
 
 namespace mw {
@@ -517,7 +518,7 @@ template <typename T> MW_HD GRef<int> IEFC(const Env<T> e, int r, int k) { retur
 
 // Solver row scalars: `info` = type + 16 * dim + 256 * k (k-th row of a dim-row cone block); the rows of a block are visited
 // from its first row with a wave-uniform counter.
-enum { SR_D = 0, SR_JAR, SR_JV, SR_FRI, SR_INFO, SR_STATE, SR_FORCE, SR_BLK, SR_AREF };
+enum { SR_D = 0, SR_JAR, SR_JV, SR_FRI, SR_INFO, SR_STATE, SR_FORCE, SR_BLK, SR_AREF };   // (AREF is read by the warm start only, JV is rewritten after every Newton direction: between the two, newton_direction_wave parks the cone blocks' scalars in them)
 MW_HD constexpr int sr_slot(int f) { return f == SR_D ? 3 : f == SR_JAR ? 6 : f == SR_JV ? 7 : f == SR_FRI ? 8 : f == SR_INFO ? 9 : f == SR_STATE ? 10 : f == SR_AREF ? 4 : 5; }
 template <typename T>
 MW_HD T sr_get(const Env<T> e, int i, int f) {
@@ -1125,19 +1126,37 @@ MW_STAGE_FN void newton_direction(const Env<T> e_) {
 //  * lane role: lane 16 b + i works for environment (group start + b) and dof i (any lane can address any environment's columns
 //    and scratchpad slice: env_view);
 //  * H is accumulated by v_mfma_f32_16x16x1_4b_f32 -- four independent 16 x 16 rank-1 updates per instruction, one per
-//    environment: A = the term's coefficient vector (D j for a quadratic row, sum_r Hc[r][c] j_r for column c of a cone block),
-//    B = the row's Jacobian, both ONE scratchpad read per lane.  (Rounds 1-3: every sub-lane zeroed a 120-153-entry triangle,
-//    added its rows with 120-153 FMAs each, and a 4-stage butterfly summed the triangles: ~4 k wave-instructions per iteration
-//    whatever the number of rows.)  Exact f32 products and sums (the 4-block f32 MFMA is an fmaf chain);
-//  * right-looking Cholesky in the accumulator layout: step k fetches row k of the current matrix (five lane permutes), scales it
-//    and removes its outer product with one more matrix instruction; lane 16 b + n ends up with row n of the factor;
-//  * the two triangular solves run on that distribution (forward: a broadcast + one FMA per step; backward: a 16-lane sum per step);
+//    environment -- in ONE pass over the constraint rows r = 0 .. nefc-1 (r is wave-uniform, so is the scratchpad / column-store
+//    decision of every access): a quadratic row is the term (D j_r) (x) j_r, one scratchpad read of j per lane.  (Rounds 1-3:
+//    every sub-lane zeroed a 120-153-entry triangle, added its rows with 120-153 FMAs each, and a 4-stage butterfly summed the
+//    triangles: ~4 k wave-instructions per iteration whatever the number of rows.)  Exact f32 products and sums (the f32 MFMA is
+//    an fmaf chain);
+//  * a cone block (state S_CONE, dim rows) is dim + 1 rank-1 terms.  With p_r = sqrt(Dm) fri_r j_r, q^ = (mu / Tn) sum_{r>=1} U_r p_r,
+//    rho = N / (mu Tn), dg = mu^2 - mu N / Tn > 0:   J' Hc J = (p_0 - q^) p_0' + (rho q^ - p_0) q^' + dg sum_{r>=1} p_r p_r'
+//    (the cone Hessian of the per-environment routine, regrouped).  The 2 dim scalars -- w_0 = sqrt(Dm) fri_0 and rho on row 0,
+//    c_r = (mu / Tn) U_r sqrt(Dm) fri_r and g_r = sqrt(Dm dg) fri_r on row r -- are computed in T by the environment's own
+//    sub-lanes (block-parallel, as before) and parked in the rows' AREF and JV fields, which are dead between the warm start
+//    and the line search; the role lanes read them with the row;
+//  * right-looking Cholesky in the accumulator layout: step k fetches row k of the current matrix (one round of lane permutes),
+//    scales it and removes its outer product with one more matrix instruction; lane 16 b + n ends up with row n of the factor;
+//  * the two triangular solves run on that distribution (forward: a lane broadcast + one FMA per step; backward: a 16-lane
+//    DPP sum per step);
 //  * nv = 17 (the stick scenes): the 17th dof is a border -- H = [H16 h; h' eta], factor = [L16 0; l' lam], l = L16^-1 h.
 // Results go to L.search of every active environment.  Called by EVERY lane of the wave (ghost lanes included, Env::ghost) with
 // its environment's `active` flag; environments that are not active are skipped (their lanes help with the others).
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float mw_f16v __attribute__((ext_vector_type(16)));
-__device__ inline float blk_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
+template <int CTRL> __device__ inline float mw_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a block, in every lane: four rotations inside the DPP row (row_ror:8 / 4 / 2 / 1), no LDS crossbar
+__device__ inline float blk_sum(float v) { v += mw_dpp<0x128>(v); v += mw_dpp<0x124>(v); v += mw_dpp<0x122>(v); v += mw_dpp<0x121>(v); return v; }
+// lane k of every block to all lanes of that block (k wave-uniform): four v_readlane + selects
+__device__ inline float blk_bcast(float v, int k, int rb) {
+    const int i = __builtin_bit_cast(int, v);
+    const int s0 = __builtin_amdgcn_readlane(i, k), s1 = __builtin_amdgcn_readlane(i, 16 + k), s2 = __builtin_amdgcn_readlane(i, 32 + k), s3 = __builtin_amdgcn_readlane(i, 48 + k);
+    return __builtin_bit_cast(float, rb == 0 ? s0 : (rb == 1 ? s1 : (rb == 2 ? s2 : s3)));
+}
 template <typename T>
 __device__ inline Env<T> env_view(const Env<T>& e, int slot) {          // the same workgroup's environment `slot`, seen from this thread
     Env<T> r = e;
@@ -1151,8 +1170,26 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
     const Env<T> e = e_.uniform();
     CLayout& L = e.lay();
     const int nv = e.nv, nv16 = nv < 16 ? nv : 16, lpb = e.lds_stride;
-    const int lane = e.thr & 63, rb = lane >> 4, ri = lane & 15, l48 = lane & 48;
+    const int lane = e.thr & 63, rb = lane >> 4, ri = lane & 15;
     const unsigned long long act = __builtin_amdgcn_ballot_w64(active);          // bit s (s < lpb) = sub-lane 0 of the environment in slot s
+    MW_TICK(t_0)
+    // ---- cone blocks: their 2 dim scalars, block-parallel over the environment's own sub-lanes, into the rows' AREF / JV fields
+    if (active) {
+        const int nblk = e.I(L.icount + IC_NBLK);
+        for (int kb = e.sub; kb < nblk; kb += e.nsub) {
+            const int i = block_row(e, kb);
+            if ((int)sr_get(e, i, SR_STATE) != S_CONE) continue;
+            const int dim = ((int)sr_get(e, i, SR_INFO) >> 4) & 15;
+            ConeEval<T> z = cone_eval<T>(Rows<T, false>{e}, i, dim, T(0));
+            const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu)), sDm = mw_sqrt(Dm), kap = z.mu / z.Tn;
+            const T dg = z.mu * z.mu - z.mu * z.N / z.Tn, sdg = mw_sqrt(dg > 0 ? dg : T(0));
+            sr_set(e, i, SR_AREF, sDm * z.fri[0]); sr_set(e, i, SR_JV, z.N / (z.mu * z.Tn));
+#pragma unroll
+            for (int r = 1; r < 4; r++)
+                if (r < dim) { sr_set(e, i + r, SR_AREF, kap * z.U[r] * sDm * z.fri[r]); sr_set(e, i + r, SR_JV, sDm * sdg * z.fri[r]); }
+        }
+    }
+    MW_SYNC();
     for (int g0 = 0; g0 < lpb; g0 += 4) {
         if (((act >> g0) & 15ull) == 0ull) continue;                              // (wave-uniform)
         const int slot = g0 + rb;
@@ -1178,53 +1215,55 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
             const T v1 = rv.R(L.qM + 16 * nv + ri), v2 = rv.R(L.qM + 16 * nv + 16);
             hb = on ? (HT)v1 : HT(0); eta = on ? (HT)v2 : HT(1);
         }
-        const int nb = on ? rv.I(L.icount + IC_NBLK) : 0;
-        int nbmax = __builtin_amdgcn_readlane(nb, 0);
-        { const int n1 = __builtin_amdgcn_readlane(nb, 16), n2 = __builtin_amdgcn_readlane(nb, 32), n3 = __builtin_amdgcn_readlane(nb, 48);
-          nbmax = nbmax > n1 ? nbmax : n1; nbmax = nbmax > n2 ? nbmax : n2; nbmax = nbmax > n3 ? nbmax : n3; }
-        // ---- + J' D J: the constraint blocks of the four environments side by side, up to four rank-1 terms per block
-        for (int kb = 0; kb < nbmax; kb++) {
-            const bool in = on && kb < nb;
-            int i = 0, st = S_SATISFIED, info = 0;
-            if (in) { i = block_row(rv, kb); st = (int)sr_get(rv, i, SR_STATE); info = (int)sr_get(rv, i, SR_INFO); }
-            const int dim = (info >> 4) & 15, type = info & 15;
-            const int nterm = (!in || st == S_SATISFIED) ? 0 : (type == C_CONTACT ? dim : 1);
-            if (!mw_any(nterm > 0)) continue;
-            HT jv[4], a[4], j16[4], a16[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const bool rowon = c < nterm;
-                jv[c] = (rowon && ri < nv16) ? (HT)ej_get(rv, i + c, ri) : HT(0);
-                j16[c] = (BORDER && rowon) ? (HT)ej_get(rv, i + c, 16) : HT(0);
-                a[c] = 0; a16[c] = 0;
+        const int ne = on ? rv.I(L.icount + 1) : 0;
+        int nmax = __builtin_amdgcn_readlane(ne, 0);
+        { const int n1 = __builtin_amdgcn_readlane(ne, 16), n2 = __builtin_amdgcn_readlane(ne, 32), n3 = __builtin_amdgcn_readlane(ne, 48);
+          nmax = nmax > n1 ? nmax : n1; nmax = nmax > n2 ? nmax : n2; nmax = nmax > n3 ? nmax : n3; }
+        // ---- + J' D J: one pass over the rows of the four environments side by side.  Row r is wave-uniform, so "scratchpad or
+        // column store" is decided once per loop, not per access: the seven reads of a row are issued together and waited for once
+        // (rows beyond an environment's nefc still exist physically -- stale -- and are masked after the read)
+        HT P0 = 0, Qh = 0, rho = 0, P016 = 0, Qh16 = 0;
+        auto row_pass = [&](auto src_tag, int r_begin, int r_end) {
+            constexpr bool LDSP = decltype(src_tag)::value;
+            for (int r = r_begin; r < r_end; r++) {
+                const bool in = on && r < ne;
+                T t_st, t_info, t_j, t_j16 = 0, t_a1, t_a2, t_d;
+                const int jcol = ri < nv16 ? ri : 0;
+                if (LDSP) {
+                    MW_LDS T* p = rv.lds + rv.S(r, 0) * rv.lds_stride;
+                    t_st = p[SR_STATE * rv.lds_stride]; t_info = p[SR_INFO * rv.lds_stride]; t_j = p[(SR_N + jcol) * rv.lds_stride];
+                    if (BORDER) t_j16 = p[(SR_N + 16) * rv.lds_stride];
+                    t_a1 = p[SR_AREF * rv.lds_stride]; t_a2 = p[SR_JV * rv.lds_stride]; t_d = p[SR_D * rv.lds_stride];
+                } else {
+                    t_st = EX(rv, r, sr_slot(SR_STATE)); t_info = EX(rv, r, sr_slot(SR_INFO)); t_j = EJ(rv, r, jcol);
+                    if (BORDER) t_j16 = EJ(rv, r, 16);
+                    t_a1 = EX(rv, r, sr_slot(SR_AREF)); t_a2 = EX(rv, r, sr_slot(SR_JV)); t_d = EX(rv, r, sr_slot(SR_D));
+                }
+                const int st = in ? (int)t_st : (int)S_SATISFIED, info = in ? (int)t_info : 0;
+                const HT jr = (in && ri < nv16) ? (HT)t_j : HT(0), j16 = (BORDER && in) ? (HT)t_j16 : HT(0);
+                const bool cone = st == S_CONE;
+                const HT s1 = cone ? (HT)t_a1 : (st != S_SATISFIED ? (HT)t_d : HT(0)), s2 = cone ? (HT)t_a2 : HT(0);
+                const int c = info >> 8, dim = (info >> 4) & 15;
+                HT A, B, A16, B16;
+                if (cone) {
+                    if (c == 0) { P0 = s1 * jr; P016 = s1 * j16; rho = s2; Qh = 0; Qh16 = 0; A = 0; B = 0; A16 = 0; B16 = 0; }
+                    else { Qh += s1 * jr; Qh16 += s1 * j16; A = s2 * jr; B = A; A16 = s2 * j16; B16 = A16; }
+                } else { A = s1 * jr; B = jr; A16 = s1 * j16; B16 = j16; }          // (a satisfied row: s1 = 0)
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A, B, acc, 0, 0, 0);
+                if (BORDER) { hb += A * B16; eta += A16 * B16; }
+                const bool endc = cone && c == dim - 1;
+                if (mw_any(endc)) {
+                    const HT A0 = endc ? P0 - Qh : HT(0), B0 = endc ? P0 : HT(0), A1 = endc ? rho * Qh - P0 : HT(0), B1 = endc ? Qh : HT(0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A0, B0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A1, B1, acc, 0, 0, 0);
+                    if (BORDER && endc) { hb += A0 * P016 + A1 * Qh16; eta += (P016 - Qh16) * P016 + (rho * Qh16 - P016) * Qh16; }
+                }
             }
-            if (nterm > 0 && st == S_CONE) {
-                ConeEval<T> z = cone_eval<T>(Rows<T, false>{rv}, i, dim, T(0));
-                const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu));
-                const T scl = z.mu * z.N / (z.Tn * z.Tn * z.Tn), dg = z.mu * z.mu - z.mu * z.N / z.Tn;
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        T v;
-                        if (r == 0 && c == 0) v = 1;
-                        else if (r == 0) v = -z.mu * z.U[c] / z.Tn;
-                        else if (c == 0) v = -z.mu * z.U[r] / z.Tn;
-                        else v = scl * z.U[r] * z.U[c] + (r == c ? dg : T(0));
-                        const HT hc = (r < dim && c < dim) ? HT(v * Dm * z.fri[r] * z.fri[c]) : HT(0);
-                        a[c] += jv[r] * hc; a16[c] += j16[r] * hc;
-                    }
-            } else if (nterm > 0) {
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    if (c < nterm) { const HT D = (HT)sr_get(rv, i + c, SR_D); a[c] = D * jv[c]; a16[c] = D * j16[c]; }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (!mw_any(c < nterm)) break;
-                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[c], jv[c], acc, 0, 0, 0);
-                if (BORDER) { hb += a[c] * j16[c]; eta += a16[c] * j16[c]; }
-            }
+        };
+        {
+            const int nl = nmax < e.lds_rows ? nmax : e.lds_rows;
+            row_pass(std::true_type{}, 0, nl);
+            row_pass(std::false_type{}, nl, nmax);
         }
         MW_TICK(t_rows)
         // ---- Cholesky: lane (rb, ri) collects row ri of the factor of ITS environment, Lr[k] = L[ri][k]
@@ -1234,10 +1273,10 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
             const int src = 16 * (k / 4) + ri;          // row k of every block sits in lanes 16 (k / 4) .. + 15, register 4 blk + k % 4
             const HT h0 = __shfl(acc[0 + k % 4], src), h1 = __shfl(acc[4 + k % 4], src), h2 = __shfl(acc[8 + k % 4], src), h3 = __shfl(acc[12 + k % 4], src);
             const HT hk = rb == 0 ? h0 : (rb == 1 ? h1 : (rb == 2 ? h2 : h3));
-            HT d = __shfl(hk, l48 | k);
+            HT d = blk_bcast(hk, k, rb);
             d = d < HT(1e-15) ? HT(1e-15) : d;
-            const HT sd = sqrtf(d), rs = HT(1) / sd;
-            const HT l = ri < k ? HT(0) : (ri == k ? sd : hk * rs);
+            const HT rs = __builtin_amdgcn_rsqf(d);          // (1 ulp: H is a preconditioner; the solves below use the same factor)
+            const HT l = ri < k ? HT(0) : (ri == k ? d * rs : hk * rs);
             Lr[k] = l;
             if (ri == k) invd = rs;
             acc = __builtin_amdgcn_mfma_f32_16x16x1f32(-l, l, acc, 0, 0, 0);
@@ -1247,10 +1286,10 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
         HT yg = (on && ri < nv16) ? (HT)gval : HT(0), yh = hb;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const HT bg = __shfl(yg * invd, l48 | k);
+            const HT bg = blk_bcast(yg * invd, k, rb);
             yg = ri == k ? bg : (ri > k ? yg - Lr[k] * bg : yg);
             if (BORDER) {
-                const HT bh = __shfl(yh * invd, l48 | k);
+                const HT bh = blk_bcast(yh * invd, k, rb);
                 yh = ri == k ? bh : (ri > k ? yh - Lr[k] * bh : yh);
             }
         }
@@ -1258,7 +1297,7 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
         if (BORDER) {
             HT lam2 = eta - blk_sum(yh * yh);
             lam2 = lam2 < HT(1e-15) ? HT(1e-15) : lam2;
-            const HT il = HT(1) / sqrtf(lam2);
+            const HT il = __builtin_amdgcn_rsqf(lam2);
             const T g17 = rv.R(L.grad + 16);
             const HT y17 = ((on ? (HT)g17 : HT(0)) - blk_sum(yh * yg)) * il;
             x17 = y17 * il;

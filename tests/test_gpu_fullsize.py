@@ -121,7 +121,7 @@ def test_bench_states_match_the_oracle(gpulib, bench_name, n):
     from tools.dump_bench_states import pick_envs
     from tests.test_tasks_parity import TOL
     env = MetaWorldGpuVectorEnv(bench_name, num_envs=n, seed=42, use_one_hot=True, precision="fp64", lib=gpulib)
-    bench.prepare(env, SimpleNamespace(no_stagger=False, warmup=20, allow_status=False), 0)      # raises on any status flag
+    bench.prepare(env, SimpleNamespace(no_stagger=False, warmup=20, allow_status=False, fixed_goals=False), 0)      # raises on any status flag
     elapsed = (np.arange(n, dtype=np.int64) * 7919 + bench.HORIZON + 20) % bench.HORIZON          # TimeLimit phase of every env now
     chosen = pick_envs(env, elapsed)
     assert len(chosen) == 4 * len(env.task_list)
