@@ -1173,20 +1173,31 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
     const int lane = e.thr & 63, rb = lane >> 4, ri = lane & 15;
     const unsigned long long act = __builtin_amdgcn_ballot_w64(active);          // bit s (s < lpb) = sub-lane 0 of the environment in slot s
     MW_TICK(t_0)
-    // ---- cone blocks: their 2 dim scalars, block-parallel over the environment's own sub-lanes, into the rows' AREF / JV fields
+    // ---- per-row coefficients, block-parallel over the environment's own sub-lanes (as the per-environment routine walks the
+    // blocks), into the rows' JV field (dead until the line search rewrites it): coefficient of the term (coef j_r) (x) j_r --
+    // 0 for a satisfied row, D for a quadratic one, the cone scalars (header) for the rows of a cone block, whose LAST row carries
+    // a minus sign as the "two more terms are due" flag; the cone blocks' other scalars go to AREF (dead after the warm start)
     if (active) {
         const int nblk = e.I(L.icount + IC_NBLK);
         for (int kb = e.sub; kb < nblk; kb += e.nsub) {
             const int i = block_row(e, kb);
-            if ((int)sr_get(e, i, SR_STATE) != S_CONE) continue;
-            const int dim = ((int)sr_get(e, i, SR_INFO) >> 4) & 15;
-            ConeEval<T> z = cone_eval<T>(Rows<T, false>{e}, i, dim, T(0));
-            const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu)), sDm = mw_sqrt(Dm), kap = z.mu / z.Tn;
-            const T dg = z.mu * z.mu - z.mu * z.N / z.Tn, sdg = mw_sqrt(dg > 0 ? dg : T(0));
-            sr_set(e, i, SR_AREF, sDm * z.fri[0]); sr_set(e, i, SR_JV, z.N / (z.mu * z.Tn));
+            const int st = (int)sr_get(e, i, SR_STATE), info = (int)sr_get(e, i, SR_INFO), dim = (info >> 4) & 15;
+            if (st == S_CONE) {
+                ConeEval<T> z = cone_eval<T>(Rows<T, false>{e}, i, dim, T(0));
+                const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu)), kap = z.mu / z.Tn;
+                const T dg0 = z.mu * z.mu - z.mu * z.N / z.Tn, dg = dg0 > 0 ? dg0 : T(0), sDm = mw_sqrt(Dm);
+                sr_set(e, i, SR_JV, Dm * z.fri[0] * z.fri[0]); sr_set(e, i, SR_AREF, z.N / (z.mu * z.Tn));
 #pragma unroll
-            for (int r = 1; r < 4; r++)
-                if (r < dim) { sr_set(e, i + r, SR_AREF, kap * z.U[r] * sDm * z.fri[r]); sr_set(e, i + r, SR_JV, sDm * sdg * z.fri[r]); }
+                for (int r = 1; r < 4; r++)
+                    if (r < dim) {
+                        const T g2 = Dm * dg * z.fri[r] * z.fri[r];
+                        sr_set(e, i + r, SR_JV, r == dim - 1 ? -(g2 > T(1e-30) ? g2 : T(1e-30)) : g2);
+                        sr_set(e, i + r, SR_AREF, kap * z.U[r] * sDm * z.fri[r]);
+                    }
+            } else {
+                const int nr = (info & 15) == C_CONTACT ? dim : 1;
+                for (int r = 0; r < nr; r++) sr_set(e, i + r, SR_JV, st == S_SATISFIED ? T(0) : sr_get(e, i + r, SR_D));
+            }
         }
     }
     MW_SYNC();
@@ -1219,51 +1230,61 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
         int nmax = __builtin_amdgcn_readlane(ne, 0);
         { const int n1 = __builtin_amdgcn_readlane(ne, 16), n2 = __builtin_amdgcn_readlane(ne, 32), n3 = __builtin_amdgcn_readlane(ne, 48);
           nmax = nmax > n1 ? nmax : n1; nmax = nmax > n2 ? nmax : n2; nmax = nmax > n3 ? nmax : n3; }
-        // ---- + J' D J: one pass over the rows of the four environments side by side.  Row r is wave-uniform, so "scratchpad or
-        // column store" is decided once per loop, not per access: the seven reads of a row are issued together and waited for once
-        // (rows beyond an environment's nefc still exist physically -- stale -- and are masked after the read)
-        HT P0 = 0, Qh = 0, rho = 0, P016 = 0, Qh16 = 0;
-        auto row_pass = [&](auto src_tag, int r_begin, int r_end) {
-            constexpr bool LDSP = decltype(src_tag)::value;
-            for (int r = r_begin; r < r_end; r++) {
-                const bool in = on && r < ne;
-                T t_st, t_info, t_j, t_j16 = 0, t_a1, t_a2, t_d;
-                const int jcol = ri < nv16 ? ri : 0;
-                if (LDSP) {
-                    MW_LDS T* p = rv.lds + rv.S(r, 0) * rv.lds_stride;
-                    t_st = p[SR_STATE * rv.lds_stride]; t_info = p[SR_INFO * rv.lds_stride]; t_j = p[(SR_N + jcol) * rv.lds_stride];
-                    if (BORDER) t_j16 = p[(SR_N + 16) * rv.lds_stride];
-                    t_a1 = p[SR_AREF * rv.lds_stride]; t_a2 = p[SR_JV * rv.lds_stride]; t_d = p[SR_D * rv.lds_stride];
-                } else {
-                    t_st = EX(rv, r, sr_slot(SR_STATE)); t_info = EX(rv, r, sr_slot(SR_INFO)); t_j = EJ(rv, r, jcol);
-                    if (BORDER) t_j16 = EJ(rv, r, 16);
-                    t_a1 = EX(rv, r, sr_slot(SR_AREF)); t_a2 = EX(rv, r, sr_slot(SR_JV)); t_d = EX(rv, r, sr_slot(SR_D));
-                }
-                const int st = in ? (int)t_st : (int)S_SATISFIED, info = in ? (int)t_info : 0;
-                const HT jr = (in && ri < nv16) ? (HT)t_j : HT(0), j16 = (BORDER && in) ? (HT)t_j16 : HT(0);
-                const bool cone = st == S_CONE;
-                const HT s1 = cone ? (HT)t_a1 : (st != S_SATISFIED ? (HT)t_d : HT(0)), s2 = cone ? (HT)t_a2 : HT(0);
-                const int c = info >> 8, dim = (info >> 4) & 15;
-                HT A, B, A16, B16;
-                if (cone) {
-                    if (c == 0) { P0 = s1 * jr; P016 = s1 * j16; rho = s2; Qh = 0; Qh16 = 0; A = 0; B = 0; A16 = 0; B16 = 0; }
-                    else { Qh += s1 * jr; Qh16 += s1 * j16; A = s2 * jr; B = A; A16 = s2 * j16; B16 = A16; }
-                } else { A = s1 * jr; B = jr; A16 = s1 * j16; B16 = j16; }          // (a satisfied row: s1 = 0)
-                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A, B, acc, 0, 0, 0);
-                if (BORDER) { hb += A * B16; eta += A16 * B16; }
-                const bool endc = cone && c == dim - 1;
-                if (mw_any(endc)) {
-                    const HT A0 = endc ? P0 - Qh : HT(0), B0 = endc ? P0 : HT(0), A1 = endc ? rho * Qh - P0 : HT(0), B1 = endc ? Qh : HT(0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A0, B0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A1, B1, acc, 0, 0, 0);
-                    if (BORDER && endc) { hb += A0 * P016 + A1 * Qh16; eta += (P016 - Qh16) * P016 + (rho * Qh16 - P016) * Qh16; }
-                }
+        // ---- + J' D J: one pass over the rows of the four environments side by side: term (|coef_r| j_r) (x) j_r for every row,
+        // two reads per lane.  Row r is wave-uniform, so "scratchpad or column store" is decided once per loop, not per access;
+        // the scratchpad rows go four at a time (eight reads issued together).  Rows beyond an environment's nefc still exist
+        // physically (stale) and are masked after the read.  A negative coefficient ends a cone block: its two cross terms
+        // (p_0 - q^) p_0' - p_0 p_0' ... see the header; here: (rho q^ - p_0) q^' - q^ p_0', p_0 p_0' being row 0's own term.
+        auto cone_tail = [&](int r, bool flag) {          // wave-uniform call; lanes with flag set finish the cone block that ends at row r
+            HT A0 = 0, B0 = 0, A1 = 0, B1 = 0, h0 = 0, e0 = 0;
+            if (flag) {
+                const int dim = ((int)sr_get(rv, r, SR_INFO) >> 4) & 15, r0 = r - dim + 1;
+                const HT w0 = sqrtf((HT)sr_get(rv, r0, SR_JV)), rho = (HT)sr_get(rv, r0, SR_AREF);
+                const HT P0 = ri < nv16 ? w0 * (HT)ej_get(rv, r0, ri) : HT(0), P016 = BORDER ? w0 * (HT)ej_get(rv, r0, 16) : HT(0);
+                HT Qh = 0, Qh16 = 0;
+#pragma unroll
+                for (int c = 1; c < 4; c++)
+                    if (c < dim) {
+                        const HT cc = (HT)sr_get(rv, r0 + c, SR_AREF);
+                        if (ri < nv16) Qh += cc * (HT)ej_get(rv, r0 + c, ri);
+                        if (BORDER) Qh16 += cc * (HT)ej_get(rv, r0 + c, 16);
+                    }
+                A0 = -Qh; B0 = P0; A1 = rho * Qh - P0; B1 = Qh;
+                h0 = A0 * P016 + A1 * Qh16; e0 = -Qh16 * P016 + (rho * Qh16 - P016) * Qh16;
             }
+            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A0, B0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A1, B1, acc, 0, 0, 0);
+            if (BORDER) { hb += h0; eta += e0; }
+        };
+        auto row_term = [&](int r, T t_c, T t_j, T t_j16) {
+            const bool in = on && r < ne;
+            const HT cf = in ? (HT)t_c : HT(0), jr = (in && ri < nv16) ? (HT)t_j : HT(0), j16 = (BORDER && in) ? (HT)t_j16 : HT(0);
+            const HT A = fabsf(cf) * jr;
+            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A, jr, acc, 0, 0, 0);
+            if (BORDER) { hb += A * j16; eta += fabsf(cf) * j16 * j16; }
+            const bool flag = cf < HT(0);
+            if (mw_any(flag)) cone_tail(r, flag);
         };
         {
-            const int nl = nmax < e.lds_rows ? nmax : e.lds_rows;
-            row_pass(std::true_type{}, 0, nl);
-            row_pass(std::false_type{}, nl, nmax);
+            const int nl = nmax < e.lds_rows ? nmax : e.lds_rows, jcol = ri < nv16 ? ri : 0;
+            int r = 0;
+            for (; r + 4 <= nl; r += 4) {          // scratchpad rows, four at a time
+                T tc[4], tj[4], tj16[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    MW_LDS T* p = rv.lds + rv.S(r + q, 0) * rv.lds_stride;
+                    tc[q] = p[SR_JV * rv.lds_stride]; tj[q] = p[(SR_N + jcol) * rv.lds_stride];
+                    tj16[q] = BORDER ? p[(SR_N + 16) * rv.lds_stride] : T(0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) row_term(r + q, tc[q], tj[q], tj16[q]);
+            }
+            for (; r < nl; r++) {
+                MW_LDS T* p = rv.lds + rv.S(r, 0) * rv.lds_stride;
+                row_term(r, p[SR_JV * rv.lds_stride], p[(SR_N + jcol) * rv.lds_stride], BORDER ? p[(SR_N + 16) * rv.lds_stride] : T(0));
+            }
+            for (; r < nmax; r++)               // rows beyond the scratchpad: column store
+                row_term(r, EX(rv, r, sr_slot(SR_JV)), EJ(rv, r, jcol), BORDER ? T(EJ(rv, r, 16)) : T(0));
         }
         MW_TICK(t_rows)
         // ---- Cholesky: lane (rb, ri) collects row ri of the factor of ITS environment, Lr[k] = L[ri][k]

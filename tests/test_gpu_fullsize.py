@@ -7,11 +7,13 @@ replayed at this size, so the full-size batch is tied to what IS pinned at small
       task must produce the same next physics step (qpos / qvel to 1e-7 / 1e-5, identical contact and constraint-row counts);
   (c) no capacity-overflow / instability flag may be raised anywhere in the batch.
 """
+import os
+
 import numpy as np
 import pytest
 
 from metaworld_amd import tasks as T
-from tests.helpers import WELD
+from tests.helpers import ROOT, WELD
 
 pytestmark = pytest.mark.gpu
 

@@ -1,6 +1,6 @@
-# round-4 development call: wave-cooperative Newton direction (MFMA), second version (row pass, DPP sums, readlane broadcasts)
+# round-4 development call: wave-cooperative Newton direction (MFMA), third version (per-row coefficients, two reads per row)
 set -u
-O=gpurun_out/c3; mkdir -p $O
+O=gpurun_out/c4; mkdir -p $O
 for v in libmwgpu.so; do for lpb in 4 8; do
   MW_LIB=$v MW_LANES_PER_BLOCK=$lpb timeout 120 python tools/experiments/ab_physics.py 2>&1 | grep -v amdgpu.ids | cut -c1-330
 done; done > $O/ab_physics.txt 2>&1
