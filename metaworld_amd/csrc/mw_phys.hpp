@@ -1151,11 +1151,14 @@ template <int CTRL> __device__ inline float mw_dpp(float v) {
 }
 // sum over the 16 lanes of a block, in every lane: four rotations inside the DPP row (row_ror:8 / 4 / 2 / 1), no LDS crossbar
 __device__ inline float blk_sum(float v) { v += mw_dpp<0x128>(v); v += mw_dpp<0x124>(v); v += mw_dpp<0x122>(v); v += mw_dpp<0x121>(v); return v; }
-// lane k of every block to all lanes of that block (k wave-uniform): four v_readlane + selects
-__device__ inline float blk_bcast(float v, int k, int rb) {
-    const int i = __builtin_bit_cast(int, v);
-    const int s0 = __builtin_amdgcn_readlane(i, k), s1 = __builtin_amdgcn_readlane(i, 16 + k), s2 = __builtin_amdgcn_readlane(i, 32 + k), s3 = __builtin_amdgcn_readlane(i, 48 + k);
-    return __builtin_bit_cast(float, rb == 0 ? s0 : (rb == 1 ? s1 : (rb == 2 ? s2 : s3)));
+// lane k of every 16-lane block to all lanes of that block: one DPP move (row_newbcast:k; k is a constant after unrolling)
+__device__ inline float blk_bcast(float v, int k) {
+    switch (k & 15) {
+    case 0: return mw_dpp<0x150>(v); case 1: return mw_dpp<0x151>(v); case 2: return mw_dpp<0x152>(v); case 3: return mw_dpp<0x153>(v);
+    case 4: return mw_dpp<0x154>(v); case 5: return mw_dpp<0x155>(v); case 6: return mw_dpp<0x156>(v); case 7: return mw_dpp<0x157>(v);
+    case 8: return mw_dpp<0x158>(v); case 9: return mw_dpp<0x159>(v); case 10: return mw_dpp<0x15A>(v); case 11: return mw_dpp<0x15B>(v);
+    case 12: return mw_dpp<0x15C>(v); case 13: return mw_dpp<0x15D>(v); case 14: return mw_dpp<0x15E>(v); default: return mw_dpp<0x15F>(v);
+    }
 }
 template <typename T>
 __device__ inline Env<T> env_view(const Env<T>& e, int slot) {          // the same workgroup's environment `slot`, seen from this thread
@@ -1287,37 +1290,42 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
                 row_term(r, EX(rv, r, sr_slot(SR_JV)), EJ(rv, r, jcol), BORDER ? T(EJ(rv, r, 16)) : T(0));
         }
         MW_TICK(t_rows)
-        // ---- Cholesky: lane (rb, ri) collects row ri of the factor of ITS environment, Lr[k] = L[ri][k]
+        // ---- Cholesky: lane (rb, ri) collects row ri of the factor of ITS environment, Lr[k] = L[ri][k] (0 above the diagonal).
+        // Branch-free: the block's copy of row k is picked with bit masks, the pivot travels by a DPP row broadcast.
         HT Lr[16], invd = 1;
+        const unsigned m0 = rb == 0 ? ~0u : 0u, m1 = rb == 1 ? ~0u : 0u, m2 = rb == 2 ? ~0u : 0u, m3 = rb == 3 ? ~0u : 0u;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int src = 16 * (k / 4) + ri;          // row k of every block sits in lanes 16 (k / 4) .. + 15, register 4 blk + k % 4
-            const HT h0 = __shfl(acc[0 + k % 4], src), h1 = __shfl(acc[4 + k % 4], src), h2 = __shfl(acc[8 + k % 4], src), h3 = __shfl(acc[12 + k % 4], src);
-            const HT hk = rb == 0 ? h0 : (rb == 1 ? h1 : (rb == 2 ? h2 : h3));
-            HT d = blk_bcast(hk, k, rb);
-            d = d < HT(1e-15) ? HT(1e-15) : d;
+            const unsigned u0 = __builtin_bit_cast(unsigned, __shfl(acc[0 + k % 4], src)), u1 = __builtin_bit_cast(unsigned, __shfl(acc[4 + k % 4], src)),
+                           u2 = __builtin_bit_cast(unsigned, __shfl(acc[8 + k % 4], src)), u3 = __builtin_bit_cast(unsigned, __shfl(acc[12 + k % 4], src));
+            const HT hk = __builtin_bit_cast(float, (u0 & m0) | (u1 & m1) | (u2 & m2) | (u3 & m3));
+            const HT d = fmaxf(blk_bcast(hk, k), HT(1e-15));
             const HT rs = __builtin_amdgcn_rsqf(d);          // (1 ulp: H is a preconditioner; the solves below use the same factor)
-            const HT l = ri < k ? HT(0) : (ri == k ? d * rs : hk * rs);
+            const unsigned keep = (unsigned)((k - 1 - ri) >> 31);          // all ones for ri >= k
+            const HT l = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, (ri == k ? d : hk) * rs) & keep);
             Lr[k] = l;
-            if (ri == k) invd = rs;
+            invd = ri == k ? rs : invd;
             acc = __builtin_amdgcn_mfma_f32_16x16x1f32(-l, l, acc, 0, 0, 0);
         }
-        // ---- forward substitution, right-hand sides g (and the border column h)
+        // ---- forward substitution, right-hand sides g (and the border column h): y_k = lane k's residual / L[k][k], broadcast,
+        // subtracted by the lanes below (Lr[k] is 0 in the lanes above)
         const T gval = rv.R(L.grad + (ri < nv16 ? ri : 0));
         HT yg = (on && ri < nv16) ? (HT)gval : HT(0), yh = hb;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const HT bg = blk_bcast(yg * invd, k, rb);
-            yg = ri == k ? bg : (ri > k ? yg - Lr[k] * bg : yg);
+            const HT bg = blk_bcast(yg * invd, k);
+            const HT ng = yg - Lr[k] * bg;
+            yg = ri == k ? bg : ng;
             if (BORDER) {
-                const HT bh = blk_bcast(yh * invd, k, rb);
-                yh = ri == k ? bh : (ri > k ? yh - Lr[k] * bh : yh);
+                const HT bh = blk_bcast(yh * invd, k);
+                const HT nh = yh - Lr[k] * bh;
+                yh = ri == k ? bh : nh;
             }
         }
         HT x17 = 0;
         if (BORDER) {
-            HT lam2 = eta - blk_sum(yh * yh);
-            lam2 = lam2 < HT(1e-15) ? HT(1e-15) : lam2;
+            const HT lam2 = fmaxf(eta - blk_sum(yh * yh), HT(1e-15));
             const HT il = __builtin_amdgcn_rsqf(lam2);
             const T g17 = rv.R(L.grad + 16);
             const HT y17 = ((on ? (HT)g17 : HT(0)) - blk_sum(yh * yg)) * il;
@@ -1325,11 +1333,13 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
             yg -= yh * x17;
         }
         // ---- backward substitution with the transposed factor: x_k = (y_k - sum_{n > k} L[n][k] x_n) / L[k][k]
+        // (x is still 0 in the lanes <= k when step k sums, and Lr[k] is 0 in the lanes < k: no mask needed)
         HT x = 0;
 #pragma unroll
         for (int k = 15; k >= 0; k--) {
-            const HT sum = blk_sum(ri > k ? Lr[k] * x : HT(0));
-            if (ri == k) x = (yg - sum) * invd;
+            const HT sum = blk_sum(Lr[k] * x);
+            const HT xk = (yg - sum) * invd;
+            x = ri == k ? xk : x;
         }
         if (on && ri < nv16) rv.R(L.search + ri) = (T)x;
         if (BORDER && on && ri == 0) rv.R(L.search + 16) = (T)x17;

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 cmd=${1:-run}; shift || true
 if [ "$cmd" = build ]; then
   name=$1; shift
-  ${HIPCC:-/opt/rocm/bin/hipcc} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o metaworld_amd/libmwgpu_v_$name.so metaworld_amd/csrc/mwgpu.hip && ls -la metaworld_amd/libmwgpu_v_$name.so
+  ${HIPCC:-/opt/rocm/bin/hipcc} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form "$@" -o metaworld_amd/libmwgpu_v_$name.so metaworld_amd/csrc/mwgpu.hip && ls -la metaworld_amd/libmwgpu_v_$name.so
   exit $?
 fi
 rounds=2
