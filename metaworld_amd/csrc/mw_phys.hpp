@@ -1185,7 +1185,16 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
         for (int kb = e.sub; kb < nblk; kb += e.nsub) {
             const int i = block_row(e, kb);
             const int st = (int)sr_get(e, i, SR_STATE), info = (int)sr_get(e, i, SR_INFO), dim = (info >> 4) & 15;
-            if (st == S_CONE) {
+            if (st != S_CONE && i + 4 <= e.lds_rows) {          // the common case, straight from / to the scratchpad: up to four rows, no per-access branch
+                MW_LDS T* p = e.lds + e.S(i, 0) * e.lds_stride;
+                const int nr = (info & 15) == C_CONTACT ? dim : 1, rw = e.lds_w * e.lds_stride;
+                T dd[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) dd[r] = p[(r < nr ? r : 0) * rw + SR_D * e.lds_stride];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (r < nr) p[r * rw + SR_JV * e.lds_stride] = st == S_SATISFIED ? T(0) : dd[r];
+            } else if (st == S_CONE) {
                 ConeEval<T> z = cone_eval<T>(Rows<T, false>{e}, i, dim, T(0));
                 const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu)), kap = z.mu / z.Tn;
                 const T dg0 = z.mu * z.mu - z.mu * z.N / z.Tn, dg = dg0 > 0 ? dg0 : T(0), sDm = mw_sqrt(Dm);
@@ -1209,20 +1218,24 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
         const int slot = g0 + rb;
         const bool on = slot < e.nslot && ((act >> slot) & 1ull) != 0ull;
         const Env<T> rv = env_view(e, on ? slot : e.slot);                       // (an idle role lane looks at its own environment and contributes zeros)
-        // ---- H <- M in the accumulator layout: lane (rb, ri), register 4 blk + v  =  H_blk[4 rb + v][ri]
+        // ---- H <- M in the accumulator layout: lane (rb, ri), register 4 blk + v  =  H_blk[4 rb + v][ri].  All sixteen loads
+        // are issued before the first use (as separate statements the compiler waited for every one of them: 16 memory round
+        // trips, more than the rest of the assembly)
         mw_f16v acc;
+        {
+            T mv[16];
+            bool ins[16];
 #pragma unroll
-        for (int blk = 0; blk < 4; blk++) {
-            const int s2 = g0 + blk;
-            const bool on2 = s2 < e.nslot && ((act >> s2) & 1ull) != 0ull;
-            const Env<T> r2 = env_view(e, on2 ? s2 : e.slot);
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
+            for (int q = 0; q < 16; q++) {
+                const int blk = q >> 2, v = q & 3, s2 = g0 + blk;
+                const bool on2 = s2 < e.nslot && ((act >> s2) & 1ull) != 0ull;
                 const int mrow = 4 * rb + v, hi = mrow > ri ? mrow : ri, lo = mrow > ri ? ri : mrow;
-                const bool inside = on2 && hi < nv16;
-                const T val = r2.R(L.qM + (inside ? hi * nv + lo : 0));
-                acc[4 * blk + v] = inside ? (HT)val : (mrow == ri ? HT(1) : HT(0));
+                ins[q] = on2 && hi < nv16;
+                const int idx = L.qM + (ins[q] ? hi * nv + lo : 0);
+                mv[q] = ((MW_GLOBAL T*)(e.col + ((on2 ? s2 : e.slot) - e.slot)))[(unsigned)idx * e.stride];
             }
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = ins[q] ? (HT)mv[q] : ((4 * rb + (q & 3)) == ri ? HT(1) : HT(0));
         }
         HT hb = 0, eta = 1;                                                        // border (nv = 17): H[16][ri], H[16][16]
         if (BORDER) {
