@@ -713,7 +713,8 @@ MW_HD Shape<T> make_shape(const Env<T> e, int g) {
 // that face, at least the depth away from its edges, the face normal is the exact contact direction (delta >= 0: the box lies in
 // the half space below the face and p's projection is a box point; delta < 0: the face (face - p) of the Minkowski difference
 // contains the foot of the origin with an in-plane clearance >= depth, so no other supporting plane is closer than the depth).
-// (iii) anything else (edges, corners, deep or partial overlaps): -1, the caller runs the portal refinement.
+// (iii) anything else (edges, corners, partial overlaps, an overlap deeper than the box's half thickness along that axis): -1, the
+// caller runs the portal refinement.
 template <typename T>
 MW_HD int box_face_sat(const Shape<T>& A, const Shape<T>& box, bool box_first, T margin, Hit<T>* h) {
     T best = T(-1e30);
@@ -730,6 +731,9 @@ MW_HD int box_face_sat(const Shape<T>& A, const Shape<T>& box, bool box_first, T
     }
     const V3<T> locv = mulT(box.mat, bp - box.pos);
     const T loc[3] = {locv.x, locv.y, locv.z}, inset = best < 0 ? -best : T(0);
+    // deeper than the box is thick along that axis (a thin wall or plate): the witness lies beyond the box's mid plane and the face
+    // normal need not be the direction of least penetration -> the caller's portal refinement decides (same guard in the oracle)
+    if (inset > box.size[bk]) return -1;
     for (int j = 0; j < 3; j++)
         if (j != bk && mw_abs(loc[j]) > box.size[j] - inset - (sizeof(T) == 8 ? T(1e-9) : T(1e-6))) return -1;
     h->dist = best;

@@ -27,6 +27,8 @@ namespace {
 // one wavefront per workgroup; the dynamic LDS allocation is the lanes' scratchpad (solver row scalars, mw_phys.hpp)
 template <class F>
 __global__ void __launch_bounds__(64) k_lanes(F f, int block_words, int chain) {
+    // (MW_SYNC, mw_common.hpp, is a wavefront-scope fence + wave barrier: correct only while a workgroup IS one wave64, and the lane
+    //  roles of newton_direction_wave, mw_phys.hpp, assume 64 lanes: Backend::init refuses a device whose wavefront is not 64 wide)
     extern __shared__ float mw_scratchpad[];
     f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, block_words, 0, 0, chain});
 }
@@ -95,6 +97,9 @@ struct Backend {
         if (d.ready) return;
         hip_check(hipDeviceGetAttribute(&d.max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device), "hipDeviceGetAttribute");
         hip_check(hipDeviceGetAttribute(&d.num_cu, hipDeviceAttributeMultiprocessorCount, device), "hipDeviceGetAttribute");
+        int wave = 0;
+        hip_check(hipDeviceGetAttribute(&wave, hipDeviceAttributeWarpSize, device), "hipDeviceGetAttribute");
+        if (wave != 64) throw std::runtime_error("libmwgpu: the lane programs assume 64-wide wavefronts (one wave per workgroup, wave-local exchanges); this device reports " + std::to_string(wave));
         hip_check(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking), "hipStreamCreate");
         for (int k = 0; k < 2; k++) {

@@ -779,6 +779,9 @@ static int box_face_sat(const Shape* A, const Shape* box, int box_first, double 
         }
     if (best > margin) return 0;
     double t[3], loc[3], inset = best < 0 ? -best : 0;
+    /* deeper than the box is thick along that axis (a thin wall or plate): the witness lies beyond the box's mid plane, the face
+       normal need not be the direction of least penetration -> portal refinement decides (same guard in csrc/mw_collide.hpp) */
+    if (inset > box->size[bk]) return -1;
     sub3(t, bp, box->pos);
     mulT(loc, box->mat, t);
     for (int j = 0; j < 3; j++)

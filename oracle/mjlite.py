@@ -17,14 +17,26 @@ _SRCS = ["mjl_core.c", "mjl_collide.c"]
 
 
 def build(force=False):
+    """compile the C restatement; safe under concurrent callers (pytest-xdist workers): one builder at a time, the compiler writes
+    a temporary file that is renamed into place"""
+    import fcntl
     srcs = [os.path.join(_HERE, s) for s in _SRCS]
     deps = srcs + [os.path.join(_HERE, "mjl_core.h")]
-    if (not force and os.path.exists(_LIB_PATH)
-            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in deps if os.path.exists(s))):
+
+    def fresh():
+        return os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in deps if os.path.exists(s))
+    if not force and fresh():
         return _LIB_PATH
     os.makedirs(os.path.dirname(_LIB_PATH), exist_ok=True)
-    cmd = ["gcc", "-O2", "-std=gnu99", "-shared", "-fPIC", "-ffp-contract=off", "-o", _LIB_PATH] + srcs + ["-lm"]
-    subprocess.check_call(cmd)
+    with open(_LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or not fresh():
+                tmp = f"{_LIB_PATH}.tmp.{os.getpid()}"
+                subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-shared", "-fPIC", "-ffp-contract=off", "-o", tmp] + srcs + ["-lm"])
+                os.replace(tmp, _LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
 
 
