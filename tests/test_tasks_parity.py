@@ -48,5 +48,5 @@ def test_task_fp32_close_to_reference_trace(hostsim, task):
     # box-close: the reference's reward adds a bonus once the lid is above z = 0.02 -- exactly its resting height; in the trace
     # the lid sits at 0.02000011 (fp64) / 0.01999891 (fp32) at one step, so the single-precision reward is on the other branch
     tol_rew = 2.0 if task == "box-close-v3" else 5e-2
-    # door-unlock: one success flag of the trace sits on the threshold of an ill-conditioned state (TOL above) in single precision
-    assert r["reset"] < 1e-2 and r["obs"] < 1e-2 and r["reward"] < tol_rew and r["success_mismatch"] <= (1 if task == "door-unlock-v3" else 0), r
+    # (success flags are exact in single precision too: the one-mismatch allowance door-unlock had in round 3 is gone)
+    assert r["reset"] < 1e-2 and r["obs"] < 1e-2 and r["reward"] < tol_rew and r["success_mismatch"] == 0, r
