@@ -459,6 +459,22 @@ def main(argv=None):
             out["saturation"] = {"envs": env3.num_envs, "value": env3.num_envs * 100 / w3, "unit": "env-steps/s", "steps": 100,
                                  "kernel_ms_per_launch": k3 / 100, "status_flags": st3}
             env3.close()
+        if world == 1 and on_gpu and not args.no_saturation:
+            # the open-loop rollout with several steps per launch (mw_step_resident_fused): the same env-steps bit for bit, the batch
+            # synchronised once per launch instead of once per step.  NOT `value`: a VectorEnv.step returns after every step.
+            env4 = build_env(args, args.precision, rank, world, local_rank, lib)
+            prepare(env4, args, rank)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            k4 = env4.step_resident(args.steps, steps_per_launch=50)
+            torch.cuda.synchronize()
+            w4 = time.perf_counter() - t4
+            st4 = check_outputs(env4, args.allow_status)
+            out["fused_rollout"] = {"steps_per_launch": 50, "value": env4.num_envs * args.steps / w4, "unit": "env-steps/s", "steps": args.steps,
+                                    "kernel_ms_per_step": k4 / args.steps, "status_flags": st4,
+                                    "note": "open-loop rollout, 50 consecutive steps of every environment per kernel launch (same results as the per-step "
+                                            "loop bit for bit: tests/test_resident_schedule.py); reported beside `value`, never as it"}
+            env4.close()
         if world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl_task)
         print(json.dumps(out), flush=True)

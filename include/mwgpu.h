@@ -101,6 +101,12 @@ int mw_step_resident(mw_ctx* c, int nsteps, int action_steps, float* kernel_ms /
 /* the same loop with the per-step cross-rank bookkeeping gather inside it (mw_comm_init first when world_size > 1): launch k+1
  * overlaps the all-gather of step k on the side stream; returns after both streams have drained */
 int mw_step_resident_gather(mw_ctx* c, int nsteps, int action_steps, float* kernel_ms);
+/* the same open loop with `steps_per_launch` consecutive steps of every environment inside ONE launch (no reference counterpart:
+ * the reference's SyncVectorEnv returns after every step).  Environments are independent, so the final state and outputs equal those
+ * of mw_step_resident bit for bit; the batch is synchronised once per launch instead of once per step, which removes the wait for
+ * each step's slowest environment.  For rollouts nobody observes between steps (pre-uploaded actions); the output buffers and the
+ * bookkeeping record hold the last step. */
+int mw_step_resident_fused(mw_ctx* c, int nsteps, int action_steps, int steps_per_launch, float* kernel_ms);
 /* RandomTaskSelectWrapper.reset (metaworld/wrappers.py:116-119: every reset of a sub-env draws a new task) INSIDE the resident
  * loop: once a schedule is set, the k-th auto-reset of env i that happens in mw_step_resident / mw_step_resident_gather takes goal
  * goal_schedule[min(k, K-1)][i] (k counts from 0 since this call) instead of the look-ahead goal of the last mw_step / mw_reset.
@@ -138,6 +144,11 @@ int mw_reset_device(mw_ctx* c, const uint8_t* mask /*device [N] or NULL = all*/,
 int mw_policy_actions(mw_ctx* c, const int32_t* policy_id /*[N]*/, const double* obs /*[N][D]*/, float* actions /*[N][4] out*/);
 int mw_policy_rollout(mw_ctx* c, const int32_t* policy_id /*[N]*/, const int32_t* goal_schedule /*[K][N]*/, int K, int nsteps,
                       int32_t* episodes /*[N] out or NULL*/, int32_t* successes /*[N] out or NULL*/, float* kernel_ms /*or NULL*/);
+
+/* the same closed loop with `steps_per_launch` (policy, step) pairs of every environment per kernel launch: an environment's policy is
+ * evaluated by its own thread between two of its steps -- same episodes and successes, no batch-wide synchronisation inside a launch */
+int mw_policy_rollout_fused(mw_ctx* c, const int32_t* policy_id /*[N]*/, const int32_t* goal_schedule /*[K][N]*/, int K, int nsteps,
+                            int steps_per_launch, int32_t* episodes /*[N] out or NULL*/, int32_t* successes /*[N] out or NULL*/, float* kernel_ms /*or NULL*/);
 
 /* ---- cross-rank bookkeeping gather (no reference counterpart: the reference's SyncVectorEnv lives in one
  *      process).  Envs are independent, so stepping needs no communication; the one exchange is this 12-byte record per

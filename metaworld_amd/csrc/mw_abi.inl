@@ -118,6 +118,10 @@ int MW_API(policy_actions)(mw_ctx* c, const int32_t* policy_id, const double* ob
 int MW_API(policy_rollout)(mw_ctx* c, const int32_t* policy_id, const int32_t* schedule, int K, int nsteps, int32_t* episodes, int32_t* successes, float* ms) {
     MW_TRY(c, { MW_NEED_IMPL(c); if (!policy_id || !schedule) throw std::invalid_argument("policy_rollout: null argument"); c->impl->policy_rollout(policy_id, schedule, K, nsteps, episodes, successes, ms); });
 }
+int MW_API(policy_rollout_fused)(mw_ctx* c, const int32_t* policy_id, const int32_t* schedule, int K, int nsteps, int per_launch, int32_t* episodes, int32_t* successes, float* ms) {
+    MW_TRY(c, { MW_NEED_IMPL(c); if (!policy_id || !schedule) throw std::invalid_argument("policy_rollout_fused: null argument"); if (per_launch < 1) throw std::invalid_argument("policy_rollout_fused: steps_per_launch must be >= 1"); c->impl->policy_rollout(policy_id, schedule, K, nsteps, episodes, successes, ms, per_launch); });
+}
+int MW_API(step_resident_fused)(mw_ctx* c, int nsteps, int asteps, int per_launch, float* ms) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->step_fused(nsteps, asteps, per_launch, ms); }); }
 int MW_API(step_resident_gather)(mw_ctx* c, int nsteps, int asteps, float* ms) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->step_resident_gather(nsteps, asteps, ms); }); }
 int MW_API(comm_unique_id)(uint8_t* id_out) {
     try { if (!id_out) return -1; Backend::comm_unique_id(id_out); return 0; } catch (...) { return -1; }

@@ -457,9 +457,10 @@ public:
     virtual void step_device(const float* d_act, const int* d_next_goal, const mw_device_out* out) = 0;
     virtual void reset_device(const uint8_t* d_mask, const int* d_goal_idx, double* d_obs) = 0;
     virtual void policy_actions(const int* policy_id, const double* obs, float* act) = 0;
-    virtual void policy_rollout(const int* policy_id, const int* schedule, int K, int nsteps, int* episodes, int* successes, float* kernel_ms) = 0;
+    virtual void policy_rollout(const int* policy_id, const int* schedule, int K, int nsteps, int* episodes, int* successes, float* kernel_ms, int per_launch = 1) = 0;
     virtual void upload_actions(const float* act, int nsteps) = 0;
     virtual void step_resident_gather(int nsteps, int act_stride_steps, float* kernel_ms) = 0;
+    virtual void step_fused(int nsteps, int act_stride_steps, int per_launch, float* kernel_ms) = 0;
     virtual void comm_init(const void* id128, int rank, int world) = 0;
     virtual void comm_info(int* out /*[4]*/) = 0;
     virtual void gather_bookkeeping(mw_bookkeeping* out, int out_on_device) = 0;
@@ -957,7 +958,7 @@ public:
 
     // closed loop entirely on the device: reset to schedule[0], then nsteps x (policy kernel -> step kernel); the k-th
     // auto-reset of env i takes goal schedule[min(k, K-1)][i].  No host round trip inside the loop.
-    void policy_rollout(const int* policy_id, const int* schedule, int K, int nsteps, int* episodes, int* successes, float* kernel_ms) override {
+    void policy_rollout(const int* policy_id, const int* schedule, int K, int nsteps, int* episodes, int* successes, float* kernel_ms, int per_launch) override {
         if (K < 1) throw std::invalid_argument("policy_rollout: the goal schedule needs at least one row");
         PolicyState ps{};
         ps.policy_id = (int*)Backend::alloc(sizeof(int) * N_); ps.schedule = (int*)Backend::alloc(sizeof(int) * N_ * K); ps.K = K;
@@ -970,10 +971,30 @@ public:
         World<T> w = world();
         const IOPtrs io = w.io; const int N = N_;
         Backend::timed_begin();
-        for (int s = 0; s < nsteps; s++) {
-            const bool account = s > 0;
-            Backend::launch_flat(N_, [io, ps, N, account] MW_LAMBDA(int gid) { policy_thread(io, ps, N, gid, account, true); });
-            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+        if (per_launch <= 1) {
+            for (int s = 0; s < nsteps; s++) {
+                const bool account = s > 0;
+                Backend::launch_flat(N_, [io, ps, N, account] MW_LAMBDA(int gid) { policy_thread(io, ps, N, gid, account, true); });
+                Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+            }
+        } else {
+            // several (policy, step) pairs per launch: the policy of an environment is evaluated by the environment's own writer thread
+            // between two of its steps (the observation it reads and the action it writes travel through the same buffers as in the
+            // two-kernel loop; its sub-lanes are lanes of the same wave: MW_SYNC orders them).  Same results, no batch-wide
+            // synchronisation between the steps of a launch.
+            for (int s0 = 0; s0 < nsteps; s0 += per_launch) {
+                const int n = nsteps - s0 < per_launch ? nsteps - s0 : per_launch;
+                Backend::launch(nblocks_, [w, ps, N, s0, n] MW_LAMBDA(int b, int t, Scratchpad sp) {
+                    Env<T> e; int gid;
+                    const bool have = locate(w, b, t, sp, &e, &gid);
+                    for (int k = 0; k < n; k++) {
+                        if (have && e.sub == 0 && !e.ghost) policy_thread(w.io, ps, N, gid, s0 + k > 0, true);
+                        MW_SYNC();
+                        lane_step(w, b, t, sp);
+                        MW_SYNC();
+                    }
+                });
+            }
         }
         if (nsteps > 0) Backend::launch_flat(N_, [io, ps, N] MW_LAMBDA(int gid) { policy_thread(io, ps, N, gid, true, false); });
         const float ms = Backend::timed_end();
@@ -1017,6 +1038,34 @@ public:
         if (kernel_ms) *kernel_ms = ms;
     }
     void step_resident_gather(int nsteps, int act_steps, float* kernel_ms) override { step_device_only(nullptr, nsteps, act_steps, kernel_ms, true); }
+
+    // OPEN-LOOP rollout with several steps per launch: every thread runs `per_launch` consecutive steps of its environment before
+    // the kernel ends.  Environments are independent (the only cross-environment effect of a step is the status word), so the
+    // results equal those of the per-step loop bit for bit -- but the batch is synchronised once per launch instead of once per
+    // step: "the slowest wave's SUM over the steps" instead of "the sum over the steps of the slowest wave".  Only for callers that
+    // do not look at the batch between steps (pre-uploaded actions; the observation / reward / flag buffers and the bookkeeping
+    // record hold the LAST step of the launch, auto-resets follow the goal schedule or next_goal as in step_device_only).
+    void step_fused(int nsteps, int act_steps, int per_launch, float* kernel_ms) override {
+        need_reset_done("step_resident_fused");
+        if (per_launch < 1) throw std::invalid_argument("step_resident_fused: steps_per_launch must be >= 1");
+        const float* base = d_act_;
+        const int N = N_;
+        Backend::timed_begin();
+        for (int s0 = 0; s0 < nsteps; s0 += per_launch) {
+            const int n = nsteps - s0 < per_launch ? nsteps - s0 : per_launch;
+            World<T> w = world();
+            if (d_sched_) { w.io.sched = d_sched_; w.io.sched_pos = d_sched_pos_; w.io.sched_K = sched_K_; }
+            Backend::launch(nblocks_, [w, base, s0, n, act_steps, N] MW_LAMBDA(int b, int t, Scratchpad sp) {
+                World<T> ws = w;
+                for (int k = 0; k < n; k++) {
+                    ws.io.act = base + (size_t)(act_steps > 0 ? (s0 + k) % act_steps : 0) * 4 * N;
+                    lane_step(ws, b, t, sp);
+                }
+            });
+        }
+        const float ms = Backend::timed_end();
+        if (kernel_ms) *kernel_ms = ms;
+    }
 
     // ---- cross-rank bookkeeping ----
     void comm_init(const void* id128, int rank, int world) override {

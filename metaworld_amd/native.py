@@ -97,6 +97,7 @@ class Lib:
         f("reset_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
         f("policy_actions", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
         f("policy_rollout", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float))
+        f("policy_rollout_fused", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float))
         f("step_resident_gather", C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float))
         f("comm_unique_id", C.c_int, C.c_void_p)
         f("comm_init", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
@@ -104,6 +105,7 @@ class Lib:
         f("gather_bookkeeping", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
         f("status", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
         f("set_episode_phase", C.c_int, C.c_void_p, C.c_void_p)
+        f("step_resident_fused", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float))
         f("set_goal_schedule", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
         f("goal_schedule_pos", C.c_int, C.c_void_p, C.c_void_p)
         f("column_size", C.c_int, C.c_void_p, C.c_int, C.c_char_p)
@@ -134,7 +136,7 @@ def load(prefix="mw_", path=None) -> Lib:
 
 EXPORTED_SYMBOLS = ["model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
                     "add_model", "add_task", "set_envs", "finalize", "set_terminate_on_success", "destroy", "last_error", "num_envs", "obs_dim",
-                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "upload_actions", "step_resident", "step_resident_gather", "comm_unique_id", "comm_init", "comm_info", "gather_bookkeeping", "status", "set_episode_phase", "set_goal_schedule", "goal_schedule_pos", "column_size", "read", "write", "read_int",
+                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "policy_rollout_fused", "upload_actions", "step_resident", "step_resident_fused", "step_resident_gather", "comm_unique_id", "comm_init", "comm_info", "gather_bookkeeping", "status", "set_episode_phase", "set_goal_schedule", "goal_schedule_pos", "column_size", "read", "write", "read_int",
                     "debug"]
 
 
@@ -229,14 +231,19 @@ class Context:
         self._check(self.lib.policy_actions(self.ptr, pid.ctypes.data, o.ctypes.data, act.ctypes.data))
         return act
 
-    def policy_rollout(self, policy_id, goal_schedule, nsteps):
-        """mw_policy_rollout -> (episodes [N], successes [N], kernel ms)"""
+    def policy_rollout(self, policy_id, goal_schedule, nsteps, steps_per_launch=None):
+        """mw_policy_rollout (or mw_policy_rollout_fused with steps_per_launch (policy, step) pairs per kernel launch)
+        -> (episodes [N], successes [N], kernel ms)"""
         pid = np.ascontiguousarray(policy_id, dtype=np.int32)
         sch = np.ascontiguousarray(goal_schedule, dtype=np.int32)
         assert pid.shape == (self.N,) and sch.ndim == 2 and sch.shape[1] == self.N
         ep, su, ms = np.zeros(self.N, dtype=np.int32), np.zeros(self.N, dtype=np.int32), C.c_float(0)
-        self._check(self.lib.policy_rollout(self.ptr, pid.ctypes.data, sch.ctypes.data, sch.shape[0], int(nsteps),
-                                            ep.ctypes.data, su.ctypes.data, C.byref(ms)))
+        if steps_per_launch:
+            self._check(self.lib.policy_rollout_fused(self.ptr, pid.ctypes.data, sch.ctypes.data, sch.shape[0], int(nsteps), int(steps_per_launch),
+                                                      ep.ctypes.data, su.ctypes.data, C.byref(ms)))
+        else:
+            self._check(self.lib.policy_rollout(self.ptr, pid.ctypes.data, sch.ctypes.data, sch.shape[0], int(nsteps),
+                                                ep.ctypes.data, su.ctypes.data, C.byref(ms)))
         return ep, su, ms.value
 
     # ---- cross-rank bookkeeping gather (RCCL inside the library; SURVEY.md 8e) ----
@@ -263,6 +270,12 @@ class Context:
         out = np.zeros((getattr(self, "world_size", 1), self.N), dtype=BOOKKEEPING_DTYPE)
         self._check(self.lib.gather_bookkeeping(self.ptr, out.ctypes.data, 0))
         return out
+
+    def step_resident_fused(self, nsteps, steps_per_launch):
+        """mw_step_resident_fused: nsteps steps on the uploaded actions, steps_per_launch of them per kernel launch -> kernel ms"""
+        ms = C.c_float(0)
+        self._check(self.lib.step_resident_fused(self.ptr, int(nsteps), self._resident_steps, int(steps_per_launch), C.byref(ms)))
+        return ms.value
 
     def step_resident_gather(self, nsteps):
         ms = C.c_float(0)

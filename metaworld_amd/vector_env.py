@@ -363,13 +363,18 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
                 self._next_goal[e] = self._select(e, commit=False)
 
     # ---- the resident loop (mw_step_resident): K steps on pre-uploaded actions, outputs left in HBM ----
-    def step_resident(self, nsteps, gather=False, schedule_rows=None):
+    def step_resident(self, nsteps, gather=False, schedule_rows=None, steps_per_launch=None):
         """`nsteps` steps of the whole batch on the actions uploaded with `ctx.upload_actions`, no host round trip in between;
         returns the HIP-event kernel time in ms.  The auto-resets that happen inside draw a NEW task per reset like
         `RandomTaskSelectWrapper.reset` (metaworld/wrappers.py:116-119): the next `schedule_rows` selections of every sub-env are
         taken from its task-selection stream and handed to the kernel (mw_set_goal_schedule), the consumed counts are read back
         and the streams advanced by them, so that a following `step()` / `reset()` continues exactly where the reference's
-        wrappers would be.  (Row K-1 repeats if an env resets more than K times: only with episodes of a few steps.)"""
+        wrappers would be.  (Row K-1 repeats if an env resets more than K times: only with episodes of a few steps.)
+        `steps_per_launch` = k runs k consecutive steps of every environment per kernel launch (mw_step_resident_fused): the same
+        final state and outputs bit for bit, one batch-wide synchronisation per launch instead of per step -- for rollouts nobody
+        observes between steps."""
+        if steps_per_launch and gather:
+            raise ValueError("the per-step cross-rank gather needs one launch per step")
         if (self._cur_goal < 0).any():
             raise RuntimeError("step_resident() called before reset(): no task has been set for some sub-envs")
         sched = None
@@ -378,7 +383,10 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
             every = np.arange(self.num_envs)
             sched = np.stack([self._random_goals(every, ahead=k) for k in range(K)]).astype(np.int32)
             self.ctx.set_goal_schedule(sched)
-        ms = self.ctx.step_resident_gather(nsteps) if gather else self.ctx.step_resident(nsteps)
+        if steps_per_launch:
+            ms = self.ctx.step_resident_fused(nsteps, steps_per_launch)
+        else:
+            ms = self.ctx.step_resident_gather(nsteps) if gather else self.ctx.step_resident(nsteps)
         if sched is not None:
             used = self.ctx.goal_schedule_pos().astype(np.int64)
             self.ctx.set_goal_schedule(None)

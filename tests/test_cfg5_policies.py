@@ -14,7 +14,7 @@ from tests.helpers import ROOT
 FIX = os.path.join(ROOT, "tests", "golden", "cfg5_ml45_train_2048_seed42.npz")
 
 
-def _run(lib, precision):
+def _run(lib, precision, steps_per_launch=None):
     from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
     G = np.load(FIX)
     env = MetaWorldGpuVectorEnv("ML45-train", num_envs=2048, seed=42, goal_seed=42, use_one_hot=False, precision=precision,
@@ -22,7 +22,7 @@ def _run(lib, precision):
     assert list(env.env_task_names) == [str(t) for t in G["task"]]
     pid = np.array([T.ALL_V3.index(n) for n in env.env_task_names], dtype=np.int32)
     sched = np.stack([G["goal"], G["goal"]]).astype(np.int32)          # one episode per env on its assigned goal
-    ep, su, ms = env.ctx.policy_rollout(pid, sched, 500)
+    ep, su, ms = env.ctx.policy_rollout(pid, sched, 500, steps_per_launch=steps_per_launch)
     flags = env.status()["flags"]
     env.close()
     assert flags == 0 and (ep == 1).all()
@@ -52,9 +52,29 @@ def test_cfg5_success_counts_equal_the_reference_on_the_gpu(gpulib):
     rows, dev, ref, ms = _run(gpulib, "fp64")
     _report(rows, dev, ref, ms, "gpu fp64")
     assert all(a == b for _, a, b, _, _ in rows), [r for r in rows if r[1] != r[2]]
+    # the same rollout with 50 (policy, step) pairs per launch (mw_policy_rollout_fused): same episodes, no per-step batch synchronisation
+    rows_f, dev_f, _, ms_f = _run(gpulib, "fp64", steps_per_launch=50)
+    _report(rows_f, dev_f, ref, ms_f, "gpu_fused fp64, 50 steps per launch")
+    assert [(t, a) for t, a, _, _, _ in rows_f] == [(t, a) for t, a, _, _, _ in rows]
 
 
 def test_cfg5_success_counts_equal_the_reference_on_the_host_build(hostsim):
     rows, dev, ref, ms = _run(hostsim, "fp64")
     _report(rows, dev, ref, None, "hostbuild fp64")
     assert all(a == b for _, a, b, _, _ in rows), [r for r in rows if r[1] != r[2]]
+
+
+def test_fused_policy_rollout_equals_the_two_kernel_loop(hostsim):
+    """mw_policy_rollout_fused on a small batch: identical episodes and successes per env as one (policy, step) pair per launch"""
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    out = []
+    for spl in (None, 7):
+        env = MetaWorldGpuVectorEnv("MT10", num_envs=20, seed=5, use_one_hot=True, precision="fp64", lib=hostsim, max_episode_steps=60)
+        pid = np.array([T.ALL_V3.index(n) for n in env.env_task_names], dtype=np.int32)
+        sched = np.stack([np.arange(20) % 50, (np.arange(20) + 7) % 50, (np.arange(20) + 13) % 50]).astype(np.int32)
+        ep, su, _ = env.ctx.policy_rollout(pid, sched, 150, steps_per_launch=spl)
+        out.append((ep.copy(), su.copy(), [env.ctx.read(e, "qpos").copy() for e in range(20)]))
+        assert env.status()["flags"] == 0
+        env.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][0].sum() > 20
+    assert all(np.array_equal(x, y) for x, y in zip(out[0][2], out[1][2]))

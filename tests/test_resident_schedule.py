@@ -89,3 +89,50 @@ def test_vectorised_selection_equals_the_per_env_rule(hostsim):
         env._begin_episodes(mask)
         assert env._cur_goal[idx].tolist() == want
     env.close()
+
+
+def test_fused_launches_equal_the_per_step_loop_bit_for_bit(hostsim):
+    """mw_step_resident_fused: several consecutive steps of every environment per launch -- same state, same outputs, same
+    task-selection streams as one launch per step (auto-resets with per-reset task draws included)"""
+    a, b = _pair(hostsim)
+    a.reset(); b.reset()
+    acts = np.random.default_rng(2).uniform(-1, 1, (8, 20, 4)).astype(np.float32)
+    for env in (a, b):
+        env.ctx.upload_actions(acts)
+        env.ctx.set_episode_phase((np.arange(20) * 3 % 7).astype(np.int32))
+    a.step_resident(23, schedule_rows=6, steps_per_launch=5)          # launches of 5, 5, 5, 5, 3 steps
+    b.step_resident(23, schedule_rows=6)
+    _same_state(a, b)
+    x = a.step(acts[0]); y = b.step(acts[0])          # (the resident loops leave their outputs on the device: compare through one ordinary step)
+    assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    _same_state(a, b)
+    assert a.ctx.status()["flags"] == 0
+    with pytest.raises(ValueError):
+        a.step_resident(2, gather=True, steps_per_launch=2)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_gpu_fused_launches_equal_the_per_step_loop_bit_for_bit(gpulib):
+    """the same on the GPU, MT50 @ 400 (every scene, partial last workgroups -> ghost lanes), fp64: 120 steps as 3 launches of 40 against 120
+    launches; also the schedule-driven resampling against the per-step host loop"""
+    envs = [MetaWorldGpuVectorEnv("MT50", num_envs=400, seed=3, use_one_hot=True, precision="fp64", lib=gpulib, max_episode_steps=45) for _ in range(3)]
+    acts = np.random.default_rng(4).uniform(-1, 1, (16, 400, 4)).astype(np.float32)
+    for env in envs:
+        env.reset()
+        env.ctx.upload_actions(acts)
+        env.ctx.set_episode_phase((np.arange(400) * 7 % 45).astype(np.int32))
+    a, b, c = envs
+    a.step_resident(120, schedule_rows=8, steps_per_launch=40)
+    b.step_resident(120, schedule_rows=8)
+    for t in range(120):
+        c.step(acts[t % 16])
+    for other in (b, c):
+        assert np.array_equal(a._cur_goal, other._cur_goal) and np.array_equal(a._reset_count, other._reset_count)
+        for e in range(0, 400, 7):
+            assert np.array_equal(a.ctx.read(e, "qpos"), other.ctx.read(e, "qpos")), e
+    x = a.step(acts[0]); y = b.step(acts[0])
+    assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    for env in envs:
+        assert env.ctx.status()["flags"] == 0
+        env.close()
