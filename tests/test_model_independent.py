@@ -280,3 +280,40 @@ def test_invweight0_from_an_independent_mass_matrix(scene):
             assert np.allclose(got, want, rtol=2e-5, atol=1e-12), (scene, b, got, want)
         else:
             assert A["body_weldid"][b] == 0 if "body_weldid" in A else True
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the hulls the narrow phase collides: the compiled hull vertices of every collision mesh against scipy's ConvexHull of the STL read
+# by THIS file's reader -- same number of extreme points, same volume, same surface area (all invariant under the principal-frame
+# transform mjcf.py applies), and every compiled vertex lies on the STL's hull
+def _stl_points(path, scale):
+    with open(path, "rb") as f:
+        data = f.read()
+    n = struct.unpack("<I", data[80:84])[0]
+    rec = np.frombuffer(data, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=n, offset=84)
+    return rec["v"].astype(np.float64).reshape(-1, 3) * np.asarray(scale)[None, :]
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_collision_hulls_are_the_convex_hulls_of_the_stl_files(scene):
+    from scipy.spatial import ConvexHull
+    from metaworld_amd.mjcf import load_model
+    m = load_model(os.path.join(ROOT, "metaworld_amd", "models", scene + ".npz"))
+    path = os.path.join(ASSETS, scene + ".xml")
+    base = os.path.dirname(path)
+    root = ET.parse(path).getroot()
+    _expand(root, base)
+    files = {}
+    for asset in root.findall("asset"):
+        for me in asset.findall("mesh"):
+            name = me.get("name") or os.path.splitext(os.path.basename(me.get("file")))[0]
+            files[name] = (os.path.join(base, me.get("file")), [float(x) for x in me.get("scale", "1 1 1").split()])
+    assert m.names["mesh"], scene
+    for name, mi in m.names["mesh"].items():
+        a, n = int(m.arrays["mesh_vertadr"][mi]), int(m.arrays["mesh_vertnum"][mi])
+        got = ConvexHull(m.arrays["mesh_vert"][a:a + n])
+        pts = np.unique(np.round(_stl_points(*files[name]), 12), axis=0)
+        want = ConvexHull(pts)
+        assert len(got.vertices) == n, (name, "a compiled hull vertex is not extreme")
+        assert n == len(want.vertices), (name, n, len(want.vertices))
+        assert got.volume == pytest.approx(want.volume, rel=1e-9) and got.area == pytest.approx(want.area, rel=1e-9), name
