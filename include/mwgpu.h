@@ -54,7 +54,8 @@ typedef struct mw_task {
 
 /* ---- model tables (replaces mujoco.MjModel.from_xml_path; reference call: gymnasium MujocoEnv.__init__) ----
  * Fields: the int / real arrays listed in metaworld_amd/pack.py (INT_FIELDS, REAL_FIELDS; names follow mjModel) incl. the
- * hull vertex graph of big meshes (mesh_nbradr, mesh_nbr, mesh_start, mesh_hill) for the hill-climbing support function.
+ * support cells of the mesh hulls (mesh_celladr, mesh_cellid: per cube-map cell of directions the ascending list of the vertices
+ * that can be the support vertex, metaworld_amd/hullcells.py) from which the runtime derives its one-round-trip support tables.
  * Options: timestep, tolerance (solver tolerance of the context's precision), reset_tolerance (tolerance of the
  * double-precision reset-snapshot build; default = tolerance), meaninertia, gravity_z, iterations, ls_iterations,
  * maxcon, maxefc (contact / constraint-row capacities per environment), nreloc, lanes_per_block (environments per

@@ -1390,7 +1390,9 @@ MW_HD void solve_impl(const Env<T> e) {
     const T cs = update_constraint<T, NV>(e);
     set_point(L.warm);
     T cost = update_constraint<T, NV>(e);
-    if (cost > cs) { set_point(L.qacc_smooth); cost = update_constraint<T, NV>(e); }
+    // (nefc == 0 -- an environment without rows inside a wave that has some, see solve(): the unconstrained optimum IS qacc_smooth,
+    //  whatever the rounding of the two costs says)
+    if (cost > cs || nefc == 0) { set_point(L.qacc_smooth); cost = update_constraint<T, NV>(e); }
     const T scale = 1 / (m.meaninertia * T(nv > 1 ? nv : 1));
     MW_TICK(t_b)
     MW_TOCK(e, L, 0, t_a, t_b)
@@ -1401,7 +1403,10 @@ MW_HD void solve_impl(const Env<T> e) {
     // made under a full EXEC mask.  One-environment-per-lane layouts (fewer than four sub-lanes) and the host build keep the
     // per-environment routine.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MW_NO_WAVE_NEWTON)
-    const bool wave_newton = e.nsub >= 4;
+    // nv == NV: the lane roles (and the border of the 17th dof) are laid out for the EXACT dispatched sizes 10 / 11 / 15 / 16 / 17;
+    // any other nv reaches this instantiation through MW_NV_DISPATCH's default (NV = 17 as a size bound) and keeps the
+    // per-environment routine, which guards every index with k < nv
+    const bool wave_newton = e.nsub >= 4 && nv == NV;
 #else
     const bool wave_newton = false;
 #endif
@@ -1539,7 +1544,10 @@ MW_STAGE_FN void solve(const Env<T> e_) {
     CLayout& L = e.lay();
     const int nv = e.nv;
     e.I(L.icount + 2) = 0;
-    if (e.I(L.icount + 1) == 0) {
+    // WAVE-UNIFORM early exit: only when NO environment of the wave has a constraint row.  In a mixed wave the ones
+    // without rows go through solve_impl as well (zero rows: qacc = qacc_smooth bit for bit, qfrc_constraint = 0), so that the
+    // wave-cooperative Newton direction is entered under a full EXEC mask.  Every Sawyer scene has the mocap weld (nefc >= 6).
+    if (!mw_any(e.I(L.icount + 1) != 0)) {
         T x[MAX_NV];
         vec_load<T, MAX_NV>(e, L.qacc_smooth, nv, x);          // (all loads, then all stores)
         vec_store<T, MAX_NV>(e, L.qacc, nv, x);

@@ -1060,6 +1060,7 @@ public:
                 for (int k = 0; k < n; k++) {
                     ws.io.act = base + (size_t)(act_steps > 0 ? (s0 + k) % act_steps : 0) * 4 * N;
                     lane_step(ws, b, t, sp);
+                    MW_SYNC();          // step boundary: the sub-lanes' read-then-advance of sched_pos, the task-block counters and the snapshot copy of an auto-reset are ordered for the next step (as in policy_rollout's fused loop)
                 }
             });
         }

@@ -241,6 +241,7 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
         self._next_goal = np.zeros(self.num_envs, dtype=np.int32)       # goal the next (auto-)reset will use
         self.sample_tasks_on_reset = task_select == "random"            # wrappers.py:96 / :154
         self.terminate_on_success = bool(terminate_on_success)
+        self.max_episode_steps = int(max_episode_steps or 500)
         D = self.ctx.D
         lo = np.concatenate([[-0.525, 0.348, -0.0525, -1.0], np.full(14, -np.inf)] * 2 + [np.zeros(3)])
         hi = np.concatenate([[0.525, 1.025, 0.7, 1.0], np.full(14, np.inf)] * 2 + [np.zeros(3)])
@@ -379,7 +380,10 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
             raise RuntimeError("step_resident() called before reset(): no task has been set for some sub-envs")
         sched = None
         if self.sample_tasks_on_reset and self.task_select == "random":
-            K = int(schedule_rows or max(2, min(64, nsteps // 50 + 2)))
+            # rows needed = the most auto-resets one env can make in nsteps: one per max_episode_steps without early termination,
+            # up to one per step with terminate_on_success (an env can succeed in its first step)
+            worst = nsteps + 1 if self.terminate_on_success else nsteps // max(1, min(self.max_episode_steps, 500)) + 3   # (+ slack for instability truncations)
+            K = int(schedule_rows or max(2, min(64, nsteps // 50 + 2, worst)))
             every = np.arange(self.num_envs)
             sched = np.stack([self._random_goals(every, ahead=k) for k in range(K)]).astype(np.int32)
             self.ctx.set_goal_schedule(sched)
@@ -390,6 +394,11 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
         if sched is not None:
             used = self.ctx.goal_schedule_pos().astype(np.int64)
             self.ctx.set_goal_schedule(None)
+            if (used > len(sched)).any():
+                # the kernel repeated the last row for the surplus resets: those draws never came from the selection streams, and
+                # advancing the streams by `used` would desynchronise every later reset from the reference's wrapper
+                raise RuntimeError(f"step_resident: an env auto-reset {int(used.max())} times but only {len(sched)} schedule rows were drawn; "
+                                   "pass schedule_rows >= the number of resets per env (short episodes with terminate_on_success)")
             hit = np.flatnonzero(used > 0)
             self._cur_goal[hit] = sched[np.minimum(used[hit], len(sched)) - 1, hit]
             self._reset_count += used
