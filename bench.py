@@ -48,31 +48,54 @@ HORIZON = 500                   # SawyerXYZEnv.max_path_length (sawyer_xyz_env.p
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def _oracle_worker(task_names, seconds, seed):
     """The CPU oracle (independent fp64 C restatement of the engine) stepping the workload on ONE core: every task of the
-    benchmark an equal share of the env-steps, random actions, 5 substeps + forward per env-step (physics only)."""
+    benchmark an equal share of the env-steps, random actions, 5 substeps + forward per env-step (physics only).  Timing build
+    (oracle/mjlite.py: -O3 -march=native, the hulls' support cells instead of the checker's all-vertex scan -- same answers by
+    construction) and the action loop in C (mjl_bench_env_steps): no Python or ctypes call per env-step."""
+    import ctypes
     from metaworld_amd import tasks as T
     from oracle.mjlite import OracleData, OracleModel
-    rng = np.random.default_rng(seed)
     sims = []
     for task in task_names:
         c = T.TASK_CONST[task]
-        om = OracleModel(T.compiled_model(c["model"]))
+        om = OracleModel(T.compiled_model(c["model"]), timing=True)
         om.view("eq_data")[:] = [0, 0, 0, 0, 0, 0, -1, 0, 0, 0, 5.0]
         d = OracleData(om)
         d.mocap_pos[:] = np.array(c["hand_init_pos"]); d.mocap_quat[:] = [1, 0, 1, 0]; d.ctrl[:] = [-1, 1]
         d.step(100)
-        sims.append((om, d, np.array(c["mocap_low"]), np.array(c["mocap_high"])))
+        sims.append((om, d, np.array(c["mocap_low"], dtype=np.float64), np.array(c["mocap_high"], dtype=np.float64)))
+    state = ctypes.c_ulonglong(88172645463325252 + 7919 * seed)
     chunk = 10
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for om, d, lo_, hi_ in sims:          # one round = `chunk` env-steps of every task
-            for _ in range(chunk):
-                a = rng.uniform(-1, 1, 4)
-                d.mocap_pos[:] = np.clip(d.mocap_pos + 0.01 * a[:3], lo_, hi_)
-                d.ctrl[:] = [a[3], -a[3]]
-                d.step(5)
-                d.forward()
-                n += 1
+            d.bench_env_steps(chunk, state, lo_, hi_)
+            n += chunk
     return n, time.perf_counter() - t0
+
+
+def host_cores():
+    """(cores this process may run on, cgroup CPU quota in cores or None, os.cpu_count()): what 'all host cores' means here"""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        quota = q / float(f.read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return aff, quota, os.cpu_count() or 1
 
 
 def _full_step_port(task_names, seconds):
@@ -85,7 +108,7 @@ def _full_step_port(task_names, seconds):
     from metaworld_amd import native
     from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
     lib = native.load("mwh_", so)
-    n = 4 * (os.cpu_count() or 1)
+    n = 4 * host_cores()[0]
     n = max(n, len(task_names))
     old_nsub = os.environ.get("MW_NSUB")
     os.environ["MW_NSUB"] = "1"          # (host harness knob: no emulated sub-lanes -- one plain lane program per env and core)
@@ -104,7 +127,7 @@ def _full_step_port(task_names, seconds):
         del os.environ["MW_NSUB"]
     else:
         os.environ["MW_NSUB"] = old_nsub
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": os.cpu_count() or 1,
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": host_cores()[0],
             "sample": f"{n} envs x {steps} full steps (physics + obs + reward + wrappers, host build of the lane programs, OpenMP) in {dt:.1f}s"}
 
 
@@ -113,16 +136,22 @@ def cpu_baseline(task_names, seconds=10.0):
     full step (with obs / reward) of the host build of the lane programs on all cores.  All three are stand-ins for the
     reference's own SyncVectorEnv / AsyncVectorEnv, which needs mujoco + gymnasium (absent here and on the GPU box)."""
     import multiprocessing as mp
+    from oracle import mjlite
+    mjlite.build(fast=True)          # (once, before the workers race for it)
     n1, dt1 = _oracle_worker(task_names, seconds, 0)
-    cores = os.cpu_count() or 1
+    aff, quota, ncpu = host_cores()
+    cores = max(1, min(aff, int(quota) if quota and quota >= 1 else aff))          # one worker per core this process may really use
     with mp.get_context("spawn").Pool(cores) as pool:
         res = pool.starmap(_oracle_worker, [(task_names, seconds, 1 + r) for r in range(cores)])
     rate_all = sum(n / dt for n, dt in res)
     what = task_names[0] if len(task_names) == 1 else f"{len(task_names)} tasks in equal shares"
     out = {"value": rate_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
-           "single_core_value": n1 / dt1,
-           "sample": f"oracle engine (fp64 C restatement; stand-in, not Farama/MuJoCo): {sum(n for n, _ in res)} env-steps of {what} "
-                     f"(random actions, 5 substeps + forward each, physics only) in {seconds:.0f}s on {cores} processes; "
+           "single_core_value": n1 / dt1, "parallel_speedup": rate_all / (n1 / dt1),
+           "host": {"sched_affinity_cores": aff, "cgroup_cpu_quota_cores": quota, "os_cpu_count": ncpu},
+           "sample": f"oracle engine (fp64 C restatement, timing build: -O3 -march=native, support cells, C action loop; stand-in, not "
+                     f"Farama/MuJoCo): {sum(n for n, _ in res)} env-steps of {what} "
+                     f"(random actions, 5 substeps + forward each, physics only) in {seconds:.0f}s on {cores} processes "
+                     f"(= the cores in this process's affinity mask / cgroup quota; measured speed-up over 1 process {rate_all / (n1 / dt1):.1f}x); "
                      f"1 process: {n1} env-steps in {dt1:.1f}s"}
     full = _full_step_port(task_names, min(seconds, 8.0))
     if full:

@@ -83,7 +83,7 @@ static const Field FIELDS[] = {
     FR(dof_damping), FR(dof_invweight0), FR(qpos0), FI(geom_type), FI(geom_bodyid), FI(geom_meshid),
     FI(geom_contype), FI(geom_conaffinity), FI(geom_condim), FI(geom_priority), FR(geom_size), FR(geom_pos),
     FR(geom_quat), FR(geom_friction), FR(geom_solref), FR(geom_solimp), FR(geom_solmix), FR(geom_margin),
-    FR(geom_gap), FR(geom_rbound), FI(mesh_vertadr), FI(mesh_vertnum), FR(mesh_vert), FI(pair_geom),
+    FR(geom_gap), FR(geom_rbound), FI(mesh_vertadr), FI(mesh_vertnum), FR(mesh_vert), FI(mesh_celladr), FI(mesh_cellid), FI(pair_geom),
     FI(site_bodyid), FR(site_pos), FR(site_quat), FI(act_dofid), FI(act_qposid), FR(act_kp), FR(act_ctrlrange),
     FI(eq_body1), FI(eq_body2), FR(eq_solref), FR(eq_solimp), FR(eq_data),
 };
@@ -1003,6 +1003,25 @@ void mjl_step(const MjlModel* m, MjlData* d) {
 }
 void mjl_step_n(const MjlModel* m, MjlData* d, int n) {
     for (int i = 0; i < n; i++) mjl_step(m, d);
+}
+static double bench_uniform(unsigned long long* s) {          /* xorshift64*, uniform in [-1, 1) */
+    unsigned long long x = *s;
+    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+    *s = x;
+    return (double)((x * 2685821657736338717ULL) >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+void mjl_bench_env_steps(const MjlModel* m, MjlData* d, int n, unsigned long long* rng, const double* lo, const double* hi) {
+    for (int s = 0; s < n; s++) {
+        double a[4];
+        for (int k = 0; k < 4; k++) a[k] = bench_uniform(rng);
+        for (int k = 0; k < 3; k++) {
+            double v = d->mocap_pos[k] + 0.01 * a[k];
+            d->mocap_pos[k] = v < lo[k] ? lo[k] : (v > hi[k] ? hi[k] : v);
+        }
+        d->ctrl[0] = a[3]; d->ctrl[1] = -a[3];
+        mjl_step_n(m, d, 5);
+        mjl_forward(m, d);
+    }
 }
 
 /* ------------------------------------------------------------------ accessors for the Python binding */

@@ -54,6 +54,11 @@ typedef struct {
         *geom_margin, *geom_gap, *geom_rbound;
     int *mesh_vertadr, *mesh_vertnum;
     double *mesh_vert;
+    /* OPTIONAL, timing only (bench.py's cpu_baseline; never set by tests or by the parity chain): the support cells of the hulls
+       (metaworld_amd/hullcells.py).  When present, support() takes the maximum over the direction cell's list instead of over all
+       vertices -- the same answer by construction of the lists -- so that the CPU stand-in is timed with the same acceleration
+       the product uses instead of a 324- / 884-vertex scan per support call. */
+    int *mesh_celladr, *mesh_cellid;
     int *pair_geom;
     /* sites */
     int *site_bodyid;
@@ -111,6 +116,9 @@ void mjl_reset_data(const MjlModel* m, MjlData* d);
 void mjl_forward(const MjlModel* m, MjlData* d);
 void mjl_step(const MjlModel* m, MjlData* d);
 void mjl_step_n(const MjlModel* m, MjlData* d, int n);
+/* timing loop of bench.py's cpu_baseline, entirely in C: n_env_steps x (random action in [-1, 1]^4 from a xorshift stream ->
+   mocap += 0.01 a clipped to [lo, hi], ctrl = (a3, -a3), 5 x mjl_step, mjl_forward) */
+void mjl_bench_env_steps(const MjlModel* m, MjlData* d, int n_env_steps, unsigned long long* rng_state, const double* lo, const double* hi);
 /* stages, exposed for unit tests */
 void mjl_kinematics(const MjlModel* m, MjlData* d);
 void mjl_crb(const MjlModel* m, MjlData* d);

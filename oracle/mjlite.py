@@ -13,13 +13,32 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libmjlite.so")
+_LIB_PATH_FAST = os.path.join(_HERE, "_build", "libmjlite_fast.so")
 _SRCS = ["mjl_core.c", "mjl_collide.c"]
+# the checker: strict IEEE, no contraction (bit-reproducible against the host build of the lane programs)
+_FLAGS = ["-O2", "-std=gnu99", "-ffp-contract=off"]
+# bench.py's cpu_baseline only: the same sources built for speed on the host they run on (the stand-in was timed at -O2
+# without -march=native)
+_FLAGS_FAST = ["-O3", "-march=native", "-std=gnu99"]
 
 
-def build(force=False):
+def _fast_path():
+    """-march=native code only runs on the CPU it was built for: the file name carries a hash of this host's CPU flags, so a
+    library built in another container is never loaded on the GPU box (it is rebuilt there, gcc is in the image)"""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((l for l in f if l.startswith("flags")), "")
+    except OSError:
+        flags = ""
+    return _LIB_PATH_FAST.replace(".so", "_" + hashlib.sha1(flags.encode()).hexdigest()[:8] + ".so")
+
+
+def build(force=False, fast=False):
     """compile the C restatement; safe under concurrent callers (pytest-xdist workers): one builder at a time, the compiler writes
-    a temporary file that is renamed into place"""
+    a temporary file that is renamed into place.  fast=True: the timing build (-O3 -march=native), a second library"""
     import fcntl
+    _LIB_PATH = _fast_path() if fast else globals()["_LIB_PATH"]
     srcs = [os.path.join(_HERE, s) for s in _SRCS]
     deps = srcs + [os.path.join(_HERE, "mjl_core.h")]
 
@@ -33,21 +52,19 @@ def build(force=False):
         try:
             if force or not fresh():
                 tmp = f"{_LIB_PATH}.tmp.{os.getpid()}"
-                subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-shared", "-fPIC", "-ffp-contract=off", "-o", tmp] + srcs + ["-lm"])
+                subprocess.check_call(["gcc"] + (_FLAGS_FAST if fast else _FLAGS) + ["-shared", "-fPIC", "-o", tmp] + srcs + ["-lm"])
                 os.replace(tmp, _LIB_PATH)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return _LIB_PATH
 
 
-_lib = None
+_lib = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+def lib(fast=False):
+    if fast not in _lib:
+        L = C.CDLL(build(fast=fast))
         L.mjl_model_new.restype = C.c_void_p
         L.mjl_data_new.restype = C.c_void_p
         L.mjl_data_new.argtypes = [C.c_void_p]
@@ -69,25 +86,30 @@ def lib():
         L.mjl_data_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.mjl_data_contact.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.mjl_data_efc_int.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        _lib = L
-    return _lib
+        L.mjl_bench_env_steps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong), C.c_void_p, C.c_void_p]
+        L.mjl_bench_env_steps.restype = None
+        _lib[fast] = L
+    return _lib[fast]
 
 
 # acceleration tables of the product's hull support function (support cells: metaworld_amd/hullcells.py, mjcf.py add_mesh_cells;
 # the hull graph / start cube map of model files written before round 4).  The oracle scans every hull vertex
-# (mjl_collide.c support()) and takes none of them.
+# (mjl_collide.c support()) and takes none of them -- except in bench.py's timing runs (OracleModel(timing=True)), which hand it
+# the support cells so that the CPU stand-in is not handicapped by the scan.
 PRODUCT_ONLY_ARRAYS = {"mesh_nbradr", "mesh_nbr", "mesh_start", "mesh_hill", "mesh_celladr", "mesh_cellid"}
 
 
 class OracleModel:
     """Holds a C MjlModel built from a metaworld_amd.mjcf.Model."""
 
-    def __init__(self, model):
-        L = lib()
+    def __init__(self, model, timing=False):
+        """timing=True (bench.py's cpu_baseline ONLY): the -O3 -march=native build + the hulls' support cells (same answers as the
+        scan by construction of the cells, tests/test_support_cells.py; the parity chain never uses it)"""
+        L = self.L = lib(fast=timing)
         self.src = model
         self.ptr = L.mjl_model_new()
         for k, v in model.arrays.items():
-            if k in PRODUCT_ONLY_ARRAYS:
+            if k in PRODUCT_ONLY_ARRAYS and not (timing and k in ("mesh_celladr", "mesh_cellid")):
                 continue
             if v.dtype.kind in "iu":
                 a = np.ascontiguousarray(v, dtype=np.int32)
@@ -112,14 +134,14 @@ class OracleModel:
     def view(self, name, shape=None):
         """writable numpy view of a real-valued model array living in C memory."""
         n = C.c_int(0)
-        p = lib().mjl_model_real_ptr(self.ptr, name.encode(), C.byref(n))
+        p = self.L.mjl_model_real_ptr(self.ptr, name.encode(), C.byref(n))
         assert p, name
         a = np.ctypeslib.as_array(p, shape=(n.value,))
         return a.reshape(shape) if shape else a
 
     def __del__(self):
         try:
-            lib().mjl_model_free(self.ptr)
+            self.L.mjl_model_free(self.ptr)
         except Exception:
             pass
 
@@ -127,7 +149,8 @@ class OracleModel:
 class OracleData:
     def __init__(self, om: OracleModel):
         self.om = om
-        self.ptr = lib().mjl_data_new(om.ptr)
+        self.L = om.L
+        self.ptr = self.L.mjl_data_new(om.ptr)
         self._views = {}
         m = om
         self.qpos = self.view("qpos")
@@ -155,7 +178,7 @@ class OracleData:
 
     def view(self, name, shape=None):
         n = C.c_int(0)
-        p = lib().mjl_data_real_ptr(self.om.ptr, self.ptr, name.encode(), C.byref(n))
+        p = self.L.mjl_data_real_ptr(self.om.ptr, self.ptr, name.encode(), C.byref(n))
         assert p, name
         a = np.ctypeslib.as_array(p, shape=(n.value,))
         return a.reshape(shape) if shape else a
@@ -166,7 +189,7 @@ class OracleData:
 
     def info(self):
         out = (C.c_int * 8)()
-        lib().mjl_data_info(self.ptr, out)
+        self.L.mjl_data_info(self.ptr, out)
         return dict(ncon=out[0], nefc=out[1], ne=out[2], nl=out[3], niter=out[4], overflow=out[5], max_ncon=out[6], max_nefc=out[7])
 
     @property
@@ -186,25 +209,30 @@ class OracleData:
         iv = (C.c_int * 4)()
         rv = (C.c_double * 16)()
         for i in range(self.ncon):
-            lib().mjl_data_contact(self.ptr, i, iv, rv)
+            self.L.mjl_data_contact(self.ptr, i, iv, rv)
             res.append(dict(geom1=iv[0], geom2=iv[1], dim=iv[2], efc_address=iv[3], dist=rv[0],
                             pos=np.array(rv[1:4]), frame=np.array(rv[4:13]), mu=rv[13]))
         return res
 
     def reset(self):
-        lib().mjl_reset_data(self.om.ptr, self.ptr)
+        self.L.mjl_reset_data(self.om.ptr, self.ptr)
 
     def forward(self):
-        lib().mjl_forward(self.om.ptr, self.ptr)
+        self.L.mjl_forward(self.om.ptr, self.ptr)
 
     def step(self, n=1):
-        lib().mjl_step_n(self.om.ptr, self.ptr, n)
+        self.L.mjl_step_n(self.om.ptr, self.ptr, n)
+
+    def bench_env_steps(self, n, rng_state, lo, hi):
+        """mjl_bench_env_steps: n random-action env-steps (5 substeps + forward each) in one C call; rng_state = c_ulonglong"""
+        lo = np.ascontiguousarray(lo, dtype=np.float64); hi = np.ascontiguousarray(hi, dtype=np.float64)
+        self.L.mjl_bench_env_steps(self.om.ptr, self.ptr, int(n), C.byref(rng_state), lo.ctypes.data, hi.ctypes.data)
 
     def kinematics(self):
-        lib().mjl_kinematics(self.om.ptr, self.ptr)
+        self.L.mjl_kinematics(self.om.ptr, self.ptr)
 
     def __del__(self):
         try:
-            lib().mjl_data_free(self.ptr)
+            self.L.mjl_data_free(self.ptr)
         except Exception:
             pass
