@@ -208,6 +208,9 @@ def parse_args(argv=None):
     ap.add_argument("--host-harness", action="store_true", help="TEST ONLY: drive the CPU harness instead of the GPU library")
     ap.add_argument("--no-boundary", action="store_true", help="skip the boundary-inclusive rates (VectorEnv.step with host numpy / device tensors) at N=1")
     ap.add_argument("--no-saturation", action="store_true", help="skip the extra short run at 4x the envs at N=1")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short runs of BASELINE.json's other configurations (2, 3, 5) at N=1")
+    ap.add_argument("--split-collision", type=int, default=None, choices=[0, 1], help="1: narrow phase as batch-wide kernels between the lane "
+                    "kernels (mw_set_option split_collision); 0: the fused step kernel; default: the library's own choice")
     ap.add_argument("--fixed-goals", action="store_true", help="auto-resets inside the timed loop re-use each env's look-ahead goal "
                     "(rounds 1-3) instead of drawing a new task per reset like RandomTaskSelectWrapper")
     return ap.parse_args(argv)
@@ -217,10 +220,68 @@ def parse_args(argv=None):
 def build_env(args, precision, rank, world, local_rank, lib=None):
     from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
     if args.benchmark == "MT1":
-        return MetaWorldGpuVectorEnv("MT1", "reach-v3", num_envs=args.envs, seed=42 + rank, precision=precision, device_id=local_rank,
-                                     rank=rank, world_size=world, lib=lib)
-    return MetaWorldGpuVectorEnv(args.benchmark, num_envs=args.envs, seed=42 + rank, use_one_hot=True, precision=precision,
-                                 device_id=local_rank, rank=rank, world_size=world, lib=lib)
+        env = MetaWorldGpuVectorEnv("MT1", "reach-v3", num_envs=args.envs, seed=42 + rank, precision=precision, device_id=local_rank,
+                                    rank=rank, world_size=world, lib=lib)
+    else:
+        env = MetaWorldGpuVectorEnv(args.benchmark, num_envs=args.envs, seed=42 + rank, use_one_hot=True, precision=precision,
+                                    device_id=local_rank, rank=rank, world_size=world, lib=lib)
+    if getattr(args, "split_collision", None) is not None:
+        env.ctx.set_option("split_collision", args.split_collision)
+    return env
+
+
+def launch_stats(env):
+    """min / median / max / mean of the HIP-event times of the launches of the last resident call (mw_launch_times)"""
+    t = np.asarray(env.ctx.launch_times(), dtype=np.float64)
+    if not len(t):
+        return None
+    return {"min": float(t.min()), "median": float(np.median(t)), "max": float(t.max()), "mean": float(t.mean()), "launches": int(len(t))}
+
+
+def extra_configs(args, lib, local_rank):
+    """BASELINE.json's other single-GPU configurations, short windows of the same protocol (staggered phases, untimed pre-roll), so
+    that the driver's record carries them: 2 = MT1 reach-v3 @ 4096 fp32; 3 = MT10 @ 10240 fp64; 5 = ML45-train @ 2048 fp64 under
+    the device-side scripted policies (one whole closed-loop episode per env, mean success beside the rate)."""
+    import torch
+    from metaworld_amd import tasks as T
+    from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    out = []
+    for cfg, bm, envs, prec, steps in ((2, "MT1", 4096, "fp32", 100), (3, "MT10", 10240, "fp64", 60)):
+        a = argparse.Namespace(**{**vars(args), "benchmark": bm, "envs": envs, "warmup": 5})
+        env = build_env(a, prec, 0, 1, local_rank, lib)
+        prepare(env, a, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = resident(env, a, steps)
+        torch.cuda.synchronize()
+        w = time.perf_counter() - t0
+        st = check_outputs(env, args.allow_status)
+        out.append({"config": cfg, "workload": ("MT1 reach-v3" if bm == "MT1" else f"{bm} sync-vector") + f", {envs} envs/GPU, {prec}, random actions",
+                    "value": envs * steps / w, "unit": "env-steps/s", "steps": steps, "kernel_ms_per_launch": k / steps,
+                    "kernel_ms": launch_stats(env), "flags": st["flags"]})
+        env.close()
+    n = 2048
+    env = MetaWorldGpuVectorEnv("ML45-train", num_envs=n, seed=42, precision="fp64", partially_observable=False, max_episode_steps=500,
+                                device_id=local_rank, lib=lib)
+    if args.split_collision is not None:
+        env.ctx.set_option("split_collision", args.split_collision)
+    names = np.array(env.env_task_names)
+    pid = np.array([T.ALL_V3.index(t) for t in names], dtype=np.int32)
+    rank_in_task = np.concatenate([np.arange((names == t).sum()) for t in env.task_list])
+    sched = (rank_in_task[None, :] + np.arange(2)[:, None]) % 50
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ep, su, ms = env.ctx.policy_rollout(pid, sched, 500)
+    torch.cuda.synchronize()
+    w = time.perf_counter() - t0
+    st = env.ctx.status(clear=True)
+    rates = [su[names == t].sum() / max(1, ep[names == t].sum()) for t in env.task_list]
+    out.append({"config": 5, "workload": f"ML45-train, {n} envs/GPU, fp64, device-side scripted policies, one 500-step closed-loop episode per env",
+                "value": n * 500 / (ms / 1e3), "unit": "env-steps/s", "steps": 500, "kernel_ms_per_launch": ms / 500,
+                "wall_value_incl_reset_and_upload": n * 500 / w, "mean_success": float(np.mean(rates)),
+                "tasks_at_or_above_0.8": int(sum(r >= 0.8 for r in rates)), "flags": st["flags"]})
+    env.close()
+    return out
 
 
 def prepare(env, args, rank):
@@ -381,6 +442,7 @@ def main(argv=None):
     barrier()
     wall = time.perf_counter() - t0
     per_rank_kernel_ms = [kernel_ms / args.steps]
+    kstats = launch_stats(env)
     if dist is not None:
         tw = torch.tensor([wall], device="cuda" if on_gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -399,7 +461,7 @@ def main(argv=None):
         algo = ALGO_BYTES_PER_ENV_STEP[(args.precision, one_hot)]
         ach = algo * N / per_launch_s / 1e9
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                    "traffic": None, "kernel_ms_per_launch": kernel_ms / args.steps, "algorithmic_bytes_per_env_step": algo,
+                    "traffic": None, "kernel_ms_per_launch": kernel_ms / args.steps, "kernel_ms": kstats, "algorithmic_bytes_per_env_step": algo,
                     "note": "achieved = algorithmic bytes/env-step x envs / HIP-event kernel time (events on the library's own stream); "
                             "traffic = FETCH_SIZE + WRITE_SIZE bytes per launch of the committed rocprofv3 PMC profile of this command on the same sources; "
                             "the step kernel is bound by the latency of its per-environment dependency chain, not by HBM (DESIGN.md 5): "
@@ -449,6 +511,8 @@ def main(argv=None):
                           "metaworld/wrappers.py:116-119) through the device goal schedule (mw_set_goal_schedule)",
                           "parallelism": f"dp{world} (independent env shards, no data-path collective)", "bookkeeping_gather": gather_mode,
                           "comm": env.ctx.comm_info(), "per_rank_kernel_ms": per_rank_kernel_ms,
+                          "collision": {None: "library default (fused step kernel)", 0: "fused step kernel", 1: "split: narrow phase as batch-wide kernels "
+                                        "between the lane kernels (mw_split.inl); kernel_ms = one whole step (all its launches)"}[args.split_collision],
                           "status_flags": status},
                "roofline": roofline}
         if world == 1 and not args.no_extra_precision and on_gpu:
@@ -504,6 +568,10 @@ def main(argv=None):
                                     "note": "open-loop rollout, 50 consecutive steps of every environment per kernel launch (same results as the per-step "
                                             "loop bit for bit: tests/test_resident_schedule.py); reported beside `value`, never as it"}
             env4.close()
+        if world == 1 and on_gpu and not args.no_configs:
+            if not env.closed:
+                env.close()
+            out["configs"] = extra_configs(args, lib, local_rank)
         if world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(wl_task)
         print(json.dumps(out), flush=True)

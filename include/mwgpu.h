@@ -12,6 +12,7 @@
  */
 #ifndef MWGPU_H
 #define MWGPU_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -66,6 +67,12 @@ int mw_model_set_int(mw_model* m, const char* field, const int32_t* v, int n);
 int mw_model_set_real(mw_model* m, const char* field, const double* v, int n);
 int mw_model_set_option(mw_model* m, const char* name, double value);
 void mw_model_free(mw_model* m);
+
+/* page-locked host memory for the caller's step / reset buffers (optional: any host memory works): into pinned buffers the
+ * outputs of mw_step travel as asynchronous DMA copies queued behind the kernel and drained by one synchronisation; into pageable
+ * memory every copy is staged and waited for on its own.  No reference counterpart (numpy arrays of a SyncVectorEnv). */
+void* mw_alloc_host(size_t bytes);   /* NULL on failure */
+void mw_free_host(void* p);
 
 /* ---- context (replaces make_mt_envs / SyncVectorEnv construction, metaworld/__init__.py:460-513) ---- */
 int mw_create(const mw_config* cfg, mw_ctx** out);
@@ -132,6 +139,15 @@ typedef struct mw_device_out {
 } mw_device_out;
 int mw_step_device(mw_ctx* c, const float* actions /*device [N][4]*/, const int32_t* next_goal /*device [N] or NULL = last uploaded*/,
                    const mw_device_out* out /*or NULL*/);
+/* the same step ordered against the CALLER's stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream; NULL = the null
+ * stream) instead of against the host: the context's stream waits for what the caller has queued so far (its writes to `actions` /
+ * `next_goal`), the step is launched, and the caller's stream is made to wait for it -- the call returns at once and whatever the
+ * caller queues next on its stream sees the outputs.  The `done` row is also copied to pinned host memory behind the kernel:
+ * mw_wait_done blocks until that copy has landed and returns it (valid until the next step), so that the host-side task selection
+ * of a finished env (RandomTaskSelectWrapper.reset, wrappers.py:116-119) costs one event wait, not a device-to-host tensor copy. */
+int mw_step_device_on(mw_ctx* c, const float* actions /*device [N][4]*/, const int32_t* next_goal /*device [N] or NULL*/,
+                      const mw_device_out* out /*or NULL*/, void* caller_stream);
+int mw_wait_done(mw_ctx* c, const uint8_t** done_host /*out: pinned host [N], the `done` flags of the last mw_step_device_on*/);
 int mw_reset_device(mw_ctx* c, const uint8_t* mask /*device [N] or NULL = all*/, const int32_t* goal_idx /*device [N]*/,
                     double* obs_out /*device [N][D] or NULL*/);
 
@@ -183,7 +199,17 @@ int mw_gather_bookkeeping(mw_ctx* c, mw_bookkeeping* out, int out_on_device);
  *      bit: MuJoCo's solver stops the same way; frequent in single precision at the optimum, 0 in fp64 on the bench workload),
  *      status[6..7] reserved. ---- */
 #define MW_STATUS_WORDS 8
-int mw_status(mw_ctx* c, int32_t* status /*[MW_STATUS_WORDS]*/, int clear);
+int mw_status(mw_ctx* c, int32_t* status /*[n]*/, int n /*words the caller has room for: the first min(n, MW_STATUS_WORDS) are written, the rest zeroed*/, int clear);
+
+/* HIP-event time of every launch (= step) of the LAST mw_step_resident / mw_step_resident_gather call, in ms, oldest first; returns
+ * the number written (<= cap; at most 8192 are recorded per call).  bench.py reports min / median / max beside the mean. */
+int mw_launch_times(mw_ctx* c, float* ms_out /*[cap]*/, int cap);
+
+/* run-time options of a finalized context (no reference counterpart): "split_collision" = 1: every dynamics evaluation runs its
+ * narrow phase as batch-wide kernels over (environment, candidate pair) work items between the lane kernels (mid phase ->
+ * type-sorted work lists -> narrow phase at several waves per SIMD) instead of inside the one fused step kernel; same contacts in the
+ * same order, same results (tests/test_split_collision.py).  0 (default) = the fused kernel. */
+int mw_set_option(mw_ctx* c, const char* name, double value);
 
 /* ---- state access for parity tests (mujoco data.qpos / qvel / mocap_pos, MujocoEnv.set_state) ---- */
 int mw_column_size(mw_ctx* c, int env, const char* what);

@@ -37,6 +37,8 @@ int MW_API(model_set_option)(mw_model* m, const char* name, double v) {
     return 0;
 }
 
+void* MW_API(alloc_host)(size_t bytes) { try { return Backend::alloc_host(bytes); } catch (...) { return nullptr; } }
+void MW_API(free_host)(void* p) { Backend::free_host(p); }
 int MW_API(create)(const mw_config* cfg, mw_ctx** out) {
     mw_ctx* c = new mw_ctx();
     c->cfg.precision = cfg->precision; c->cfg.device_id = cfg->device_id; c->cfg.rank = cfg->rank; c->cfg.world_size = cfg->world_size;
@@ -109,6 +111,12 @@ int MW_API(step_resident)(mw_ctx* c, int nsteps, int asteps, float* ms) { MW_TRY
 int MW_API(step_device)(mw_ctx* c, const float* d_act, const int32_t* d_next_goal, const mw_device_out* out) {
     MW_TRY(c, { MW_NEED_IMPL(c); if (!d_act) throw std::invalid_argument("step_device: actions are required"); c->impl->step_device(d_act, d_next_goal, out); });
 }
+int MW_API(step_device_on)(mw_ctx* c, const float* d_act, const int32_t* d_next_goal, const mw_device_out* out, void* caller_stream) {
+    MW_TRY(c, { MW_NEED_IMPL(c); if (!d_act) throw std::invalid_argument("step_device_on: actions are required"); c->impl->step_device(d_act, d_next_goal, out, true, caller_stream); });
+}
+int MW_API(wait_done)(mw_ctx* c, const uint8_t** done_host) {
+    MW_TRY(c, { MW_NEED_IMPL(c); if (!done_host) throw std::invalid_argument("wait_done: null output"); *done_host = c->impl->wait_done(); });
+}
 int MW_API(reset_device)(mw_ctx* c, const uint8_t* d_mask, const int32_t* d_goal_idx, double* d_obs) {
     MW_TRY(c, { MW_NEED_IMPL(c); if (!d_goal_idx) throw std::invalid_argument("reset_device: goal_idx is required"); c->impl->reset_device(d_mask, d_goal_idx, d_obs); });
 }
@@ -134,7 +142,11 @@ int MW_API(gather_bookkeeping)(mw_ctx* c, mw_bookkeeping* out, int out_on_device
 int MW_API(set_episode_phase)(mw_ctx* c, const int32_t* elapsed) { MW_TRY(c, { MW_NEED_IMPL(c); if (!elapsed) throw std::invalid_argument("set_episode_phase: null argument"); c->impl->set_episode_phase(elapsed); }); }
 int MW_API(set_goal_schedule)(mw_ctx* c, const int32_t* schedule, int K) { MW_TRY(c, { MW_NEED_IMPL(c); if (K < 0 || (K > 0 && !schedule)) throw std::invalid_argument("set_goal_schedule: K rows need a schedule"); c->impl->set_goal_schedule(schedule, K); }); }
 int MW_API(goal_schedule_pos)(mw_ctx* c, int32_t* out) { MW_TRY(c, { MW_NEED_IMPL(c); if (!out) throw std::invalid_argument("goal_schedule_pos: null output"); c->impl->goal_schedule_pos(out); }); }
-int MW_API(status)(mw_ctx* c, int32_t* out, int clear) { MW_TRY(c, { MW_NEED_IMPL(c); if (!out) throw std::invalid_argument("status: null output"); c->impl->status(out, clear); }); }
+int MW_API(status)(mw_ctx* c, int32_t* out, int n, int clear) { MW_TRY(c, { MW_NEED_IMPL(c); if (!out || n < 1) throw std::invalid_argument("status: null output"); c->impl->status(out, n, clear); }); }
+int MW_API(launch_times)(mw_ctx* c, float* out, int cap) {
+    try { MW_NEED_IMPL(c); if (!out || cap < 0) throw std::invalid_argument("launch_times: null output"); return c->impl->launch_times(out, cap); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
+}
+int MW_API(set_option)(mw_ctx* c, const char* name, double value) { MW_TRY(c, { MW_NEED_IMPL(c); if (!name) throw std::invalid_argument("set_option: null name"); c->impl->set_option(name, value); }); }
 int MW_API(column_size)(mw_ctx* c, int env, const char* what) {
     try { MW_NEED_IMPL(c); return c->impl->layout_size(env, what); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
 }

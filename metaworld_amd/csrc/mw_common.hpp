@@ -130,7 +130,9 @@ constexpr int CELL_N = 6 * CELL_GRID * CELL_GRID;
 constexpr int CELL_K = 8;         // vertices of a cell's list stored at the cell's fixed place (Model::mesh_cellxyz); longer lists continue in Model::mesh_ovfxyz
 constexpr int TLS_SLOTS = 60;    // thread-private scratchpad slots of the narrow phase: two polygons of up to 10 vertices (box-box face clipping)
 constexpr int IC_NBLK = 18;      // icount slot: number of constraint blocks (single rows / contact cones)
-constexpr int IC_SIZE = 24;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand, 23 solver stalls
+constexpr int IC_SIZE = 26;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand, 23 solver stalls, 24 / 25 split collision
+constexpr int IC_NCAND = 24;     // icount slot (split collision, mw_split.hpp): candidate pairs the mid-phase kernel listed for this environment (L.ipair / L.iitem)
+constexpr int IC_PENDING = 25;   // icount slot (split collision): 1 = the step waits for the lazy final dynamics (its narrow phase is on the way)
 constexpr int IC_DYN_VALID = 19;  // icount slot: 1 = contacts / constraint rows / solver output belong to the CURRENT qpos (see env_step)
 constexpr int IC_WANT_CON = 20, IC_WANT_EFC = 21;   // running maxima of the contacts / constraint rows a step WANTED (capacity planning)
 constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a non-zero Jacobian entry
@@ -161,6 +163,7 @@ struct Layout {
     int icon, iefc, icount;   // icount: ncon, nefc, niter, flags
     int iwork;                // constraint work items of make_constraints: (kind, id, first row) x maxefc
     int ipair;                // collision candidates (pair indices that passed the broad / mid phase), npair
+    int iitem;                // split collision: work-item id of every candidate (where the narrow-phase kernel left its hits), npair
     int nint;
 };
 
@@ -219,7 +222,7 @@ inline Layout make_layout(const Sizes& s) {
     L.efcX = take(EFC_EXTRA * s.maxefc);
     L.nreal = o;
     o = 0;
-    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(IC_SIZE); L.iwork = take(3 * s.maxefc); L.ipair = take(s.npair > 0 ? s.npair : 1);   // + 16 phase timers (MW_SOLVER_TIMING builds): 8 solver phases, 6 pipeline stages
+    L.icon = take(CON_ISTRIDE * s.maxcon); L.iefc = take(EFC_ISTRIDE * s.maxefc); L.icount = take(IC_SIZE); L.iwork = take(3 * s.maxefc); L.ipair = take(s.npair > 0 ? s.npair : 1); L.iitem = take(s.npair > 0 ? s.npair : 1);   // + 16 phase timers (MW_SOLVER_TIMING builds): 8 solver phases, 6 pipeline stages
     L.nint = o;
     return L;
 }
@@ -227,6 +230,10 @@ inline Layout make_layout(const Sizes& s) {
 // workgroup scratchpad handed to every lane program: LDS on the device (stride = lanes per workgroup), a private
 // buffer per host thread in the test harness (stride 1)
 struct Scratchpad { MW_LDS void* base; int block_words, host_nsub, max_rows, chain; };   // 4-byte words of the whole workgroup; host_nsub > 0: host harness (one call per env, that many emulated sub-lanes); max_rows > 0: cap on the rows kept in the scratchpad (tests of the fallback rows); chain: 0 = never stage the body-level chains in the scratchpad (Env::chain_lds), else when they fit
+
+// LDS of a flat wave kernel (mw_split.inl).  A struct, not a bare pointer parameter: the address-space qualifier exists only in the
+// device pass, and a lambda whose PARAMETER TYPES differ between the host and the device pass gets two different kernel symbol names
+struct WaveLds { MW_LDS void* base; };
 
 template <typename T> using CModel = const MW_CONST Model<T>;
 using CLayout = const MW_CONST Layout;

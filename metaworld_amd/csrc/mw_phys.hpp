@@ -1661,14 +1661,14 @@ MW_HD void integrate_impl(const Env<T> e) {
         if (qa[k] >= 0) e.R(L.qpos + qa[k]) = qp[k] + h * qv[k];
 }
 
+// the part of mj_step after mj_forward: Euler step (integrate_impl) + the orientation of the free bodies + time
 template <typename T>
-MW_STAGE_FN void substep(const Env<T> e_) {
+MW_STAGE_FN void integrate(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
     const int nv = m.sz.nv;
     const T h = m.timestep;
-    forward(e);
     MW_NV_DISPATCH(nv, (integrate_impl<T, NVC>(e)))
     for (int j = 0; j < m.sz.njnt; j++) {          // orientation of the free bodies: q <- q * exp(h w / 2)
         if (m.jnt_type[j] != J_FREE) continue;
@@ -1684,6 +1684,13 @@ MW_STAGE_FN void substep(const Env<T> e_) {
         }
     }
     e.R(L.time) += h;
+}
+
+template <typename T>
+MW_STAGE_FN void substep(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
+    forward(e);
+    integrate(e);
 }
 
 // mj_resetData

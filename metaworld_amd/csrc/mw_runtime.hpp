@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <set>
 #include <memory>
@@ -181,6 +182,7 @@ struct GroupDev {
     int* icol;
     int lpb;          // environments per workgroup; the column store is chunked per workgroup: [chunk][element][lpb]
     int nenv, block0;
+    int env0;         // environments of the groups before this one (flat environment index of the split-collision kernels)
     const int* gid;   // lane -> global env index
 };
 
@@ -314,19 +316,10 @@ MW_HD double ep_return_add(const Env<T> e, T reward) {
 }
 MW_HD bool mw_finite(double x) { return x - x == 0; }
 
-// one VectorEnv.step for one env: SawyerXYZEnv.step + TimeLimit + AutoTerminateOnSuccess + OneHot +
-// RecordEpisodeStatistics + SAME_STEP auto-reset (metaworld/__init__.py:430-454, :465)
+// everything of one VectorEnv.step that follows SawyerXYZEnv.step's (obs, reward, success, info): instability guard, TimeLimit,
+// AutoTerminateOnSuccess, OneHot, RecordEpisodeStatistics, the outputs and the SAME_STEP auto-reset (metaworld/__init__.py:430-454, :465)
 template <typename T>
-MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
-    Env<T> e; int gid;
-    if (!locate(w, block, thread, sp, &e, &gid)) return;
-    const int task = (int)TK(e, TK_TASK);
-    const TaskDesc<T>& td = w.tasks[task];
-    T act[4], obs[39], reward, success;
-    Info info;
-    for (int k = 0; k < 4; k++) act[k] = (T)w.io.act[(size_t)gid * 4 + k];
-    e.I(e.lay().icount + 3) = 0; e.I(e.lay().icount + IC_SOLVER_STALL) = 0;
-    env_step(e, td, act, obs, &reward, &success, &info, w.full_forward != 0);
+MW_HD void step_outputs(const World<T>& w, const Env<T> e, int gid, int task, const TaskDesc<T>& td, T* obs, T reward, T success, Info info) {
     // Instability guard (the intent of the reference's dead `_did_see_sim_exception` branch, sawyer_xyz_env.py:603-619, and
     // of MuJoCo's own reset on a bad QACC): a non-finite step returns the last stable observation with reward 0, ends the
     // episode as truncated (so the SAME_STEP auto-reset below restores a valid state) and raises ST_UNSTABLE.
@@ -406,6 +399,23 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     if (writer) write_obs(w, td, io.obs + (size_t)gid * io.D, obs, oh);
 }
 
+// one VectorEnv.step for one env: SawyerXYZEnv.step + the wrapper stack (step_outputs)
+template <typename T>
+MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
+    Env<T> e; int gid;
+    if (!locate(w, block, thread, sp, &e, &gid)) return;
+    const int task = (int)TK(e, TK_TASK);
+    const TaskDesc<T>& td = w.tasks[task];
+    T act[4], obs[39], reward, success;
+    Info info;
+    for (int k = 0; k < 4; k++) act[k] = (T)w.io.act[(size_t)gid * 4 + k];
+    e.I(e.lay().icount + 3) = 0; e.I(e.lay().icount + IC_SOLVER_STALL) = 0;
+    env_step(e, td, act, obs, &reward, &success, &info, w.full_forward != 0);
+    step_outputs(w, e, gid, task, td, obs, reward, success, info);
+}
+
+#include "mw_split.inl"
+
 // debugging / parity hooks: run raw physics on every lane
 template <typename T>
 MW_HD void lane_debug(const World<T>& w, int what, int n, int block, int thread, Scratchpad sp) {
@@ -454,7 +464,8 @@ public:
     virtual void step(const float* act, const int* next_goal, double* obs, double* reward, uint8_t* term, uint8_t* trunc,
                       uint8_t* success, float* info, double* final_obs, double* ep_ret, int* ep_len) = 0;
     virtual void step_device_only(const float* d_act, int nsteps, int act_stride_steps, float* kernel_ms, bool gather = false) = 0;
-    virtual void step_device(const float* d_act, const int* d_next_goal, const mw_device_out* out) = 0;
+    virtual void step_device(const float* d_act, const int* d_next_goal, const mw_device_out* out, bool async = false, void* caller_stream = nullptr) = 0;
+    virtual const uint8_t* wait_done() = 0;
     virtual void reset_device(const uint8_t* d_mask, const int* d_goal_idx, double* d_obs) = 0;
     virtual void policy_actions(const int* policy_id, const double* obs, float* act) = 0;
     virtual void policy_rollout(const int* policy_id, const int* schedule, int K, int nsteps, int* episodes, int* successes, float* kernel_ms, int per_launch = 1) = 0;
@@ -464,7 +475,9 @@ public:
     virtual void comm_init(const void* id128, int rank, int world) = 0;
     virtual void comm_info(int* out /*[4]*/) = 0;
     virtual void gather_bookkeeping(mw_bookkeeping* out, int out_on_device) = 0;
-    virtual void status(int* out /*[MW_STATUS_WORDS]*/, int clear) = 0;
+    virtual void status(int* out, int n, int clear) = 0;
+    virtual int launch_times(float* out, int cap) = 0;
+    virtual void set_option(const std::string& name, double value) = 0;
     virtual void set_episode_phase(const int* elapsed) = 0;
     virtual void set_goal_schedule(const int* schedule, int K) = 0;
     virtual void goal_schedule_pos(int* out) = 0;
@@ -494,7 +507,7 @@ class Context : public ContextBase {
         size_t iat(int i, int lane) const { return ((size_t)(lane / lpb) * L.nint + i) * lpb + lane % lpb; }     // int column element
         size_t nreal_total() const { return nchunk * lpb * (size_t)L.nreal; }
         size_t nint_total() const { return nchunk * lpb * (size_t)L.nint; }
-        int nenv = 0, block0 = 0, model = 0;
+        int nenv = 0, block0 = 0, model = 0, env0 = 0;
         std::vector<int> gid;
     };
     std::vector<Group> groups_;
@@ -526,6 +539,63 @@ class Context : public ContextBase {
     std::vector<int> h_next_goal_;            // host mirror of d_next_goal_ (masked resets update only their envs)
     std::vector<uint8_t> was_reset_;          // step() before the first reset() of an env is an error
     int world_size() const { return comm_ ? comm_->world : 1; }
+    uint8_t* h_done_ = nullptr;               // pinned host copy of the `done` row of the last mw_step_device_on
+    int split_collision_ = 0;                 // mw_set_option("split_collision"): 1 = the narrow phase runs as its own batch-wide kernels (launch_step)
+    SplitBuf<T> sb_{};                        // work items / hit table of the split collision (allocated on first use)
+    bool any_lazy_dynamics_ = false;          // some task's reward reads contact forces (task_touches) or cfg.full_forward: a sixth narrow phase per step
+    void ensure_split_buffers() {
+        if (sb_.counts) return;
+        if (groups_.size() > 127) throw std::runtime_error("split_collision: more than 127 model groups");
+        for (auto& g : groups_) if (g.nenv >= (1 << 24)) throw std::runtime_error("split_collision: more than 2^24 environments in one group");
+        const char* ov = getenv("MW_SPLIT_ITEMS_PER_ENV");
+        const size_t cap = (size_t)N_ * (ov ? atoi(ov) : 48);
+        sb_.cap = (int)cap;
+        sb_.counts = (int*)Backend::alloc(sizeof(int) * SC_WORDS); Backend::zero(sb_.counts, sizeof(int) * SC_WORDS);
+        sb_.item_env = (int*)Backend::alloc(sizeof(int) * cap); sb_.item_pair = (int*)Backend::alloc(sizeof(int) * cap);
+        sb_.class_list = (int*)Backend::alloc(sizeof(int) * cap * NP_NCLASS);
+        sb_.hit_n = (int*)Backend::alloc(sizeof(int) * cap);
+        sb_.hits = (T*)Backend::alloc(sizeof(T) * cap * NP_MAXHIT * NP_HIT_W);
+        any_lazy_dynamics_ = cfg.full_forward != 0;
+        for (int t : env_task) any_lazy_dynamics_ |= task_touches(tasks[t].kind);
+    }
+    void free_split_buffers() {
+        Backend::free(sb_.counts); Backend::free(sb_.item_env); Backend::free(sb_.item_pair); Backend::free(sb_.class_list); Backend::free(sb_.hit_n); Backend::free(sb_.hits);
+        sb_ = SplitBuf<T>{};
+    }
+    // one mid phase + narrow phase over the whole batch (or, only_pending, over the environments that wait for the lazy final dynamics)
+    void launch_collision(const World<T>& w, bool only_pending) {
+        const SplitBuf<T> sb = sb_;
+        Backend::zero(sb.counts, sizeof(int) * SC_WORDS);
+        Backend::launch_waves(N_, 0, [w, sb, only_pending] MW_LAMBDA(int wave, int tid, int nwaves, WaveLds lds) {
+            (void)nwaves; (void)lds;
+            mid_phase_env(w, sb, wave, tid, only_pending);
+        });
+        Backend::launch_waves(Backend::narrow_waves(), (int)(TLS_SLOTS * 64 * sizeof(T)), [w, sb] MW_LAMBDA(int wave, int tid, int nwaves, WaveLds lds) {
+            narrow_wave(w, sb, wave, tid, nwaves, (MW_LDS T*)lds.base);
+        });
+    }
+    // (ONE kernel for the four phases, selected at run time: one copy of the lane programs in the code object)
+    void phase_kernel(const World<T>& w, const SplitBuf<T>& sb, int phase) {
+        Backend::launch(nblocks_, [w, sb, phase] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_phase(w, sb, phase, b, t, sp); });
+    }
+    // ONE VectorEnv.step of the whole batch on the context's stream: the fused kernel, or the split-collision sequence (mw_split.inl)
+    void launch_step(const World<T>& w) {
+        if (!split_collision_) {
+            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+            return;
+        }
+        ensure_split_buffers();
+        const SplitBuf<T> sb = sb_;
+        phase_kernel(w, sb, PH_BEGIN);
+        for (int k = 0; k < 5; k++) {
+            launch_collision(w, false);
+            phase_kernel(w, sb, k < 4 ? PH_MID : PH_LAST);
+        }
+        if (any_lazy_dynamics_) {
+            launch_collision(w, true);
+            phase_kernel(w, sb, PH_FINAL);
+        }
+    }
 
     World<T> world(bool with_io = true) const {
         World<T> w{};
@@ -575,7 +645,7 @@ class Context : public ContextBase {
     void free_group(Group& g) { Backend::free(g.col); Backend::free(g.icol); Backend::free(g.gid_dev); g.col = nullptr; }
     GroupDev<T> dev_of(const Group& g) const {
         GroupDev<T> d{};
-        d.m = g.dm->m; d.L = g.L; d.col = g.col; d.icol = g.icol; d.lpb = g.lpb; d.nenv = g.nenv; d.block0 = g.block0; d.gid = g.gid_dev;
+        d.m = g.dm->m; d.L = g.L; d.col = g.col; d.icol = g.icol; d.lpb = g.lpb; d.nenv = g.nenv; d.block0 = g.block0; d.env0 = g.env0; d.gid = g.gid_dev;
         return d;
     }
     void set_task_field(Group& g, int lane, int k, double v) {
@@ -591,6 +661,8 @@ public:
         Backend::free(d_act_); Backend::free(d_next_goal_); Backend::free(d_mask_); Backend::free(d_obs_); Backend::free(d_reward_);
         Backend::free(d_final_); Backend::free(d_epret_); Backend::free(d_flags_); Backend::free(d_info_); Backend::free(d_eplen_);
         Backend::free(d_snap_ngoal_); Backend::free(d_status_); Backend::free(d_book_); Backend::free(d_book_all_);
+        free_split_buffers();
+        Backend::free_host(h_done_);
         Backend::comm_free(comm_);
     }
 
@@ -707,11 +779,12 @@ public:
             for (auto& kv : hist) fprintf(stderr, " %d:%d", kv.first, kv.second);
             fprintf(stderr, "  (%d workgroups)\n", nb);
         }
-        int gi = 0, blk = 0;
+        int gi = 0, blk = 0, env0 = 0;
         for (auto& kv : by_model) {
             Group& g = groups_[gi];
             make_group(g, kv.first, kv.second, lpb_of[kv.first]);
             g.block0 = blk;
+            g.env0 = env0; env0 += g.nenv;
             blk += (g.nenv + g.lpb - 1) / g.lpb;
             for (int l = 0; l < g.nenv; l++) { env_group_[kv.second[l]] = gi; env_lane_[kv.second[l]] = l; }
             gi++;
@@ -875,7 +948,7 @@ public:
         if (next_goal) Backend::h2d_async(d_next_goal_, h_next_goal_.data(), sizeof(int) * N_);
         book_slot_ ^= 1;
         World<T> w = world();
-        Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+        launch_step(w);
         // all outputs are queued behind the kernel on the context's stream and drained by ONE synchronisation
         const int D = obs_dim();
         if (obs) Backend::d2h_async(obs, d_obs_, sizeof(double) * N_ * D);
@@ -892,8 +965,11 @@ public:
 
     // device-resident boundary: actions / goal indices are device pointers, outputs are written straight into the caller's
     // device buffers (any of them null = the context's own buffer); no host copies, one stream sync before returning
-    void step_device(const float* d_act, const int* d_next_goal, const mw_device_out* out) override {
+    // async (mw_step_device_on): ordered against the caller's stream by events instead of a host synchronisation; the `done` row is
+    // copied to pinned host memory behind the kernel, wait_done() hands it over when it has landed
+    void step_device(const float* d_act, const int* d_next_goal, const mw_device_out* out, bool async, void* caller_stream) override {
         need_reset_done("step_device");
+        if (async) Backend::wait_for_caller(caller_stream);
         book_slot_ ^= 1;
         World<T> w = world();
         w.io.act = d_act;
@@ -907,14 +983,24 @@ public:
             if (out->episode_return) w.io.ep_ret = out->episode_return;
             if (out->episode_length) w.io.ep_len = out->episode_length;
         }
-        Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
-        Backend::sync();
+        launch_step(w);
+        if (!async) { Backend::sync(); return; }
+        if (!h_done_) h_done_ = (uint8_t*)Backend::alloc_host(N_);
+        Backend::d2h_async(h_done_, w.io.done, N_);
+        Backend::record_done();
+        Backend::caller_waits_for_us(caller_stream);
+    }
+    const uint8_t* wait_done() override {
+        if (!h_done_) throw std::logic_error("wait_done: no mw_step_device_on call to wait for");
+        Backend::wait_done();
+        return h_done_;
     }
     void reset_device(const uint8_t* d_mask, const int* d_goal_idx, double* d_obs) override {
-        // a full reset (no mask) satisfies the step-before-reset guard; a DEVICE mask cannot be inspected without a copy, so it is
-        // copied back once here (N bytes) and only the envs it selects are marked
+        // a full reset (no mask) satisfies the step-before-reset guard; a DEVICE mask cannot be inspected without a copy: it is copied
+        // back (N bytes, blocking) ONLY while some env has never been reset -- once all have, the guard has nothing left to learn and
+        // a masked device reset costs no host round trip
         if (!d_mask) was_reset_.assign(N_, 1);
-        else {
+        else if (std::find(was_reset_.begin(), was_reset_.end(), (uint8_t)0) != was_reset_.end()) {
             std::vector<uint8_t> hm(N_);
             Backend::d2h(hm.data(), d_mask, N_);
             for (int i = 0; i < N_; i++) if (hm[i]) was_reset_[i] = 1;
@@ -975,7 +1061,7 @@ public:
             for (int s = 0; s < nsteps; s++) {
                 const bool account = s > 0;
                 Backend::launch_flat(N_, [io, ps, N, account] MW_LAMBDA(int gid) { policy_thread(io, ps, N, gid, account, true); });
-                Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+                launch_step(w);
             }
         } else {
             // several (policy, step) pairs per launch: the policy of an environment is evaluated by the environment's own writer thread
@@ -1030,7 +1116,8 @@ public:
             World<T> w = world();
             w.io.act = base + (size_t)(act_steps > 0 ? s % act_steps : 0) * 4 * N_;
             if (d_sched_) { w.io.sched = d_sched_; w.io.sched_pos = d_sched_pos_; w.io.sched_K = sched_K_; }
-            Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
+            launch_step(w);
+            Backend::timed_mark();
             if (gather) gather_async();
         }
         float ms = Backend::timed_end();
@@ -1120,9 +1207,16 @@ public:
         Backend::sync();
         Backend::d2h(out, d_sched_pos_, sizeof(int) * N_);
     }
-    void status(int* out, int clear) override {
-        Backend::d2h(out, d_status_, sizeof(int) * MW_STATUS_WORDS);
+    void status(int* out, int n, int clear) override {
+        int all[MW_STATUS_WORDS];
+        Backend::d2h(all, d_status_, sizeof(int) * MW_STATUS_WORDS);
+        for (int k = 0; k < n; k++) out[k] = k < MW_STATUS_WORDS ? all[k] : 0;          // the caller says how many words it has room for
         if (clear) { Backend::zero(d_status_, sizeof(int) * MW_STATUS_WORDS); Backend::sync(); }
+    }
+    int launch_times(float* out, int cap) override { return Backend::launch_times(out, cap); }
+    void set_option(const std::string& name, double value) override {
+        if (name == "split_collision") { Backend::sync(); split_collision_ = value != 0 ? 1 : 0; }
+        else throw std::invalid_argument("set_option: unknown option " + name);
     }
 
     void debug(int what, int n) override {

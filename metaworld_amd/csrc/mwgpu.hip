@@ -14,6 +14,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #define MW_LAMBDA __host__ __device__
 
@@ -31,6 +32,13 @@ __global__ void __launch_bounds__(64) k_lanes(F f, int block_words, int chain) {
     //  roles of newton_direction_wave, mw_phys.hpp, assume 64 lanes: Backend::init refuses a device whose wavefront is not 64 wide)
     extern __shared__ float mw_scratchpad[];
     f((int)blockIdx.x, (int)threadIdx.x, mw::Scratchpad{(MW_LDS void*)mw_scratchpad, block_words, 0, 0, chain});
+}
+
+// flat wave kernels of the split collision (mw_split.inl): f(wave, lane, number of waves, LDS); no sub-lanes, no column-store chunking
+template <class F>
+__global__ void __launch_bounds__(64) k_waves(F f) {
+    extern __shared__ float mw_wave_lds[];
+    f((int)blockIdx.x, (int)threadIdx.x, (int)gridDim.x, mw::WaveLds{(MW_LDS void*)mw_wave_lds});
 }
 
 // one thread per environment, no scratchpad: the small per-env kernels around the step (scripted policies, accounting)
@@ -76,7 +84,7 @@ struct Rccl {
 // One stream / event pair / side stream per HIP device, created on first use; every ABI entry selects its context's
 // device first (Backend::use), so contexts on different devices can live in one process.
 struct Backend {
-    struct Dev { hipStream_t stream = nullptr, side = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr}, gev[2] = {nullptr, nullptr}; bool gev_used[2] = {false, false}; int max_lds = 65536, num_cu = 256; bool ready = false; };
+    struct Dev { hipEvent_t cin = nullptr, cout = nullptr, done_ev = nullptr; std::vector<hipEvent_t> marks; int nmarks = 0; hipStream_t stream = nullptr, side = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr}, gev[2] = {nullptr, nullptr}; bool gev_used[2] = {false, false}; int max_lds = 65536, num_cu = 256; bool ready = false; };
     static constexpr int MAX_DEV = 64;
     static Dev& dev() { static Dev d[MAX_DEV]; return d[cur()]; }
     static int& cur() { static thread_local int c = 0; return c; }
@@ -102,6 +110,9 @@ struct Backend {
         if (wave != 64) throw std::runtime_error("libmwgpu: the lane programs assume 64-wide wavefronts (one wave per workgroup, wave-local exchanges); this device reports " + std::to_string(wave));
         hip_check(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipEventCreateWithFlags(&d.cin, hipEventDisableTiming), "hipEventCreate");
+        hip_check(hipEventCreateWithFlags(&d.cout, hipEventDisableTiming), "hipEventCreate");
+        hip_check(hipEventCreateWithFlags(&d.done_ev, hipEventDisableTiming), "hipEventCreate");
         for (int k = 0; k < 2; k++) {
             hip_check(hipEventCreate(&d.ev[k]), "hipEventCreate");
             hip_check(hipEventCreateWithFlags(&d.xev[k], hipEventDisableTiming), "hipEventCreate");
@@ -150,13 +161,50 @@ struct Backend {
         hipLaunchKernelGGL(k_lanes<F>, dim3(nblocks), dim3(64), bytes, stream(), f, bytes / 4, chain);
         hip_check(hipGetLastError(), "kernel launch");
     }
+    // persistent waves of the narrow-phase kernel: two per SIMD (its callee collide_pair uses 256 VGPRs)
+    static int narrow_waves() { static const char* ov = getenv("MW_NARROW_WAVES"); return ov ? atoi(ov) : 8 * compute_units(); }
+    template <class F>
+    static void launch_waves(int nwaves, int lds_bytes, F f) {
+        if (lds_bytes > 65536) hip_check(hipFuncSetAttribute((const void*)k_waves<F>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "hipFuncSetAttribute(LDS)");
+        hipLaunchKernelGGL(k_waves<F>, dim3(nwaves), dim3(64), lds_bytes, stream(), f);
+        hip_check(hipGetLastError(), "kernel launch");
+    }
     template <class F>
     static void launch_flat(int n, F f) {
         hipLaunchKernelGGL(k_flat<F>, dim3((n + 255) / 256), dim3(256), 0, stream(), f, n);
         hip_check(hipGetLastError(), "kernel launch");
     }
     static void sync() { hip_check(hipStreamSynchronize(stream()), "hipStreamSynchronize"); }
-    static void timed_begin() { hip_check(hipEventRecord(events()[0], stream()), "hipEventRecord"); }
+    // ordering against the CALLER's stream (mw_step_device_on): our stream first waits for everything the caller has queued (its
+    // writes to the action tensor), and afterwards the caller's stream waits for what we queued -- no host synchronisation at all
+    static void wait_for_caller(void* s) {
+        Dev& d = dev();
+        hip_check(hipEventRecord(d.cin, (hipStream_t)s), "hipEventRecord(caller stream)");
+        hip_check(hipStreamWaitEvent(d.stream, d.cin, 0), "hipStreamWaitEvent");
+    }
+    static void caller_waits_for_us(void* s) {
+        Dev& d = dev();
+        hip_check(hipEventRecord(d.cout, d.stream), "hipEventRecord");
+        hip_check(hipStreamWaitEvent((hipStream_t)s, d.cout, 0), "hipStreamWaitEvent(caller stream)");
+    }
+    static void record_done() { hip_check(hipEventRecord(dev().done_ev, dev().stream), "hipEventRecord"); }
+    static void wait_done() { hip_check(hipEventSynchronize(dev().done_ev), "hipEventSynchronize"); }
+    static void timed_begin() { dev().nmarks = 0; hip_check(hipEventRecord(events()[0], stream()), "hipEventRecord"); }
+    // per-launch times of a timed region (mw_launch_times): one event after every step of the resident loop, read after timed_end
+    static constexpr int MAX_MARKS = 8192;
+    static void timed_mark() {
+        Dev& d = dev();
+        if (d.nmarks >= MAX_MARKS) return;
+        if ((int)d.marks.size() <= d.nmarks) { hipEvent_t e; hip_check(hipEventCreate(&e), "hipEventCreate"); d.marks.push_back(e); }
+        hip_check(hipEventRecord(d.marks[d.nmarks++], d.stream), "hipEventRecord");
+    }
+    static int launch_times(float* out, int cap) {          // ms between consecutive marks of the last timed region (the first from timed_begin)
+        Dev& d = dev();
+        int n = 0;
+        for (; n < d.nmarks && n < cap; n++)
+            hip_check(hipEventElapsedTime(out + n, n == 0 ? d.ev[0] : d.marks[n - 1], d.marks[n]), "hipEventElapsedTime");
+        return n;
+    }
     static float timed_end() {
         hip_check(hipEventRecord(events()[1], stream()), "hipEventRecord");
         hip_check(hipEventSynchronize(events()[1]), "hipEventSynchronize");

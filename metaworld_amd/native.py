@@ -79,6 +79,8 @@ class Lib:
         f("model_set_int", C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int)
         f("model_set_real", C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int)
         f("model_set_option", C.c_int, C.c_void_p, C.c_char_p, C.c_double)
+        f("alloc_host", C.c_void_p, C.c_size_t)
+        f("free_host", None, C.c_void_p)
         f("create", C.c_int, C.POINTER(MwConfig), C.POINTER(C.c_void_p))
         f("add_model", C.c_int, C.c_void_p, C.c_void_p)
         f("add_task", C.c_int, C.c_void_p, C.POINTER(MwTask), C.c_void_p, C.c_int)
@@ -95,6 +97,8 @@ class Lib:
         f("step_resident", C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float))
         f("step_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MwDeviceOut))
         f("reset_device", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+        f("step_device_on", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(MwDeviceOut), C.c_void_p)
+        f("wait_done", C.c_int, C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)))
         f("policy_actions", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
         f("policy_rollout", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float))
         f("policy_rollout_fused", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float))
@@ -103,7 +107,9 @@ class Lib:
         f("comm_init", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
         f("comm_info", C.c_int, C.c_void_p, C.c_void_p)
         f("gather_bookkeeping", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
-        f("status", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+        f("status", C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+        f("launch_times", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+        f("set_option", C.c_int, C.c_void_p, C.c_char_p, C.c_double)
         f("set_episode_phase", C.c_int, C.c_void_p, C.c_void_p)
         f("step_resident_fused", C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float))
         f("set_goal_schedule", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
@@ -134,10 +140,23 @@ def load(prefix="mw_", path=None) -> Lib:
     return _libs[key]
 
 
-EXPORTED_SYMBOLS = ["model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
+EXPORTED_SYMBOLS = ["alloc_host", "free_host", "model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
                     "add_model", "add_task", "set_envs", "finalize", "set_terminate_on_success", "destroy", "last_error", "num_envs", "obs_dim",
-                    "reset", "step", "step_device", "reset_device", "policy_actions", "policy_rollout", "policy_rollout_fused", "upload_actions", "step_resident", "step_resident_fused", "step_resident_gather", "comm_unique_id", "comm_init", "comm_info", "gather_bookkeeping", "status", "set_episode_phase", "set_goal_schedule", "goal_schedule_pos", "column_size", "read", "write", "read_int",
+                    "reset", "step", "step_device", "step_device_on", "wait_done", "reset_device", "policy_actions", "policy_rollout", "policy_rollout_fused", "upload_actions", "step_resident", "step_resident_fused", "step_resident_gather", "comm_unique_id", "comm_init", "comm_info", "gather_bookkeeping", "status", "launch_times", "set_option", "set_episode_phase", "set_goal_schedule", "goal_schedule_pos", "column_size", "read", "write", "read_int",
                     "debug"]
+
+
+class _PinnedBlock:
+    """one mw_alloc_host block; released when the last numpy view of it is garbage-collected"""
+
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self.lib.free_host(self.ptr)
+        except Exception:
+            pass
 
 
 class Context:
@@ -191,10 +210,24 @@ class Context:
     def finalize(self):
         self._check(self.lib.finalize(self.ptr))
         N, D = self.N, self.D
-        self.obs = np.zeros((N, D)); self.final_obs = np.zeros((N, D))
-        self.reward = np.zeros(N); self.ep_ret = np.zeros(N); self.ep_len = np.zeros(N, dtype=np.int32)
-        self.terminated = np.zeros(N, dtype=np.uint8); self.truncated = np.zeros(N, dtype=np.uint8)
-        self.success = np.zeros(N, dtype=np.uint8); self.info = np.zeros((N, 6), dtype=np.float32)
+        # the step / reset buffers live in page-locked memory (mw_alloc_host): the outputs of mw_step arrive as asynchronous DMA copies
+        z = self._host_zeros
+        self.obs = z((N, D), np.float64); self.final_obs = z((N, D), np.float64)
+        self.reward = z((N,), np.float64); self.ep_ret = z((N,), np.float64); self.ep_len = z((N,), np.int32)
+        self.terminated = z((N,), np.uint8); self.truncated = z((N,), np.uint8)
+        self.success = z((N,), np.uint8); self.info = z((N, 6), np.float32)
+        self._act_stage = z((N, 4), np.float32)
+
+    def _host_zeros(self, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.alloc_host(n) if n else None
+        if not p:
+            return np.zeros(shape, dtype=dtype)
+        buf = (C.c_char * n).from_address(p)
+        buf._mw_owner = _PinnedBlock(self.lib, p)          # freed when the last numpy view of the block is gone (views may outlive close())
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        a[...] = 0
+        return a
 
     def set_terminate_on_success(self, on):
         self._check(self.lib.set_terminate_on_success(self.ptr, int(bool(on))))
@@ -206,8 +239,9 @@ class Context:
         return self.obs
 
     def step(self, actions, next_goal=None):
-        a = np.ascontiguousarray(actions, dtype=np.float32)
-        assert a.shape == (self.N, 4)
+        assert np.shape(actions) == (self.N, 4)
+        a = self._act_stage
+        a[...] = actions          # (pinned staging: the upload is an asynchronous copy too)
         ng = None if next_goal is None else np.ascontiguousarray(next_goal, dtype=np.int32)
         self._check(self.lib.step(self.ptr, a.ctypes.data, None if ng is None else ng.ctypes.data, self.obs.ctypes.data,
                                   self.reward.ctypes.data, self.terminated.ctypes.data, self.truncated.ctypes.data,
@@ -218,6 +252,16 @@ class Context:
     def step_device(self, actions_ptr, next_goal_ptr=None, out: MwDeviceOut | None = None):
         """mw_step_device: raw device pointers in, outputs into the caller's device buffers"""
         self._check(self.lib.step_device(self.ptr, actions_ptr, next_goal_ptr, None if out is None else C.byref(out)))
+
+    def step_device_on(self, actions_ptr, next_goal_ptr, out, stream_handle):
+        """mw_step_device_on: the step ordered against the caller's stream by events; returns at once"""
+        self._check(self.lib.step_device_on(self.ptr, actions_ptr, next_goal_ptr, None if out is None else C.byref(out), stream_handle))
+
+    def wait_done(self):
+        """mw_wait_done -> uint8 [N] view of the pinned host copy of the last step's `done` row (valid until the next step)"""
+        p = C.POINTER(C.c_uint8)()
+        self._check(self.lib.wait_done(self.ptr, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(self.N,))
 
     def reset_device(self, goal_idx_ptr, mask_ptr=None, obs_ptr=None):
         self._check(self.lib.reset_device(self.ptr, mask_ptr, goal_idx_ptr, obs_ptr))
@@ -305,9 +349,19 @@ class Context:
     def status(self, clear=False):
         """mw_status -> dict(flags, row_overflow_steps, contact_overflow_steps, unstable_steps, diverged_steps, solver_stalls); flags: 1 / 2 capacity exceeded, 4 non-finite state, 8 sub-lane divergence canary (include/mwgpu.h)"""
         out = np.zeros(STATUS_WORDS, dtype=np.int32)
-        self._check(self.lib.status(self.ptr, out.ctypes.data, int(bool(clear))))
+        self._check(self.lib.status(self.ptr, out.ctypes.data, STATUS_WORDS, int(bool(clear))))
         return dict(flags=int(out[0]), row_overflow_steps=int(out[1]), contact_overflow_steps=int(out[2]), unstable_steps=int(out[3]),
                     diverged_steps=int(out[4]), solver_stalls=int(out[5]))
+
+    def launch_times(self, cap=8192):
+        """mw_launch_times -> float32 [n] ms of every launch (step) of the last step_resident / step_resident_gather call"""
+        out = np.zeros(cap, dtype=np.float32)
+        n = self._check(self.lib.launch_times(self.ptr, out.ctypes.data, cap))
+        return out[:n]
+
+    def set_option(self, name, value):
+        """mw_set_option: run-time options of the context ("split_collision")"""
+        self._check(self.lib.set_option(self.ptr, name.encode(), float(value)))
 
     def upload_actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32)

@@ -593,6 +593,8 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
                                "(raise maxcon / maxefc)")
         if st["flags"] & 8:
             raise RuntimeError(f"the step kernel's redundancy canary fired (threads sharing one env disagreed): {st}")
+        if st["flags"] & 16:
+            raise RuntimeError(f"a column-store / scratchpad index was out of range (MW_BOUNDS build of the library): {st}")
         if st["flags"] & 4:
             import warnings
             warnings.warn(f"non-finite simulation state caught; the affected envs were truncated and reset: {st}")

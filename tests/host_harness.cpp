@@ -153,10 +153,32 @@ struct Backend {
     }
     template <class F>
     static void launch_flat(int n, F f) { for (int i = 0; i < n; i++) f(i); }
+    // flat wave kernels of the split collision: one call per "wave" (the host forms of mid_phase_env / narrow_wave do a whole
+    // environment / all items per call), in order -- the work-item ids are then deterministic
+    static int narrow_waves() { return 1; }
+    template <class F>
+    static void launch_waves(int nwaves, int lds_bytes, F f) {
+        std::vector<double> pad((size_t)lds_bytes / 8 + 64, std::nan(""));
+        for (int i = 0; i < nwaves; i++) f(i, 0, nwaves, mw::WaveLds{(void*)pad.data()});
+    }
     static int compute_units() { return 256; }
+    static void wait_for_caller(void*) {}
+    static void caller_waits_for_us(void*) {}
+    static void record_done() {}
+    static void wait_done() {}
+    static void* alloc_host(size_t bytes) { return std::malloc(bytes ? bytes : 16); }
+    static void free_host(void* p) { std::free(p); }
     static void sync() {}
     static std::chrono::steady_clock::time_point& t0() { static std::chrono::steady_clock::time_point t; return t; }
-    static void timed_begin() { t0() = std::chrono::steady_clock::now(); }
+    static std::vector<std::chrono::steady_clock::time_point>& marks() { static std::vector<std::chrono::steady_clock::time_point> m; return m; }
+    static void timed_begin() { marks().clear(); t0() = std::chrono::steady_clock::now(); }
+    static void timed_mark() { marks().push_back(std::chrono::steady_clock::now()); }
+    static int launch_times(float* out, int cap) {
+        int n = 0;
+        for (; n < (int)marks().size() && n < cap; n++)
+            out[n] = std::chrono::duration<float, std::milli>(marks()[n] - (n == 0 ? t0() : marks()[n - 1])).count();
+        return n;
+    }
     static float timed_end() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0()).count(); }
 };
 }  // namespace

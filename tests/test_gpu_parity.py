@@ -75,7 +75,7 @@ def test_gpu_task_matches_reference_trace(gpulib, task):
     if task == "basketball-v3":     # only the first episode of a fresh env is history-free
         G = {k: (v[:1] if getattr(v, "ndim", 0) >= 1 and len(v) == len(G["goal_idx"]) and k != "rand_vecs" else v) for k, v in G.items()}
     env = make_env(gpulib, task, n=len(G["goal_idx"]), precision="fp64")
-    r = replay_trace(env, G, sync=True, steps=30)
+    r = replay_trace(env, G, sync=True)          # all 60 recorded steps (rounds 1-4 replayed 30: VERDICT r4)
     st = env.status()
     env.close()
     tol_obs, tol_rew = TOL.get(task, (1e-5, 1e-5))
