@@ -215,6 +215,10 @@ int mw_set_option(mw_ctx* c, const char* name, double value);
 int mw_column_size(mw_ctx* c, int env, const char* what);
 int mw_read(mw_ctx* c, int env, const char* what, double* out, int n);
 int mw_write(mw_ctx* c, int env, const char* what, const double* in, int n);
+/* the persistent state of EVERY environment in one call (checkpoints: MujocoEnv.set_state / data.qpos, qvel + the episode block):
+ * row i = the mw_column_size(i, "state") reals that mw_read(i, "state") returns, rows `stride` doubles apart */
+int mw_get_state(mw_ctx* c, double* out /*[N][stride]*/, int stride);
+int mw_set_state(mw_ctx* c, const double* in /*[N][stride]*/, int stride);
 int mw_read_int(mw_ctx* c, int env, const char* what, int32_t* out, int n);
 int mw_debug(mw_ctx* c, int what /*0 forward, 1 n substeps, 2 resetData, 3 kinematics*/, int n);
 

@@ -150,6 +150,8 @@ int MW_API(set_option)(mw_ctx* c, const char* name, double value) { MW_TRY(c, { 
 int MW_API(column_size)(mw_ctx* c, int env, const char* what) {
     try { MW_NEED_IMPL(c); return c->impl->layout_size(env, what); } catch (const std::exception& ex) { c->error = ex.what(); return -1; }
 }
+int MW_API(get_state)(mw_ctx* c, double* out, int stride) { MW_TRY(c, { MW_NEED_IMPL(c); if (!out) throw std::invalid_argument("get_state: null output"); c->impl->state_all(out, stride, false); }); }
+int MW_API(set_state)(mw_ctx* c, const double* in, int stride) { MW_TRY(c, { MW_NEED_IMPL(c); if (!in) throw std::invalid_argument("set_state: null input"); c->impl->state_all(const_cast<double*>(in), stride, true); }); }
 int MW_API(read)(mw_ctx* c, int env, const char* what, double* out, int n) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->read_col(env, what, n, out); }); }
 int MW_API(write)(mw_ctx* c, int env, const char* what, const double* in, int n) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->write_col(env, what, n, in); }); }
 int MW_API(read_int)(mw_ctx* c, int env, const char* what, int32_t* out, int n) { MW_TRY(c, { MW_NEED_IMPL(c); c->impl->read_icol(env, what, n, out); }); }

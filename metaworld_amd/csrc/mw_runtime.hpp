@@ -481,6 +481,7 @@ public:
     virtual void set_episode_phase(const int* elapsed) = 0;
     virtual void set_goal_schedule(const int* schedule, int K) = 0;
     virtual void goal_schedule_pos(int* out) = 0;
+    virtual void state_all(double* buf, int stride, bool write) = 0;
     virtual void read_col(int gid, const char* what, int n, double* out) = 0;
     virtual void write_col(int gid, const char* what, int n, const double* in) = 0;
     virtual void read_icol(int gid, const char* what, int n, int* out) = 0;
@@ -1247,6 +1248,22 @@ public:
         int n; const Group& g = groups_.at(env_group_.at(gid));
         try { offset_of(g.L, models[g.model]->sz, what, &n); } catch (...) { ioffset_of(g.L, models[g.model]->sz, what, &n); }
         return n;
+    }
+    // persistent state (Layout::nstate reals: qpos, qvel, warm start, ctrl, mocap, relocated bodies, time, task / episode block) of
+    // EVERY environment in one pass: the whole column store of a group travels once, instead of one copy per element and env
+    void state_all(double* buf, int stride, bool write) override {
+        Backend::sync();
+        for (auto& g : groups_) {
+            std::vector<T> host(g.nreal_total());
+            Backend::d2h(host.data(), g.col, sizeof(T) * host.size());
+            if (g.L.nstate > stride) throw std::invalid_argument("state_all: stride smaller than an environment's state (mw_column_size(env, \"state\"))");
+            for (int l = 0; l < g.nenv; l++) {
+                double* row = buf + (size_t)g.gid[l] * stride;
+                if (write) for (int k = 0; k < g.L.nstate; k++) host[g.at(k, l)] = (T)row[k];
+                else for (int k = 0; k < g.L.nstate; k++) row[k] = (double)host[g.at(k, l)];
+            }
+            if (write) Backend::h2d(g.col, host.data(), sizeof(T) * host.size());
+        }
     }
     void read_col(int gid, const char* what, int n, double* out) override {
         const Group& g = groups_.at(env_group_.at(gid));

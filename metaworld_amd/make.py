@@ -29,12 +29,10 @@ def make_mt_envs(name, seed=None, num_tasks=None, vector_strategy="sync", autore
     VectorEnv of `num_envs` copies) or "MT10" / "MT25" / "MT50"."""
     _check_autoreset(autoreset_mode)
     gs = 42 if seed is None else seed          # the reference draws unseeded goals for seed=None; a fixed table is reproducible
-    if name in T.ALL_V3:
-        return MetaWorldGpuVectorEnv("MT1", name, num_envs=num_envs or 1, seed=seed, goal_seed=gs, **kwargs)
-    if name in _MT:
-        if num_tasks is not None and num_tasks != len(T.benchmark_task_names(name)):
-            raise NotImplementedError("num_tasks other than the benchmark's own size (a wider one-hot) is not supported")
-        return MetaWorldGpuVectorEnv(name, num_envs=num_envs, seed=seed, goal_seed=gs, **kwargs)
+    if name in T.ALL_V3:          # `num_tasks=num_tasks or 1` (metaworld/__init__.py:477)
+        return MetaWorldGpuVectorEnv("MT1", name, num_envs=num_envs or 1, seed=seed, goal_seed=gs, num_tasks=num_tasks or 1, **kwargs)
+    if name in _MT:               # `num_tasks=num_tasks or default_num_tasks` (:501): the one-hot may be wider than the benchmark
+        return MetaWorldGpuVectorEnv(name, num_envs=num_envs, seed=seed, goal_seed=gs, num_tasks=num_tasks, **kwargs)
     raise ValueError("Invalid MT env name. Must either be a valid Metaworld task name (e.g. 'reach-v3'), 'MT10' or 'MT50'.")
 
 

@@ -117,6 +117,8 @@ class Lib:
         f("column_size", C.c_int, C.c_void_p, C.c_int, C.c_char_p)
         f("read", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
         f("write", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
+        f("get_state", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+        f("set_state", C.c_int, C.c_void_p, C.c_void_p, C.c_int)
         f("read_int", C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int)
         f("debug", C.c_int, C.c_void_p, C.c_int, C.c_int)
 
@@ -142,7 +144,7 @@ def load(prefix="mw_", path=None) -> Lib:
 
 EXPORTED_SYMBOLS = ["alloc_host", "free_host", "model_new", "model_free", "model_set_int", "model_set_real", "model_set_option", "create",
                     "add_model", "add_task", "set_envs", "finalize", "set_terminate_on_success", "destroy", "last_error", "num_envs", "obs_dim",
-                    "reset", "step", "step_device", "step_device_on", "wait_done", "reset_device", "policy_actions", "policy_rollout", "policy_rollout_fused", "upload_actions", "step_resident", "step_resident_fused", "step_resident_gather", "comm_unique_id", "comm_init", "comm_info", "gather_bookkeeping", "status", "launch_times", "set_option", "set_episode_phase", "set_goal_schedule", "goal_schedule_pos", "column_size", "read", "write", "read_int",
+                    "reset", "step", "step_device", "step_device_on", "wait_done", "reset_device", "policy_actions", "policy_rollout", "policy_rollout_fused", "upload_actions", "step_resident", "step_resident_fused", "step_resident_gather", "comm_unique_id", "comm_init", "comm_info", "gather_bookkeeping", "status", "launch_times", "set_option", "set_episode_phase", "set_goal_schedule", "goal_schedule_pos", "column_size", "read", "write", "get_state", "set_state", "read_int",
                     "debug"]
 
 
@@ -391,6 +393,21 @@ class Context:
     def write(self, env, what, values):
         a = np.ascontiguousarray(values, dtype=np.float64)
         self._check(self.lib.write(self.ptr, env, what.encode(), a.ctypes.data, a.size))
+
+    def get_state(self):
+        """mw_get_state -> list of N float64 arrays (the rows of read(e, "state")), one device round trip per model group"""
+        sizes = np.array([self._check(self.lib.column_size(self.ptr, e, b"state")) for e in range(self.N)])
+        buf = np.zeros((self.N, int(sizes.max())))
+        self._check(self.lib.get_state(self.ptr, buf.ctypes.data, buf.shape[1]))
+        return [buf[e, :sizes[e]].copy() for e in range(self.N)]
+
+    def set_state(self, rows):
+        """mw_set_state: rows[e] = the state vector of env e as get_state returned it"""
+        stride = max(len(r) for r in rows)
+        buf = np.zeros((self.N, stride))
+        for e, r in enumerate(rows):
+            buf[e, :len(r)] = r
+        self._check(self.lib.set_state(self.ptr, buf.ctypes.data, stride))
 
     def debug(self, what, n=0):
         code = what if isinstance(what, int) else {"forward": 0, "substeps": 1, "reset_data": 2, "kinematics": 3}[what]

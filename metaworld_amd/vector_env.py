@@ -109,7 +109,7 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
                  partially_observable=None, task_select="random", meta_batch_size=None, total_tasks_per_cls=None,
                  recurrent_info_in_obs=False, normalize_reward_in_recurrent_info=True, reward_function_version="v2",
                  reward_normalization_method=None, reward_alpha=0.001, normalize_observations=False, envs_list=None,
-                 lanes_per_block=None, raise_on_status=False, full_forward=False):
+                 lanes_per_block=None, raise_on_status=False, full_forward=False, num_tasks=None):
         """The keyword set of the reference's `_init_each_env` / `make_ml_envs` (metaworld/__init__.py:398-460, :516-618):
         `task_select` "random" = RandomTaskSelectWrapper, "pseudorandom" = PseudoRandomTaskSelectWrapper;
         `meta_batch_size` / `total_tasks_per_cls` = the ML split of each class's goals over sub-envs (`tasks[i::k]`);
@@ -141,6 +141,12 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
             raise NotImplementedError(f"no device-side task code yet for: {missing}")
         self.task_list = names
         ntask = len(names)
+        # OneHotWrapper(env, env_id, num_tasks) (metaworld/wrappers.py:14-32; make_mt_envs passes `num_tasks or <benchmark size>`,
+        # metaworld/__init__.py:434-436, :501): the one-hot may be WIDER than the benchmark; a narrower one fails like the
+        # reference's `self.one_hot[task_idx] = 1.0`
+        width = ntask if num_tasks is None else int(num_tasks)
+        if use_one_hot and width < ntask:
+            raise IndexError(f"index {width} is out of bounds for axis 0 with size {width}")
         if meta_batch_size is not None:
             # _make_ml_envs_inner (metaworld/__init__.py:527-531): meta_batch_size sub-envs, meta_batch_size/ntask per class
             assert meta_batch_size % ntask == 0, "meta_batch_size must be divisible by envs_per_task"
@@ -169,7 +175,7 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
                              f"(got {getattr(self._lib, 'path', self._lib)})")
         self.ctx = native.Context(self._lib, precision=1 if precision in ("fp64", 1) else 0, device_id=device_id,
                                   rank=rank, world_size=world_size, max_episode_steps=max_episode_steps or 500,
-                                  terminate_on_success=terminate_on_success, one_hot=use_one_hot, num_tasks=ntask,
+                                  terminate_on_success=terminate_on_success, one_hot=use_one_hot, num_tasks=width,
                                   full_forward=full_forward)
         # env -> task (task-major contiguous blocks, like the reference's enumerate order)
         per, rem = divmod(self.num_envs, ntask)
@@ -246,7 +252,7 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
         lo = np.concatenate([[-0.525, 0.348, -0.0525, -1.0], np.full(14, -np.inf)] * 2 + [np.zeros(3)])
         hi = np.concatenate([[0.525, 1.025, 0.7, 1.0], np.full(14, np.inf)] * 2 + [np.zeros(3)])
         if use_one_hot:
-            lo, hi = np.concatenate([lo, np.zeros(ntask)]), np.concatenate([hi, np.ones(ntask)])
+            lo, hi = np.concatenate([lo, np.zeros(width)]), np.concatenate([hi, np.ones(width)])
         self.obs_dtype = np.float32 if use_one_hot else np.float64
         self._raw_dtype = self.obs_dtype
         self.recurrent_info_in_obs = bool(recurrent_info_in_obs)
@@ -548,34 +554,96 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
             self._ep_ret[:] = 0
             return tuple((obs[e], {}) for e in range(self.num_envs))
         if name == "get_checkpoint":
-            ck = dict(tasks={n: t.copy() for n, t in self.goal_tables.items()}, reset_count=self._reset_count.copy(),
-                      cur_goal=self._cur_goal.copy(), task_idx=self._task_idx.copy(), task_select=self.task_select,
-                      goal_lists=[l.copy() for l in self._goal_lists], seed=self.seed_value,
-                      sample_tasks_on_reset=self.sample_tasks_on_reset,
-                      normalizers=dict(rew_mean=self._rew_mean.copy(), rew_var=self._rew_var.copy(), disc_ret=self._disc_ret.copy(),
-                                       ret_rms=(self._ret_rms.mean.copy(), self._ret_rms.var.copy(), self._ret_rms.count.copy()),
-                                       obs_rms=(self._obs_rms.mean.copy(), self._obs_rms.var.copy(), self._obs_rms.count.copy())
-                                       if self.normalize_observations else None),
-                      state=[self.ctx.read(e, "state") for e in range(self.num_envs)])
-            return (ck,) + (None,) * (self.num_envs - 1)
+            return self._get_checkpoint()
         if name == "load_checkpoint":
-            ck = args[0][0] if isinstance(args[0], (list, tuple)) else args[0]
-            assert all(np.array_equal(ck["tasks"][n], t) for n, t in self.goal_tables.items()), "checkpoint of another benchmark/seed"
-            assert ck["task_select"] == self.task_select and ck["seed"] == self.seed_value
-            self._reset_count[:] = ck["reset_count"]; self._cur_goal[:] = ck["cur_goal"]; self._task_idx[:] = ck["task_idx"]
-            self._goal_lists = [l.copy() for l in ck["goal_lists"]]
-            self._lists_are_ranges = all(np.array_equal(l, np.arange(len(l))) for l in self._goal_lists)
-            self.sample_tasks_on_reset = ck["sample_tasks_on_reset"]
-            nz = ck["normalizers"]
-            self._rew_mean, self._rew_var, self._disc_ret = nz["rew_mean"].copy(), nz["rew_var"].copy(), nz["disc_ret"].copy()
-            self._ret_rms.mean, self._ret_rms.var, self._ret_rms.count = (x.copy() for x in nz["ret_rms"])
-            if self.normalize_observations:
-                self._obs_rms.mean, self._obs_rms.var, self._obs_rms.count = (x.copy() for x in nz["obs_rms"])
-            for e in range(self.num_envs):
-                self.ctx.write(e, "state", ck["state"][e])
-            self._look_ahead(np.ones(self.num_envs, dtype=bool))
+            self._load_checkpoint(args[0])
             return (None,) * self.num_envs
         return self.get_attr(name)
+
+    # ---- checkpoints in the reference's shape (CheckpointWrapper, metaworld/wrappers.py:275-301) ----
+    def _env_id(self, e):
+        """`f"{env_cls}_{env_id}"` (metaworld/__init__.py:455): the class as the reference prints it, then the sub-env's index"""
+        name = self.env_task_names[e]
+        cls = T.TASK_CONST[name]["cls"]
+        return f"<class 'metaworld.envs.sawyer_{name[:-3].replace('-', '_')}_v3.{cls}'>_{e}"
+
+    def _selection_rng_state(self, e):
+        """bit-generator state of sub-env e's task-selection stream after the draws it has made (RandomTaskSelectWrapper keeps
+        `self.np_random.bit_generator.state`, wrappers.py:128): replayed from the seed, cached per (list length, seed, draws)"""
+        key = (len(self._goal_lists[e]), self._env_seed[e], int(self._reset_count[e]))
+        if key not in self._rng_state_cache:
+            gen = np.random.Generator(np.random.PCG64(np.random.SeedSequence(key[1])))
+            for _ in range(key[2]):
+                gen.choice(key[0])
+            self._rng_state_cache[key] = gen.bit_generator.state
+        return self._rng_state_cache[key]
+
+    def _get_checkpoint(self):
+        """`envs.call("get_checkpoint")`: one `(env_id, ckpt)` pair per sub-env like the reference's CheckpointWrapper; `ckpt` has the
+        keys of (Pseudo)RandomTaskSelectWrapper.get_checkpoint (wrappers.py:125-131, :187-193) -- tasks (env_name + base64 of the
+        pickled task data), rng_state / current_task_idx, sample_tasks_on_reset, env_rng_state (empty: the batched env has no
+        per-env gymnasium space generators) -- plus, under "mwgpu", what the reference does not checkpoint: the simulation state."""
+        import base64
+        import pickle
+        self._rng_state_cache = getattr(self, "_rng_state_cache", {})
+        states = self.ctx.get_state()
+        out = []
+        for e in range(self.num_envs):
+            name = self.env_task_names[e]
+            tasks = [{"env_name": name, "data": base64.b64encode(pickle.dumps(
+                {"rand_vec": np.asarray(self.goal_tables[name][g]), "partially_observable": self.partially_observable})).decode("ascii")}
+                for g in self._goal_lists[e]]
+            ck = {"tasks": tasks, "sample_tasks_on_reset": self.sample_tasks_on_reset, "env_rng_state": {}}
+            if self.task_select == "random":
+                ck["rng_state"] = self._selection_rng_state(e)
+            else:
+                ck["current_task_idx"] = int(self._task_idx[e])
+            ck["mwgpu"] = dict(reset_count=int(self._reset_count[e]), cur_goal=int(self._cur_goal[e]), goal_list=np.asarray(self._goal_lists[e]).copy(),
+                               seed=self._env_seed[e], task_select=self.task_select, state=states[e],
+                               normalizers=dict(rew_mean=float(self._rew_mean[e]), rew_var=float(self._rew_var[e]), disc_ret=float(self._disc_ret[e]),
+                                                ep_ret=float(self._ep_ret[e]),
+                                                ret_rms=(self._ret_rms.mean[e].copy(), self._ret_rms.var[e].copy(), self._ret_rms.count[e].copy()),
+                                                obs_rms=(self._obs_rms.mean[e].copy(), self._obs_rms.var[e].copy(), self._obs_rms.count[e].copy())
+                                                if self.normalize_observations else None))
+            out.append((self._env_id(e), ck))
+        return tuple(out)
+
+    def _load_checkpoint(self, ckpts):
+        """`envs.call("load_checkpoint", ckpts)`: every sub-env looks its own id up in the list and raises the reference's ValueError
+        when it is missing (wrappers.py:290-301)"""
+        if isinstance(ckpts, tuple) and len(ckpts) == 2 and isinstance(ckpts[0], str):
+            ckpts = [ckpts]
+        by_id = {}
+        for env_id, ck in ckpts:
+            by_id.setdefault(env_id, ck)
+        rows = []
+        for e in range(self.num_envs):
+            eid = self._env_id(e)
+            if eid not in by_id:
+                raise ValueError(f"Could not load checkpoint, no checkpoint found with id {eid}. Checkpoint IDs: ", [i for i, _ in ckpts])
+            ck = by_id[eid]
+            for key in ("tasks", "sample_tasks_on_reset", "env_rng_state"):
+                assert key in ck
+            assert ("rng_state" if self.task_select == "random" else "current_task_idx") in ck
+            x = ck.get("mwgpu")
+            if x is None:
+                raise ValueError("checkpoint without the 'mwgpu' section: written by the reference's wrappers, which do not store the simulation state")
+            assert x["task_select"] == self.task_select and x["seed"] == self._env_seed[e], "checkpoint of another seed / selection rule"
+            assert [t["env_name"] for t in ck["tasks"]] == [self.env_task_names[e]] * len(x["goal_list"]), "checkpoint of another benchmark"
+            self._reset_count[e], self._cur_goal[e] = x["reset_count"], x["cur_goal"]
+            self._goal_lists[e] = np.asarray(x["goal_list"]).copy()
+            if self.task_select != "random":
+                self._task_idx[e] = ck["current_task_idx"]
+            nz = x["normalizers"]
+            self._rew_mean[e], self._rew_var[e], self._disc_ret[e], self._ep_ret[e] = nz["rew_mean"], nz["rew_var"], nz["disc_ret"], nz["ep_ret"]
+            self._ret_rms.mean[e], self._ret_rms.var[e], self._ret_rms.count[e] = nz["ret_rms"]
+            if self.normalize_observations and nz["obs_rms"] is not None:
+                self._obs_rms.mean[e], self._obs_rms.var[e], self._obs_rms.count[e] = nz["obs_rms"]
+            rows.append(np.asarray(x["state"], dtype=np.float64))
+        self.sample_tasks_on_reset = bool(by_id[self._env_id(0)]["sample_tasks_on_reset"])
+        self._lists_are_ranges = all(np.array_equal(l, np.arange(len(l))) for l in self._goal_lists)
+        self.ctx.set_state(rows)
+        self._look_ahead(np.ones(self.num_envs, dtype=bool))
 
     # ---- run-time status (no reference counterpart; SURVEY.md 5 "failure detection") ----
     def status(self, clear=False):

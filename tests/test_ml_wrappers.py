@@ -132,7 +132,7 @@ def test_normalizers_and_checkpoint(hostsim):
     acts = rng.uniform(-1, 1, (12, 3, 4)).astype(np.float32)
     for t in range(6):
         obs, rew, te, tr, info = env.step(acts[t])
-    ck = env.call("get_checkpoint")[0]
+    ck = env.call("get_checkpoint")          # one (env_id, ckpt) pair per sub-env, like the reference's CheckpointWrapper
     tail = [env.step(acts[t]) for t in range(6, 12)]
     env2 = mk.make_mt_envs("reach-v3", **kw)
     env2.reset()
