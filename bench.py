@@ -493,7 +493,9 @@ def main(argv=None):
                     "valu_active_frac_of_wave_cycles": pj.get("valu_active_frac"),
                     "lane_utilisation": pj.get("lane_utilisation"), "wave_slot_occupancy": pj.get("wave_slot_occupancy"),
                     "wait_frac": pj.get("wait_frac"),
-                    "note": "frac = (f64 VALU wave-instructions x 4 + the other VALU wave-instructions x 2 cycles, MI355X_MICROARCH.md) / "
+                    "mfma": pj.get("mfma"),
+                    "note": "mfma = the matrix-core counters of the same profile (Newton direction: v_mfma_f32_16x16x1_4b_f32; utilisation = "
+                            "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles)); frac = (f64 VALU wave-instructions x 4 + the other VALU wave-instructions x 2 cycles, MI355X_MICROARCH.md) / "
                             "(1024 SIMDs x this run's kernel time x 2.4 GHz); counts from the PMC pass of the same sources (SQ_INSTS_VALU, "
                             "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64); valu_active_frac = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; "
                             "lane_utilisation = envs / (waves x 64); wave_slot_occupancy = SQ_WAVE_CYCLES x 4 / (1024 SIMDs x kernel cycles); "

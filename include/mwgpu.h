@@ -35,6 +35,8 @@ typedef struct mw_config {
     int32_t full_forward;          /* 0 (product): the final mj_forward of a step (sawyer_xyz_env.py:620) stops after the kinematics unless the
                                     * task's reward reads contact forces (touching_object, :401-440) -- same observations, rewards and state;
                                     * 1: always complete, for callers that read ncon / nefc / efc_force after a step (engine-level tests) */
+    int32_t reward_version;        /* SawyerXYZEnv(reward_function_version=...), every sawyer_*_v3.py compute_reward: 1 = the "v1" branches,
+                                    * 0 / 2 = "v2" (the reference's default) */
 } mw_config;
 
 /* Per-task constants: what the reference keeps in each SawyerXYZEnv subclass

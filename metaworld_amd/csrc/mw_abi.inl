@@ -43,7 +43,7 @@ int MW_API(create)(const mw_config* cfg, mw_ctx** out) {
     mw_ctx* c = new mw_ctx();
     c->cfg.precision = cfg->precision; c->cfg.device_id = cfg->device_id; c->cfg.rank = cfg->rank; c->cfg.world_size = cfg->world_size;
     c->cfg.max_episode_steps = cfg->max_episode_steps; c->cfg.terminate_on_success = cfg->terminate_on_success;
-    c->cfg.one_hot = cfg->one_hot; c->cfg.num_tasks = cfg->num_tasks; c->cfg.full_forward = cfg->full_forward;
+    c->cfg.one_hot = cfg->one_hot; c->cfg.num_tasks = cfg->num_tasks; c->cfg.full_forward = cfg->full_forward; c->cfg.reward_version = cfg->reward_version;
     *out = c;
     MW_TRY(c, Backend::init(cfg->device_id));
 }

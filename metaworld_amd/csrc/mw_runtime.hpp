@@ -218,6 +218,7 @@ struct World {
     const int* snap_stride;   // per task: elements per snapshot (= nstate + 39)
     const int* snap_ngoal;    // per task: number of goals (snapshots)
     int max_episode_steps, terminate_on_success, one_hot, num_tasks, full_forward;
+    int reward_v1;            // 1 = the reference's reward_function_version="v1" branches (mw_tasks_v1.hpp) for every task of the context
     IOPtrs io;
 };
 
@@ -288,7 +289,7 @@ MW_HD void lane_reset_full(const World<T>& w, int block, int thread, Scratchpad 
     const int task = (int)TK(e, TK_TASK);
     const TaskDesc<T>& td = w.tasks[task];
     T obs[39];
-    env_reset(e, td, obs);
+    env_reset(e, td, obs, w.reward_v1 != 0);
     if (w.io.obs && e.sub == 0) write_obs(w, td, w.io.obs + (size_t)gid * w.io.D, obs, (int)td.c[15]);
 }
 
@@ -410,7 +411,7 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     Info info;
     for (int k = 0; k < 4; k++) act[k] = (T)w.io.act[(size_t)gid * 4 + k];
     e.I(e.lay().icount + 3) = 0; e.I(e.lay().icount + IC_SOLVER_STALL) = 0;
-    env_step(e, td, act, obs, &reward, &success, &info, w.full_forward != 0);
+    env_step(e, td, act, obs, &reward, &success, &info, w.full_forward != 0, w.reward_v1 != 0);
     step_outputs(w, e, gid, task, td, obs, reward, success, info);
 }
 
@@ -444,6 +445,7 @@ struct Config {
     int device_id, rank, world_size;
     int max_episode_steps, terminate_on_success, one_hot, num_tasks;
     int full_forward;   // 1 = complete final mj_forward for every task (see env_step)
+    int reward_version; // 1 = v1 reward functions, anything else = v2 (mw_config.reward_version)
 };
 
 struct TaskSpec {      // precision-independent TaskDesc
@@ -603,7 +605,7 @@ class Context : public ContextBase {
         w.groups = d_groups_; w.ngroups = (int)groups_.size(); w.tasks = d_tasks_;
         w.snap = d_snap_; w.snap_off = d_snap_off_; w.snap_stride = d_snap_stride_; w.snap_ngoal = d_snap_ngoal_;
         w.max_episode_steps = cfg.max_episode_steps; w.terminate_on_success = cfg.terminate_on_success;
-        w.one_hot = cfg.one_hot; w.num_tasks = cfg.num_tasks; w.full_forward = cfg.full_forward;
+        w.one_hot = cfg.one_hot; w.num_tasks = cfg.num_tasks; w.full_forward = cfg.full_forward; w.reward_v1 = cfg.reward_version == 1;
         if (with_io) {
             w.io.act = d_act_; w.io.next_goal = d_next_goal_; w.io.obs = d_obs_; w.io.reward = d_reward_;
             w.io.terminated = d_flags_; w.io.truncated = d_flags_ + N_; w.io.success = d_flags_ + 2 * N_; w.io.done = d_flags_ + 3 * N_;

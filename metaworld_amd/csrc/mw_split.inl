@@ -265,11 +265,8 @@ MW_HD void split_finish(const World<T>& w, const Env<T> e, int gid, int task, co
     for (int k = 0; k < 4; k++) act[k] = (T)w.io.act[(size_t)gid * 4 + k];
     get_obs(e, td, obs);
     clip_obs(td, obs);
-#if defined(MW_REWARD_V1)
-    task_evaluate_v1(e, td, obs, act, &reward, &success, &info);
-#else
-    task_evaluate(e, td, obs, act, &reward, &success, &info);
-#endif
+    if (w.reward_v1) task_evaluate_v1(e, td, obs, act, &reward, &success, &info);
+    else task_evaluate(e, td, obs, act, &reward, &success, &info);
     step_outputs(w, e, gid, task, td, obs, reward, success, info);
 }
 

@@ -1261,27 +1261,23 @@ MW_HD void task_after_reset(const Env<T> e, const TaskDesc<T>& td, V3<T> persist
     if (!td.partially_observable) { obs39[36] = s.x; obs39[37] = s.y; obs39[38] = s.z; }
 }
 
-#if defined(MW_REWARD_V1)
 }  // namespace mw
-#include "mw_tasks_v1.hpp"   // reward_function_version = "v1": a separate build of the library (libmwgpu_v1.so), see the header
+#include "mw_tasks_v1.hpp"   // reward_function_version = "v1": selected per context at run time (mw_config.reward_version, World::reward_v1)
 namespace mw {
-#endif
 
 // =========================================================================== env-level reset / step
 // SawyerXYZEnv.reset (:664-682) second pass semantics: mj_resetData -> reset_model -> obs with prev := curr.
 // (The first reset_model pass only leaves model writes behind; they are functions of rand_vec and are
 //  re-applied by the second pass, see DESIGN.md "reset".)
 template <typename T>
-MW_HD void env_reset(const Env<T> e, const TaskDesc<T>& td, T* obs39) {
+MW_HD void env_reset(const Env<T> e, const TaskDesc<T>& td, T* obs39, bool reward_v1) {
     reset_data(e);
     TK(e, TK_PATHLEN) = 0; TK(e, TK_ELAPSED) = 0; TK(e, TK_EPRET) = 0; TK(e, TK_EPRET_LO) = 0; TK(e, TK_EPLEN) = 0; TK(e, TK_SUCCESS) = 0;
     for (int k = 0; k < 16; k++) TK(e, TK_EXTRA + k) = 0;
     const V3<T> persist = tk3(e, TK_PERSIST0);
     task_model_writes(e, td);
     task_reset_model(e, td);
-#if defined(MW_REWARD_V1)
-    task_reset_v1(e, td);
-#endif
+    if (reward_v1) task_reset_v1(e, td);          // (the per-env quantities the v1 branches keep on `self`: spare reals of the task block)
     get_obs(e, td, obs39);
     for (int k = 0; k < 18; k++) { obs39[18 + k] = obs39[k]; TK(e, TK_PREVOBS + k) = obs39[k]; }
     task_after_reset(e, td, persist, obs39);
@@ -1294,7 +1290,7 @@ MW_HD void env_reset(const Env<T> e, const TaskDesc<T>& td, T* obs39) {
 // after a step).  Same values either way: the two halves do not feed back into each other, and the next step's first
 // mj_step recomputes everything from (qpos, qvel, mocap, ctrl).  tests/test_lazy_forward.py holds the equivalence.
 template <typename T>
-MW_HD void env_step(const Env<T> e, const TaskDesc<T>& td, const T* act, T* obs39, T* reward, T* success, Info* info, bool full_forward) {
+MW_HD void env_step(const Env<T> e, const TaskDesc<T>& td, const T* act, T* obs39, T* reward, T* success, Info* info, bool full_forward, bool reward_v1) {
     // set_xyz_action: mocap += clip(a,-1,1)*0.01, clipped to the mocap box
     // (the reference multiplies the float32 action by action_scale in float32: numpy keeps float32 * python-float in float32)
     for (int k = 0; k < 3; k++) {
@@ -1314,11 +1310,8 @@ MW_HD void env_step(const Env<T> e, const TaskDesc<T>& td, const T* act, T* obs3
     if (mw_any(full_forward || task_touches(td.kind))) forward_dynamics(e);
     get_obs(e, td, obs39);
     clip_obs(td, obs39);
-#if defined(MW_REWARD_V1)
-    task_evaluate_v1(e, td, obs39, act, reward, success, info);
-#else
-    task_evaluate(e, td, obs39, act, reward, success, info);
-#endif
+    if (reward_v1) task_evaluate_v1(e, td, obs39, act, reward, success, info);          // (wave-uniform: one flag per context)
+    else task_evaluate(e, td, obs39, act, reward, success, info);
 }
 
 }  // namespace mw

@@ -1,8 +1,7 @@
 // mw_tasks_v1.hpp -- the reference's `reward_function_version="v1"` branches (the `else:` of every
 // metaworld/envs/sawyer_*_v3.py::compute_reward, with the success / info composition of its evaluate_state), one environment per
-// lane.  Compiled ONLY into the v1 build of the library (-DMW_REWARD_V1 -> metaworld_amd/libmwgpu_v1.so; the default library does
-// not contain a byte of it): a v1 context evaluates v1 rewards for every task.  Physics, observations, resets and wrappers are the
-// v2 build's.  The per-env quantities the v1 branches keep on `self` (maxDist, maxPullDist, heightTarget, pickCompleted, ...) live
+// lane.  Selected per CONTEXT at run time (mw_config.reward_version = 1 -> World::reward_v1; rounds 2-4 compiled it into a second
+// library, libmwgpu_v1.so): a v1 context evaluates v1 rewards for every task.  Physics, observations, resets and wrappers are shared.  The per-env quantities the v1 branches keep on `self` (maxDist, maxPullDist, heightTarget, pickCompleted, ...) live
 // in the spare reals of the task block (TK_V1 ...), are set by task_reset_v1 right after reset_model and so travel with the reset
 // snapshots.  Tasks without a restatement yet fall through to the v2 evaluation; metaworld_amd/tasks.py::V1_TASKS lists the ported
 // ones and the Python boundary refuses the others.

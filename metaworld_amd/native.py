@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmwgpu.so")
-LIB_PATH_V1 = os.path.join(os.path.dirname(LIB_PATH), "libmwgpu_v1.so")          # reward_function_version="v1" (csrc/mw_tasks_v1.hpp)
+LIB_PATH_V1 = LIB_PATH          # rounds 2-4 built the v1 reward functions into a second library; they are a run-time flag now (mw_config.reward_version)
 NPROBE = 16
 STATUS_WORDS = 8          # MW_STATUS_WORDS (include/mwgpu.h)
 
@@ -33,7 +33,7 @@ def source_hash():
 
 class MwConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("precision", "device_id", "rank", "world_size", "max_episode_steps",
-                                         "terminate_on_success", "one_hot", "num_tasks", "full_forward")]
+                                         "terminate_on_success", "one_hot", "num_tasks", "full_forward", "reward_version")]
 
 
 class MwTask(C.Structure):
@@ -165,10 +165,10 @@ class Context:
     """Thin object wrapper over mw_ctx."""
 
     def __init__(self, lib: Lib, precision=0, device_id=0, rank=0, world_size=1, max_episode_steps=500,
-                 terminate_on_success=False, one_hot=False, num_tasks=1, full_forward=False):
+                 terminate_on_success=False, one_hot=False, num_tasks=1, full_forward=False, reward_version=2):
         self.lib = lib
         cfg = MwConfig(int(precision), device_id, rank, world_size, max_episode_steps, int(terminate_on_success),
-                       int(one_hot), num_tasks, int(full_forward))
+                       int(one_hot), num_tasks, int(full_forward), int(reward_version))
         self.ptr = C.c_void_p()
         rc = lib.create(C.byref(cfg), C.byref(self.ptr))
         self._check(rc)

@@ -163,20 +163,17 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
         self.partially_observable = benchmark.startswith("ML") if partially_observable is None else bool(partially_observable)
         self.seed_value = seed
         if v1:
-            # the v1 reward functions live in their own build of the library (csrc/mw_tasks_v1.hpp, -DMW_REWARD_V1); tasks whose
+            # the v1 reward functions (csrc/mw_tasks_v1.hpp) are selected per context (mw_config.reward_version); tasks whose
             # v1 branch has no device restatement yet are refused here rather than silently evaluated with v2
             missing_v1 = [n for n in names if n not in T.V1_TASKS]
             if missing_v1:
                 raise NotImplementedError(f"reward_function_version='v1' has no device code yet for: {missing_v1}")
         self.reward_function_version = reward_function_version
-        self._lib = lib or (native.load("mw_", native.LIB_PATH_V1) if v1 else native.load())
-        if v1 != ("_v1" in os.path.basename(getattr(self._lib, "path", ""))):          # a library of the other flavour was handed in
-            raise ValueError(f"reward_function_version={reward_function_version!r} needs the {'v1' if v1 else 'v2'} build of the library "
-                             f"(got {getattr(self._lib, 'path', self._lib)})")
+        self._lib = lib or native.load()
         self.ctx = native.Context(self._lib, precision=1 if precision in ("fp64", 1) else 0, device_id=device_id,
                                   rank=rank, world_size=world_size, max_episode_steps=max_episode_steps or 500,
                                   terminate_on_success=terminate_on_success, one_hot=use_one_hot, num_tasks=width,
-                                  full_forward=full_forward)
+                                  full_forward=full_forward, reward_version=1 if v1 else 2)
         # env -> task (task-major contiguous blocks, like the reference's enumerate order)
         per, rem = divmod(self.num_envs, ntask)
         env_task_names = []

@@ -27,7 +27,7 @@ warnings.filterwarnings("ignore")
 INFO_KEYS = ["near_object", "grasp_success", "grasp_reward", "in_place_reward", "obj_to_target", "unscaled_reward"]
 
 
-def run_task(name, seed, episodes, steps, mode, rng, reward_version="v2"):
+def run_task(name, seed, episodes, steps, mode, rng, reward_version="v2", first_goal=0):
     import metaworld
     from metaworld.policies import ENV_POLICY_MAP
     mt1 = metaworld.MT1(name, seed=seed)
@@ -42,7 +42,7 @@ def run_task(name, seed, episodes, steps, mode, rng, reward_version="v2"):
                            "success", "info", "truncate", "qpos", "qvel", "mocap", "warm", "goal_idx")}
     d = env.data
     for ep in range(episodes):
-        gi = ep % len(mt1.train_tasks)
+        gi = (first_goal + ep) % len(mt1.train_tasks)
         env.set_task(mt1.train_tasks[gi])
         obs, _ = env.reset()
         out["goal_idx"].append(gi)
@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--mode", default="mixed", choices=["random", "policy", "mixed"])
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--first-goal", type=int, default=0, help="goal index of the first episode (episode k uses first_goal + k)")
+    ap.add_argument("--tag", default="", help="file name infix: trace_<tag>_<task>_seed<seed>.npz (e.g. policy200: --mode policy --steps 200 --episodes 1 --first-goal 7)")
     ap.add_argument("--reward-version", default="v2", choices=["v1", "v2"], help="v1: files are named trace_v1_<task>_seed<seed>.npz")
     args = ap.parse_args()
     from oracle import refshim
@@ -85,8 +87,8 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     for name in args.tasks:
         rng = np.random.default_rng(args.seed)
-        res = run_task(name, args.seed, args.episodes, args.steps, args.mode, rng, args.reward_version)
-        tag = "v1_" if args.reward_version == "v1" else ""
+        res = run_task(name, args.seed, args.episodes, args.steps, args.mode, rng, args.reward_version, args.first_goal)
+        tag = ("v1_" if args.reward_version == "v1" else "") + (args.tag + "_" if args.tag else "")
         path = os.path.join(args.out, f"trace_{tag}{name}_seed{args.seed}.npz")
         np.savez_compressed(path, **res)
         print(name, "->", path, f"({os.path.getsize(path) / 1024:.0f} KiB)", "success steps:", int(res["success"].sum()))

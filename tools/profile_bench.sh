@@ -18,6 +18,17 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   name=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --output-format csv -d "$out/pmc_$name" -- python $root/bench.py $args > "$out/pmc_$name.log" 2>&1
 done
+# matrix-core counters: whichever of the candidate names this rocprofv3 lists for gfx950, in one extra pass
+avail=$(rocprofv3 -L 2>/dev/null | grep -o -E 'SQ_[A-Z0-9_]*MFMA[A-Z0-9_]*' | sort -u | tr '\n' ' ')
+echo "MFMA counters listed by rocprofv3 -L: $avail" > "$out/mfma_counters_available.txt"
+mf=""
+for c in SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F64; do
+  echo " $avail " | grep -q " $c " && mf="$mf $c"
+done
+if [ -n "$mf" ]; then
+  rocprofv3 --pmc $mf SQ_BUSY_CU_CYCLES --output-format csv -d "$out/pmc_MFMA" -- python $root/bench.py $args > "$out/pmc_MFMA.log" 2>&1 || \
+  rocprofv3 --pmc $mf --output-format csv -d "$out/pmc_MFMA" -- python $root/bench.py $args > "$out/pmc_MFMA.log" 2>&1
+fi
 cd $root
 find "$out" -name "*.db" -delete
 stats=$(find "$out/kt" -name "*kernel_stats.csv" | head -1)

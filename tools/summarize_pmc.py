@@ -55,6 +55,9 @@ if args.json and mean:
            "valu_wave_instr_per_launch": mean.get("SQ_INSTS_VALU", 0.0), "salu_wave_instr_per_launch": mean.get("SQ_INSTS_SALU", 0.0),
            "vmem_rd_wave_instr_per_launch": mean.get("SQ_INSTS_VMEM_RD", 0.0), "vmem_wr_wave_instr_per_launch": mean.get("SQ_INSTS_VMEM_WR", 0.0),
            "lds_wave_instr_per_launch": mean.get("SQ_INSTS_LDS", 0.0), "waves_per_launch": waves,
+           # matrix cores (the wave-cooperative Newton direction, v_mfma_f32_16x16x1_4b_f32): instructions / MOPS / busy cycles per launch
+           # from whichever counters this rocprofv3 offers on gfx950; utilisation = busy cycles / (1024 SIMDs x kernel cycles)
+           "mfma": {k: mean[k] for k in sorted(mean) if "MFMA" in k} or None,
            "wait_frac": mean.get("SQ_WAIT_ANY", 0.0) / mean["SQ_WAVE_CYCLES"] if mean.get("SQ_WAVE_CYCLES") else None,
            "tcc_hit_rate": mean.get("TCC_HIT_sum", 0.0) / (mean.get("TCC_HIT_sum", 0.0) + mean.get("TCC_MISS_sum", 1.0)) if mean.get("TCC_HIT_sum") else None,
            # envs x sub-lanes all do useful (distinct or replicated-by-design) work only where the lanes hold an env: lanes / (waves x 64)
@@ -65,6 +68,8 @@ if args.json and mean:
         # distinct environments per lane slot: 1 = one env per lane; below that the other lanes are sub-lanes of the same env
         # (they split the row / pair sweeps and replicate the serial parts)
         out["lane_utilisation"] = args.envs / (64.0 * waves)
+    if out["mfma"] and args.kernel_ms and mean.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        out["mfma"]["utilisation"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * args.kernel_ms * 1e-3 * 2.4e9)
     if mean.get("SQ_WAVE_CYCLES") and args.kernel_ms:
         cycles = args.kernel_ms * 1e-3 * 2.4e9
         out["wave_slot_occupancy"] = mean["SQ_WAVE_CYCLES"] * 4 / (1024 * cycles)      # SQ_WAVE_CYCLES counts quad-cycles
