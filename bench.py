@@ -235,7 +235,8 @@ def launch_stats(env):
     t = np.asarray(env.ctx.launch_times(), dtype=np.float64)
     if not len(t):
         return None
-    return {"min": float(t.min()), "median": float(np.median(t)), "max": float(t.max()), "mean": float(t.mean()), "launches": int(len(t))}
+    return {"min": float(t.min()), "median": float(np.median(t)), "max": float(t.max()), "mean": float(t.mean()), "launches": int(len(t)),
+            "argmax": int(t.argmax()), "first": [float(x) for x in t[:3]]}
 
 
 def extra_configs(args, lib, local_rank):
@@ -335,15 +336,19 @@ def boundary_rates(args, lib, local_rank, steps=40):
             env.step(acts[t % 8])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        stamps = []
         for t in range(steps):
             o, r, te, tr, info = env.step(acts[t % 8])
+            stamps.append(time.perf_counter())          # (host time at which step t returned; the tensor path's outputs are stream-ordered)
         if key == "torch_device":
             float(r.sum().item())          # the learner reads what it got
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         st = env.ctx.status(clear=True)
         env.close()
-        out[key] = {"value": N * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "status_flags": st["flags"]}
+        per = np.diff(np.array([t0] + stamps)) * 1e3
+        out[key] = {"value": N * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "median_ms_per_step": float(np.median(per)),
+                    "max_ms_per_step": float(per.max()), "steps": steps, "status_flags": st["flags"]}
     out["note"] = ("the same batch through VectorEnv.step instead of the resident loop: host_numpy = numpy actions in, every output + infos dict "
                    "on the host (MetaWorldGpuVectorEnv); torch_device = CUDA tensors in / out (MetaWorldTorchVectorEnv); `value` itself is the resident loop")
     return out

@@ -689,7 +689,12 @@ public:
         std::map<int, int> lpb_of;
         {
             const char* ov = getenv("MW_LANES_PER_BLOCK");
-            const int budget = 4 * Backend::compute_units();
+            // MW_OVERSUBSCRIBE = f > 1 (experiment, round 5): allow f x more workgroups than SIMDs.  The launch lasts as long as its slowest
+            // wave while the mean wave is busy ~40 % of it; with more, smaller workgroups (fewer environments each = shorter) than wave
+            // slots the hardware dispatcher hands the next workgroup to whichever SIMD frees up first, and with the groups ORDERED by
+            // predicted time (longest first: list scheduling) the short ones fill the tail.
+            const double oversub = getenv("MW_OVERSUBSCRIBE") ? atof(getenv("MW_OVERSUBSCRIBE")) : 1.0;
+            const int budget = (int)(4 * Backend::compute_units() * (oversub > 1.0 ? oversub : 1.0));
             auto blocks = [&]() { int nb = 0; for (auto& kv : by_model) nb += ((int)kv.second.size() + lpb_of[kv.first] - 1) / lpb_of[kv.first]; return nb; };
             auto predicted = [&](int model, int l) {
                 const ModelData& md = *models[model];
@@ -782,8 +787,21 @@ public:
             for (auto& kv : hist) fprintf(stderr, " %d:%d", kv.first, kv.second);
             fprintf(stderr, "  (%d workgroups)\n", nb);
         }
+        // block order = group order: by model index, or (MW_OVERSUBSCRIBE > 1) by predicted workgroup time, longest first
+        std::vector<std::pair<int, std::vector<int>>> ordered(by_model.begin(), by_model.end());
+        if (getenv("MW_OVERSUBSCRIBE") && atof(getenv("MW_OVERSUBSCRIBE")) > 1.0) {
+            auto weight = [&](int model) {
+                const ModelData& md = *models[model];
+                double t4 = md.step_ms_lpb4, t8 = md.step_ms_lpb8;
+                if (!(t4 > 0 && t8 >= t4)) { t4 = 1.0 + md.sz.maxefc / 150.0; t8 = 1.3 * t4; }
+                const int l = lpb_of[model];
+                const double f = l >= 4 ? (l - 4) / 4.0 * (l > 8 ? 0.93 : 1.0) : (l == 2 ? -0.4 : -0.55);
+                return t4 + (t8 - t4) * f;
+            };
+            std::stable_sort(ordered.begin(), ordered.end(), [&](const auto& a, const auto& b) { return weight(a.first) > weight(b.first); });
+        }
         int gi = 0, blk = 0, env0 = 0;
-        for (auto& kv : by_model) {
+        for (auto& kv : ordered) {
             Group& g = groups_[gi];
             make_group(g, kv.first, kv.second, lpb_of[kv.first]);
             g.block0 = blk;

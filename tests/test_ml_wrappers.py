@@ -106,8 +106,11 @@ def test_factories_and_errors(hostsim):
         mk.make_ml_envs("ML10", split="test", meta_batch_size=12, lib=hostsim)
     with pytest.raises(AssertionError):          # 50 goals over 4 sub-envs per class: uneven (metaworld/__init__.py:540-542)
         mk.make_ml_envs("ML10", split="test", meta_batch_size=20, lib=hostsim)
-    with pytest.raises(ValueError):          # v1 rewards live in the v1 build of the library (tests/test_v1_rewards.py), not in this one
-        mk.make_mt_envs("reach-v3", reward_function_version="v1", lib=hostsim)
+    v1 = mk.make_mt_envs("reach-v3", reward_function_version="v1", lib=hostsim)          # one library since round 5: v1 is a run-time flag (tests/test_v1_rewards.py)
+    assert v1.reward_function_version == "v1"
+    v1.close()
+    with pytest.raises(ValueError):
+        mk.make_mt_envs("reach-v3", reward_function_version="v3", lib=hostsim)
     with pytest.raises(NotImplementedError):
         mk.make_mt_envs("MT10", autoreset_mode="NextStep", lib=hostsim)
     env = mk.make_ml_envs_test("ML10", seed=3, meta_batch_size=20, total_tasks_per_cls=40, lib=hostsim)

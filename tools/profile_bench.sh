@@ -8,7 +8,7 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
-args="--no-cpu-baseline --no-extra-precision $*"
+args="--no-cpu-baseline --no-extra-precision --no-configs $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python $root/bench.py $args > "$out/kt.log" 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" \
