@@ -502,7 +502,11 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
             self._episode_start[done] = now
             self._ep_ret[done] = 0
             self._begin_episodes(done)          # the auto-reset the kernel just did used _next_goal == this selection
-        return obs.astype(self.obs_dtype, copy=True), rew, term_b, trunc_b, infos
+        # (obs is already a fresh array of this step -- the astype / concatenate above made it -- unless dtypes matched and it is still a
+        #  view of the context's pinned output buffer, which the next step overwrites)
+        if obs.dtype != self.obs_dtype or obs.base is not None or obs is self.ctx.obs:
+            obs = obs.astype(self.obs_dtype, copy=True)
+        return obs, rew, term_b, trunc_b, infos
 
     def get_attr(self, name):
         if name == "task_name":

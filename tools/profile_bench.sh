@@ -37,14 +37,14 @@ kms=$(python - "$out/kernel_stats.csv" <<'PY'
 import csv, sys
 try:
     for r in csv.DictReader(open(sys.argv[1])):
-        if "step_device_only" in r["Name"]:
+        if "launch_step" in r["Name"]:
             print(float(r["AverageNs"]) / 1e6); break
 except Exception:
     print(0)
 PY
 )
 prec=$(echo "$args" | grep -q "fp32" && echo fp32 || echo fp64)
-python tools/summarize_pmc.py "$out/pmc_*/**/*counter_collection.csv" --kernel step_device_only --json "$out/pmc.json" \
+python tools/summarize_pmc.py "$out/pmc_*/**/*counter_collection.csv" --kernel launch_step --json "$out/pmc.json" \
   --workload "MT50 sync-vector, 4096 envs/GPU, $prec, random actions" --kernel-ms "$kms" > "$out/pmc_summary.txt" 2>&1
 grep -h '^{' "$out/kt.log" | tail -1 > "$out/bench_line_under_kernel_trace.json"
 # keep the summaries only (gpurun copies at most 64 MiB back; the raw kernel trace + counter CSVs are ~40 MB per run)

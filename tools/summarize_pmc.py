@@ -16,7 +16,7 @@ from metaworld_amd import native  # noqa: E402  (source_hash: which sources the 
 
 ap = argparse.ArgumentParser()
 ap.add_argument("pattern", nargs="?", default="gpurun_out/pmc_*/**/*counter_collection.csv")
-ap.add_argument("--kernel", default="step_device_only")
+ap.add_argument("--kernel", default="launch_step")
 ap.add_argument("--json")
 ap.add_argument("--workload", default="")
 ap.add_argument("--envs", type=int, default=4096)
