@@ -98,6 +98,12 @@ def host_cores():
     return aff, quota, os.cpu_count() or 1
 
 
+def usable_cores():
+    """the cores this process can really use at once: the affinity mask capped by the cgroup CPU quota"""
+    aff, quota, _ = host_cores()
+    return max(1, min(aff, int(quota) if quota and quota >= 1 else aff))
+
+
 def _full_step_port(task_names, seconds):
     """The WHOLE step (physics + observation + reward + wrappers, the product's own lane programs compiled for the host,
     tests/host_harness.cpp, OpenMP over envs) on all host cores: the stand-in for the reference's Python obs / reward layer,
@@ -107,8 +113,10 @@ def _full_step_port(task_names, seconds):
         return None
     from metaworld_amd import native
     from metaworld_amd.vector_env import MetaWorldGpuVectorEnv
+    cores = usable_cores()
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))          # (read when the OpenMP runtime of the harness starts: one thread per usable core)
     lib = native.load("mwh_", so)
-    n = 4 * host_cores()[0]
+    n = 4 * cores
     n = max(n, len(task_names))
     old_nsub = os.environ.get("MW_NSUB")
     os.environ["MW_NSUB"] = "1"          # (host harness knob: no emulated sub-lanes -- one plain lane program per env and core)
@@ -127,7 +135,7 @@ def _full_step_port(task_names, seconds):
         del os.environ["MW_NSUB"]
     else:
         os.environ["MW_NSUB"] = old_nsub
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": host_cores()[0],
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores,
             "sample": f"{n} envs x {steps} full steps (physics + obs + reward + wrappers, host build of the lane programs, OpenMP) in {dt:.1f}s"}
 
 
@@ -140,7 +148,7 @@ def cpu_baseline(task_names, seconds=10.0):
     mjlite.build(fast=True)          # (once, before the workers race for it)
     n1, dt1 = _oracle_worker(task_names, seconds, 0)
     aff, quota, ncpu = host_cores()
-    cores = max(1, min(aff, int(quota) if quota and quota >= 1 else aff))          # one worker per core this process may really use
+    cores = usable_cores()          # one worker per core this process may really use
     with mp.get_context("spawn").Pool(cores) as pool:
         res = pool.starmap(_oracle_worker, [(task_names, seconds, 1 + r) for r in range(cores)])
     rate_all = sum(n / dt for n, dt in res)
