@@ -39,7 +39,12 @@ def test_gpu_reach_matches_reference_trace_fp32(gpulib):
     G = golden("trace_reach-v3_seed42.npz")
     env = make_env(gpulib, n=len(G["goal_idx"]), precision="fp32")
     r = replay_trace(env, G, sync=True)
-    assert r["obs"] < 2e-3 and r["reward"] < 1e-4 and r["success_mismatch"] == 0, r
+    # BASELINE config 2 (MT1 reach-v3, fp32, contact-free path) at north_star's tolerance: observations within 1e-5 abs in SINGLE precision
+    # (measured 1.0e-6 on the host build); the reward is a number of magnitude 10 computed in float32 -- 1.6e-5 abs = 1.6e-6 relative = 17 ulp
+    # of float32 at 10 -- and is held to 5e-5 abs (rounds 1-4 asserted 2e-3 / 1e-4 here)
+    assert r["obs"] < 1e-5 and r["reward"] < 5e-5 and r["success_mismatch"] == 0, r
+    r = replay_trace(env, G, sync=False)          # ... and free-running over the 60 steps of the trace (no contacts: no amplification)
+    assert r["obs"] < 1e-5 and r["reward"] < 1e-4 and r["success_mismatch"] == 0, r
     env.close()
 
 

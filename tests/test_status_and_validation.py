@@ -126,3 +126,47 @@ def test_registration_under_the_reference_ids(hostsim):
         assert bad in gym.envs.registration.registry
     with pytest.raises(ValueError, match="Invalid MT env name"):          # metaworld/__init__.py:486-488
         mk.make_mt_envs("MT7")
+
+
+def test_round5_abi_entry_points_on_the_host_build(hostsim):
+    """mw_status with the caller's word count, mw_launch_times, mw_set_option, mw_get_state / mw_set_state, mw_alloc_host,
+    mw_step_device_on / mw_wait_done (the host harness runs them synchronously)"""
+    import ctypes as C
+    env = make_env(hostsim, "door-open-v3", n=3, precision="fp64")
+    ctx = env.ctx
+    ctx.reset(np.array([0, 1, 2]))
+    # status: the caller says how many words it has room for -- fewer than the library keeps, or more (zero-filled)
+    for n in (3, 8, 12):
+        out = np.full(n, -7, dtype=np.int32)
+        assert hostsim.status(ctx.ptr, out.ctypes.data, n, 0) == 0 and (out[:min(n, 8)] == 0).all() and (out[8:] == 0).all()
+    assert hostsim.status(ctx.ptr, None, 8, 0) < 0
+    # run-time options: unknown names are refused
+    ctx.set_option("split_collision", 1); ctx.set_option("split_collision", 0)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        ctx.set_option("no_such_option", 1)
+    # per-launch times of the resident loop
+    ctx.upload_actions(np.zeros((2, 3, 4), dtype=np.float32))
+    ctx.step_resident(5)
+    t = ctx.launch_times()
+    assert t.shape == (5,) and (t > 0).all()
+    # the whole batch's persistent state in one call = the per-env reads, and it round-trips
+    rows = ctx.get_state()
+    assert all(np.array_equal(rows[e], ctx.read(e, "state")) for e in range(3))
+    a = np.random.default_rng(0).uniform(-1, 1, (3, 4)).astype(np.float32)
+    o1 = ctx.step(a)[0].copy()
+    ctx.set_state(rows)
+    assert np.array_equal(ctx.step(a)[0], o1)
+    # page-locked allocation (plain malloc in the harness): usable memory, freed without complaint
+    p = hostsim.alloc_host(1024)
+    assert p
+    C.memset(p, 1, 1024)
+    hostsim.free_host(p)
+    # the stream-ordered device step + the pinned done row
+    import torch
+    from metaworld_amd.native import MwDeviceOut
+    act = torch.zeros((3, 4), dtype=torch.float32)
+    goal = torch.zeros(3, dtype=torch.int32)
+    ctx.step_device_on(act.data_ptr(), goal.data_ptr(), MwDeviceOut(), None)
+    done = ctx.wait_done()
+    assert done.shape == (3,) and done.dtype == np.uint8 and not done.any()
+    env.close()
