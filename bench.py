@@ -116,7 +116,7 @@ def _full_step_port(task_names, seconds):
     cores = usable_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))          # (read when the OpenMP runtime of the harness starts: one thread per usable core)
     lib = native.load("mwh_", so)
-    n = 4 * cores
+    n = 32 * cores          # (enough envs per OpenMP thread that the per-step fork / join does not dominate)
     n = max(n, len(task_names))
     old_nsub = os.environ.get("MW_NSUB")
     os.environ["MW_NSUB"] = "1"          # (host harness knob: no emulated sub-lanes -- one plain lane program per env and core)
@@ -341,7 +341,9 @@ def boundary_rates(args, lib, local_rank, steps=40):
         if key == "torch_device":
             acts = torch.from_numpy(acts).to(env.device)
         for t in range(3):
-            env.step(acts[t % 8])
+            o, r, te, tr, info = env.step(acts[t % 8])
+        if key == "torch_device":
+            float(r.sum().item())          # (untimed: the first reduction loads its kernel, ~20 ms once per process)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         stamps = []
@@ -357,6 +359,8 @@ def boundary_rates(args, lib, local_rank, steps=40):
         per = np.diff(np.array([t0] + stamps)) * 1e3
         out[key] = {"value": N * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "median_ms_per_step": float(np.median(per)),
                     "max_ms_per_step": float(per.max()), "steps": steps, "status_flags": st["flags"]}
+        if os.environ.get("MW_BENCH_PER_STEP"):          # diagnosis: the host time of every step
+            out[key]["per_step_ms"] = [round(float(x), 2) for x in per]
     out["note"] = ("the same batch through VectorEnv.step instead of the resident loop: host_numpy = numpy actions in, every output + infos dict "
                    "on the host (MetaWorldGpuVectorEnv); torch_device = CUDA tensors in / out (MetaWorldTorchVectorEnv); `value` itself is the resident loop")
     return out
