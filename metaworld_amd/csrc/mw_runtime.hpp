@@ -689,11 +689,16 @@ public:
         std::map<int, int> lpb_of;
         {
             const char* ov = getenv("MW_LANES_PER_BLOCK");
-            // MW_OVERSUBSCRIBE = f > 1 (experiment, round 5): allow f x more workgroups than SIMDs.  The launch lasts as long as its slowest
-            // wave while the mean wave is busy ~40 % of it; with more, smaller workgroups (fewer environments each = shorter) than wave
-            // slots the hardware dispatcher hands the next workgroup to whichever SIMD frees up first, and with the groups ORDERED by
-            // predicted time (longest first: list scheduling) the short ones fill the tail.
-            const double oversub = getenv("MW_OVERSUBSCRIBE") ? atof(getenv("MW_OVERSUBSCRIBE")) : 1.0;
+            // MILD OVERSUBSCRIPTION (round 5): the budget is 1.2 x the SIMDs (MW_OVERSUBSCRIBE = f overrides; 1 = rounds 1-4: one workgroup
+            // per SIMD at most).  The launch lasts as long as its slowest wave while the mean wave is busy ~40 % of it; with a few more,
+            // smaller workgroups than wave slots the dispatcher hands the next workgroup to whichever SIMD frees up first, and with the
+            // groups ORDERED by predicted time (longest first: list scheduling, below) the short ones fill the tail.  Measured at MT50 @
+            // 4096 fp64 inside one call (profiles/r05_oversubscribe_ab.txt): f = 1 1.134 M env-steps/s (lanes per workgroup 1 / 2 / 4 / 8
+            // for 1 / 5 / 15 / 17 scenes, 1021 workgroups), 1.1 1.156 M, **1.2 1.200 M** (1 / 2 / 4 for 1 / 5 / 32 scenes, 1221
+            // workgroups: the light scenes go from 8 to 4 environments per workgroup), 1.25 1.196 M, 1.3 1.182 M, 1.4 1.138 M, 1.5 1.112 M,
+            // 2 1.02 M, 3 0.87 M -- beyond ~1.3 the extra chains cost more than the shorter critical path gains.  (Round 3 measured "4
+            // lanes everywhere" at -8 %: 1040 workgroups in model order, whose last 16 started when the first wave had finished.)
+            const double oversub = getenv("MW_OVERSUBSCRIBE") ? atof(getenv("MW_OVERSUBSCRIBE")) : 1.2;
             const int budget = (int)(4 * Backend::compute_units() * (oversub > 1.0 ? oversub : 1.0));
             auto blocks = [&]() { int nb = 0; for (auto& kv : by_model) nb += ((int)kv.second.size() + lpb_of[kv.first] - 1) / lpb_of[kv.first]; return nb; };
             auto predicted = [&](int model, int l) {
@@ -787,9 +792,9 @@ public:
             for (auto& kv : hist) fprintf(stderr, " %d:%d", kv.first, kv.second);
             fprintf(stderr, "  (%d workgroups)\n", nb);
         }
-        // block order = group order: by model index, or (MW_OVERSUBSCRIBE > 1) by predicted workgroup time, longest first
+        // block order = group order: by predicted workgroup time, longest first (by model index with MW_OVERSUBSCRIBE <= 1)
         std::vector<std::pair<int, std::vector<int>>> ordered(by_model.begin(), by_model.end());
-        if (getenv("MW_OVERSUBSCRIBE") && atof(getenv("MW_OVERSUBSCRIBE")) > 1.0) {
+        if (!getenv("MW_OVERSUBSCRIBE") || atof(getenv("MW_OVERSUBSCRIBE")) > 1.0) {
             auto weight = [&](int model) {
                 const ModelData& md = *models[model];
                 double t4 = md.step_ms_lpb4, t8 = md.step_ms_lpb8;
