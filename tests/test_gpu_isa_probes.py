@@ -3,7 +3,10 @@
     (csrc/mw_phys.hpp) uses for the Hessian, the Cholesky and the triangular solves;
 (b) a non-inlined 256-VGPR callee with SGPR spills into VGPR lanes, entered under a partial EXEC mask, leaves the caller's values alone
     (DESIGN.md 5 "register hazard": the generic pattern is handled by the calling convention).
-The probes are small stand-alone HIP programs (tools/experiments/*.hip), compiled here with hipcc and run."""
+The probes are small stand-alone HIP programs (tools/experiments/*.hip), compiled here with hipcc and run.
+
+Lab notes, not product tests (VERDICT r4): they run only with MW_RUN_ISA_PROBES=1 (`MW_RUN_ISA_PROBES=1 pytest tests/test_gpu_isa_probes.py -m gpu`);
+the default GPU suite skips them."""
 import os
 import shutil
 import subprocess
@@ -16,6 +19,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def _run(src, tmp_path, extra=()):
+    if not os.environ.get("MW_RUN_ISA_PROBES"):
+        pytest.skip("ISA probes run on request only (MW_RUN_ISA_PROBES=1)")
     if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
         pytest.skip("no hipcc on this box")
     exe = str(tmp_path / "probe")
