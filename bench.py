@@ -257,17 +257,20 @@ def extra_configs(args, lib, local_rank):
     out = []
     for cfg, bm, envs, prec, steps in ((2, "MT1", 4096, "fp32", 100), (3, "MT10", 10240, "fp64", 60)):
         a = argparse.Namespace(**{**vars(args), "benchmark": bm, "envs": envs, "warmup": 5})
+        tb = time.perf_counter()
         env = build_env(a, prec, 0, 1, local_rank, lib)
+        setup_s = time.perf_counter() - tb
         prepare(env, a, 0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         k = resident(env, a, steps)
         torch.cuda.synchronize()
         w = time.perf_counter() - t0
+        ks = launch_stats(env)
         st = check_outputs(env, args.allow_status)
         out.append({"config": cfg, "workload": ("MT1 reach-v3" if bm == "MT1" else f"{bm} sync-vector") + f", {envs} envs/GPU, {prec}, random actions",
                     "value": envs * steps / w, "unit": "env-steps/s", "steps": steps, "kernel_ms_per_launch": k / steps,
-                    "kernel_ms": launch_stats(env), "flags": st["flags"]})
+                    "kernel_ms": ks, "value_median_based": envs / (ks["median"] / 1e3) if ks else None, "setup_s": setup_s, "flags": st["flags"]})
         env.close()
     n = 2048
     env = MetaWorldGpuVectorEnv("ML45-train", num_envs=n, seed=42, precision="fp64", partially_observable=False, max_episode_steps=500,
@@ -412,7 +415,9 @@ def main(argv=None):
         lib = native.load("mwh_", g.build_host_harness())
         local_rank = 0
     from metaworld_amd import tasks as T
+    t_build = time.perf_counter()
     env = build_env(args, args.precision, rank, world, local_rank, lib)
+    setup_s = time.perf_counter() - t_build          # model upload + mw_finalize: the faithful reset of every (task, goal) once (compute_snapshots)
     N = env.num_envs
     one_hot = args.benchmark != "MT1"
     wl_task = ["reach-v3"] if args.benchmark == "MT1" else list(env.task_list)
@@ -521,7 +526,9 @@ def main(argv=None):
                "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.precision == "fp32" else "f64", "data": "synthetic",
+               "value_median_based": (N * world / (kstats["median"] / 1e3)) if kstats else None,
                "config": {"workload": workload, "envs_per_gpu": N, "tasks_with_device_code": len(T.supported_tasks()),
+                          "setup_s": setup_s,
                           "episode_phase": "all envs start together (early-episode window)" if args.no_stagger else
                           f"staggered uniformly over the {HORIZON}-step horizon (mw_set_episode_phase + untimed {HORIZON}-step pre-roll): "
                           "every window samples whole episodes incl. auto-resets",
@@ -544,10 +551,12 @@ def main(argv=None):
             k2 = resident(env2, args, args.steps)
             torch.cuda.synchronize()
             w2 = time.perf_counter() - t1
+            ks2 = launch_stats(env2)
             st2 = check_outputs(env2, args.allow_status)
             key = "throughput_mode" if other == "fp32" else "parity_mode"
             out[key] = {"dtype": "f32" if other == "fp32" else "f64", "value": N * args.steps / w2, "unit": "env-steps/s",
-                        "ms_per_step": w2 / args.steps * 1e3, "kernel_ms_per_launch": k2 / args.steps, "status_flags": st2,
+                        "ms_per_step": w2 / args.steps * 1e3, "kernel_ms_per_launch": k2 / args.steps, "kernel_ms": ks2,
+                        "value_median_based": N / (ks2["median"] / 1e3) if ks2 else None, "status_flags": st2,
                         "note": "fp32 state and arithmetic: success flags exact, obs / reward within the single-precision contact-geometry "
                                 "floor (not 1e-5 on every task, DESIGN.md 6)" if other == "fp32" else "fp64 state and arithmetic"}
             env2.close()
@@ -567,9 +576,11 @@ def main(argv=None):
             k3 = resident(env3, sat_args, 100)
             torch.cuda.synchronize()
             w3 = time.perf_counter() - t3
+            ks3 = launch_stats(env3)
             st3 = check_outputs(env3, args.allow_status)
             out["saturation"] = {"envs": env3.num_envs, "value": env3.num_envs * 100 / w3, "unit": "env-steps/s", "steps": 100,
-                                 "kernel_ms_per_launch": k3 / 100, "status_flags": st3}
+                                 "kernel_ms_per_launch": k3 / 100, "kernel_ms": ks3,
+                                 "value_median_based": env3.num_envs / (ks3["median"] / 1e3) if ks3 else None, "status_flags": st3}
             env3.close()
         if world == 1 and on_gpu and not args.no_saturation:
             # the open-loop rollout with several steps per launch (mw_step_resident_fused): the same env-steps bit for bit, the batch
@@ -578,12 +589,13 @@ def main(argv=None):
             prepare(env4, args, rank)
             torch.cuda.synchronize()
             t4 = time.perf_counter()
-            k4 = env4.step_resident(args.steps, steps_per_launch=50)
+            fsteps = max(args.steps, 150)          # its own window: at least three launches of 50 steps whatever --steps says
+            k4 = env4.step_resident(fsteps, steps_per_launch=50)
             torch.cuda.synchronize()
             w4 = time.perf_counter() - t4
             st4 = check_outputs(env4, args.allow_status)
-            out["fused_rollout"] = {"steps_per_launch": 50, "value": env4.num_envs * args.steps / w4, "unit": "env-steps/s", "steps": args.steps,
-                                    "kernel_ms_per_step": k4 / args.steps, "status_flags": st4,
+            out["fused_rollout"] = {"steps_per_launch": 50, "value": env4.num_envs * fsteps / w4, "unit": "env-steps/s", "steps": fsteps,
+                                    "kernel_ms_per_step": k4 / fsteps, "status_flags": st4,
                                     "note": "open-loop rollout, 50 consecutive steps of every environment per kernel launch (same results as the per-step "
                                             "loop bit for bit: tests/test_resident_schedule.py); reported beside `value`, never as it"}
             env4.close()

@@ -367,6 +367,7 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
                 self._next_goal[e] = self._select(e, commit=False)
 
     # ---- the resident loop (mw_step_resident): K steps on pre-uploaded actions, outputs left in HBM ----
+    _MAX_SCHEDULE_ROWS = 4096          # default cap on the goal-schedule rows of one call (16 KB per row at 4096 envs)
     def step_resident(self, nsteps, gather=False, schedule_rows=None, steps_per_launch=None):
         """`nsteps` steps of the whole batch on the actions uploaded with `ctx.upload_actions`, no host round trip in between;
         returns the HIP-event kernel time in ms.  The auto-resets that happen inside draw a NEW task per reset like
@@ -386,7 +387,11 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
             # rows needed = the most auto-resets one env can make in nsteps: one per max_episode_steps without early termination,
             # up to one per step with terminate_on_success (an env can succeed in its first step)
             worst = nsteps + 1 if self.terminate_on_success else nsteps // max(1, min(self.max_episode_steps, 500)) + 3   # (+ slack for instability truncations)
-            K = int(schedule_rows or max(2, min(64, nsteps // 50 + 2, worst)))
+            # K follows the bound: a K x N int32 table is cheap, and a default smaller than `worst` turned legitimate
+            # configurations (short episodes, terminate_on_success) into a failure after the kernel had already run
+            if schedule_rows is not None and int(schedule_rows) < 1:
+                raise ValueError("schedule_rows must be >= 1")
+            K = int(schedule_rows) if schedule_rows is not None else max(2, min(self._MAX_SCHEDULE_ROWS, worst))
             every = np.arange(self.num_envs)
             sched = np.stack([self._random_goals(every, ahead=k) for k in range(K)]).astype(np.int32)
             self.ctx.set_goal_schedule(sched)
@@ -397,15 +402,18 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
         if sched is not None:
             used = self.ctx.goal_schedule_pos().astype(np.int64)
             self.ctx.set_goal_schedule(None)
+            # the host bookkeeping follows the device for the rows that were really consumed -- also when the table overflowed, so
+            # that the env object stays usable (its streams are then ahead of the reference's by the surplus resets: reported below)
+            took = np.minimum(used, len(sched))
+            hit = np.flatnonzero(took > 0)
+            self._cur_goal[hit] = sched[took[hit] - 1, hit]
+            self._reset_count += took
+            self._look_ahead(np.ones(self.num_envs, dtype=bool))
             if (used > len(sched)).any():
-                # the kernel repeated the last row for the surplus resets: those draws never came from the selection streams, and
-                # advancing the streams by `used` would desynchronise every later reset from the reference's wrapper
+                # the kernel repeated the last row for the surplus resets: those draws never came from the selection streams, so the
+                # trajectory after them is not the reference wrapper's
                 raise RuntimeError(f"step_resident: an env auto-reset {int(used.max())} times but only {len(sched)} schedule rows were drawn; "
                                    "pass schedule_rows >= the number of resets per env (short episodes with terminate_on_success)")
-            hit = np.flatnonzero(used > 0)
-            self._cur_goal[hit] = sched[np.minimum(used[hit], len(sched)) - 1, hit]
-            self._reset_count += used
-            self._look_ahead(np.ones(self.num_envs, dtype=bool))
         return ms
 
     # ---- the observation / reward wrappers between the env and the vectoriser (metaworld/__init__.py:438-449) ----

@@ -59,6 +59,39 @@ def test_resident_loop_without_resampling_keeps_the_goal(hostsim):
     a.close(); b.close()
 
 
+def test_default_schedule_rows_follow_the_reset_bound(hostsim):
+    """with short episodes the DEFAULT number of schedule rows must cover every auto-reset an env can make (round 5:
+    K = nsteps // 50 + 2 = 2 against 3-4 resets here -> RuntimeError after the kernel had run)"""
+    a, b = _pair(hostsim)
+    a.reset(); b.reset()
+    acts = np.random.default_rng(2).uniform(-1, 1, (8, 20, 4)).astype(np.float32)
+    a.ctx.upload_actions(acts)
+    a.step_resident(23)                                         # max_episode_steps = 7: up to 4 resets per env
+    for t in range(23):
+        b.step(acts[t % 8])
+    _same_state(a, b)
+    a.close(); b.close()
+
+
+def test_schedule_overflow_leaves_the_bookkeeping_consistent(hostsim):
+    """an explicit table that is too short: the error is raised AFTER the host bookkeeping has followed the device for the rows that
+    were consumed (goal of every env = the last row the kernel used), and the env object stays usable"""
+    a, _b = _pair(hostsim)
+    _b.close()
+    a.reset()
+    acts = np.random.default_rng(3).uniform(-1, 1, (8, 20, 4)).astype(np.float32)
+    a.ctx.upload_actions(acts)
+    count0 = a._reset_count.copy()
+    with pytest.raises(RuntimeError, match="schedule rows"):
+        a.step_resident(23, schedule_rows=2)
+    assert (a._reset_count - count0 == 2).all()                # every env made >= 3 resets, two rows were real draws
+    with pytest.raises(ValueError):
+        a.step_resident(3, schedule_rows=0)
+    o, r, *_ = a.step(acts[0])                                  # still steps
+    assert np.isfinite(o).all() and np.isfinite(r).all()
+    a.close()
+
+
 def test_schedule_validation(hostsim):
     env = MetaWorldGpuVectorEnv("MT1", "reach-v3", num_envs=2, seed=0, precision="fp32", lib=hostsim)
     env.reset()
