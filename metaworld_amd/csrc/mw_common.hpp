@@ -259,7 +259,7 @@ struct Env {
     // lane-role loads that need all 64 lanes) and every non-inlined stage function then run under a full EXEC mask.
     int slot, nslot, ghost;
     int lds_rows;      // constraint rows that fit in the scratchpad: scalars + Jacobian row (the rest stay in the column store)
-    int lds_w;         // scratchpad slots per row = SR_N + nv
+    int lds_w;         // scratchpad slots per row = SR_N + nv, rounded up to an odd number
     // BODY-LEVEL CHAINS IN THE SCRATCHPAD.  Kinematics, the composite inertias and the recursive Newton-Euler passes are chains
     // over the body tree in which every link reads what the previous one wrote: through the column store that is one L2 round
     // trip (~700 cycles) per link and array, through LDS ~100.  When the environment's share of the scratchpad is large enough
@@ -291,7 +291,7 @@ struct Env {
         sub = host ? 0 : thread / lpb;
         thr = thread;
         nsub = host ? sp.host_nsub : 64 / lpb;
-        lds_w = SR_N + nv_;
+        lds_w = (SR_N + nv_) | 1;          // odd: rows r, r + 1, ... of one field then start in different LDS banks (row-per-lane sweeps; an even width put all 16 rows of a sweep on the same 8 banks)
         const int words = (int)((host ? sp.block_words : sp.block_words / lpb) * 4 / sizeof(T));          // slots of this environment
         chain_lds = sp.chain == 0 ? 0 : (words >= 7 * nv_ + nq_ + 18 * nbody + 2 * lds_w ? 2 : (words >= 7 * nv_ + nq_ + 10 * nbody + 2 * lds_w ? 1 : 0));
         if (sp.chain > 0 && sp.chain < chain_lds) chain_lds = sp.chain;          // (tests / experiments: cap the level)

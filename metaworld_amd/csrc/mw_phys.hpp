@@ -807,19 +807,28 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
 
 
 // ------------------------------------------------------------------ Newton solver
-// Row accessors for the sweep bodies: Rows<T, true> reads the scratchpad unconditionally (the caller has checked
-// that row i .. i+3 are inside it), Rows<T, false> takes the per-access generic path.  Instantiating each sweep body
-// for both keeps the scratchpad reads of one row in a single basic block (issued back to back, one wait).
-template <typename T, bool IN_LDS>
+// Row accessors for the sweep bodies: Rows<T, 1> (= Rows<T, true>) reads the scratchpad unconditionally (the caller has checked
+// that row i .. i+3 are inside it), Rows<T, 2> the column store unconditionally (all of them beyond the scratchpad), Rows<T, 0>
+// (= Rows<T, false>) takes the per-access generic path.  Instantiating each sweep body per mode keeps the reads of one row in
+// a single basic block (issued back to back, one wait): behind a per-access branch every read of a row in the column store is
+// its own L2 round trip, 16 of them for one cone block.
+template <typename T, int MODE>
 struct Rows {
     Env<T> e;
     MW_HD T get(int i, int f) const {
-        if (IN_LDS) return e.lds[e.S(i, f) * e.lds_stride];
+        if (MODE == 1) return e.lds[e.S(i, f) * e.lds_stride];
+        if (MODE == 2) return EX(e, i, sr_slot(f));
         return sr_get(e, i, f);
     }
     MW_HD void set(int i, int f, T v) const {
-        if (IN_LDS) e.lds[e.S(i, f) * e.lds_stride] = v;
+        if (MODE == 1) e.lds[e.S(i, f) * e.lds_stride] = v;
+        else if (MODE == 2) EX(e, i, sr_slot(f)) = v;
         else sr_set(e, i, f, v);
+    }
+    MW_HD T getj(int i, int k) const {          // Jacobian entry k of row i
+        if (MODE == 1) return e.lds[e.S(i, SR_N + k) * e.lds_stride];
+        if (MODE == 2) return EJ(e, i, k);
+        return ej_get(e, i, k);
     }
 };
 
@@ -1361,6 +1370,9 @@ MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
     }
 }
 #endif
+}  // namespace mw
+#include "mw_solve_wave.hpp"          // the whole solve in the lane-role layout (device, >= 4 sub-lanes per environment)
+namespace mw {
 
 template <typename T, int NV>
 MW_HD void solve_impl(const Env<T> e) {
@@ -1554,6 +1566,16 @@ MW_STAGE_FN void solve(const Env<T> e_) {
         for (int k = 0; k < nv; k++) e.R(L.qfrc_c + k) = 0;
         return;
     }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MW_NO_WAVE_SOLVER)
+    // every layout with sub-lanes (all bench configurations): the solve in the lane-role layout, entered by all 64 lanes (ghosts
+    // included) under a full EXEC mask; the rows and the smooth forces were written by the environment's own sub-lanes
+    if (e.nsub >= 4 && nv <= MAX_NV) {
+        MW_SYNC();
+        if (nv > 16) solve_wave<T, true>(e);
+        else solve_wave<T, false>(e);
+        return;
+    }
+#endif
     MW_NV_DISPATCH(nv, (solve_impl<T, NVC>(e)))
 }
 
