@@ -557,6 +557,10 @@ def main(argv=None):
             out[key] = {"dtype": "f32" if other == "fp32" else "f64", "value": N * args.steps / w2, "unit": "env-steps/s",
                         "ms_per_step": w2 / args.steps * 1e3, "kernel_ms_per_launch": k2 / args.steps, "kernel_ms": ks2,
                         "value_median_based": N / (ks2["median"] / 1e3) if ks2 else None, "status_flags": st2,
+                        # line searches abandoned on a non-descent direction (single-precision factor of an ill-conditioned Hessian, or
+                        # rounding at the optimum): the Newton loop of that environment ends there like the reference solver's does; each
+                        # env-step holds ~6 solves x ~2 iterations
+                        "solver_stalls_per_1000_env_steps": 1e3 * st2["solver_stalls"] / (N * args.steps),
                         "note": "fp32 state and arithmetic: success flags exact, obs / reward within the single-precision contact-geometry "
                                 "floor (not 1e-5 on every task, DESIGN.md 6)" if other == "fp32" else "fp64 state and arithmetic"}
             env2.close()

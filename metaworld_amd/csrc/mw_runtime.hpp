@@ -415,7 +415,12 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     step_outputs(w, e, gid, task, td, obs, reward, success, info);
 }
 
+// Split collision (narrow phase as batch-wide kernels between the lane kernels): measured 25-37 % SLOWER than the fused kernel
+// (profiles/r05_split_collision_*), so it is compiled only into -DMW_SPLIT_COLLISION variants of the library
+// (tools/build_variants.sh, tests/test_split_collision.py); the default library carries neither its kernels nor its buffers.
+#if defined(MW_SPLIT_COLLISION)
 #include "mw_split.inl"
+#endif
 
 // debugging / parity hooks: run raw physics on every lane
 template <typename T>
@@ -543,9 +548,14 @@ class Context : public ContextBase {
     std::vector<uint8_t> was_reset_;          // step() before the first reset() of an env is an error
     int world_size() const { return comm_ ? comm_->world : 1; }
     uint8_t* h_done_ = nullptr;               // pinned host copy of the `done` row of the last mw_step_device_on
-    int split_collision_ = 0;                 // mw_set_option("split_collision"): 1 = the narrow phase runs as its own batch-wide kernels (launch_step)
+    int split_collision_ = 0;                 // mw_set_option("split_collision"): 1 = the narrow phase runs as its own batch-wide kernels (launch_step); -DMW_SPLIT_COLLISION builds only
+#if defined(MW_SPLIT_COLLISION)
     SplitBuf<T> sb_{};                        // work items / hit table of the split collision (allocated on first use)
     bool any_lazy_dynamics_ = false;          // some task's reward reads contact forces (task_touches) or cfg.full_forward: a sixth narrow phase per step
+#else
+    void free_split_buffers() {}
+#endif
+#if defined(MW_SPLIT_COLLISION)
     void ensure_split_buffers() {
         if (sb_.counts) return;
         if (groups_.size() > 127) throw std::runtime_error("split_collision: more than 127 model groups");
@@ -581,12 +591,14 @@ class Context : public ContextBase {
     void phase_kernel(const World<T>& w, const SplitBuf<T>& sb, int phase) {
         Backend::launch(nblocks_, [w, sb, phase] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_phase(w, sb, phase, b, t, sp); });
     }
+#endif
     // ONE VectorEnv.step of the whole batch on the context's stream: the fused kernel, or the split-collision sequence (mw_split.inl)
     void launch_step(const World<T>& w) {
         if (!split_collision_) {
             Backend::launch(nblocks_, [w] MW_LAMBDA(int b, int t, Scratchpad sp) { lane_step(w, b, t, sp); });
             return;
         }
+#if defined(MW_SPLIT_COLLISION)
         ensure_split_buffers();
         const SplitBuf<T> sb = sb_;
         phase_kernel(w, sb, PH_BEGIN);
@@ -598,6 +610,7 @@ class Context : public ContextBase {
             launch_collision(w, true);
             phase_kernel(w, sb, PH_FINAL);
         }
+#endif
     }
 
     World<T> world(bool with_io = true) const {
@@ -1241,7 +1254,13 @@ public:
     }
     int launch_times(float* out, int cap) override { return Backend::launch_times(out, cap); }
     void set_option(const std::string& name, double value) override {
-        if (name == "split_collision") { Backend::sync(); split_collision_ = value != 0 ? 1 : 0; }
+        if (name == "split_collision") {
+#if defined(MW_SPLIT_COLLISION)
+            Backend::sync(); split_collision_ = value != 0 ? 1 : 0;
+#else
+            if (value != 0) throw std::invalid_argument("set_option: split_collision needs a library built with -DMW_SPLIT_COLLISION (tools/build_variants.sh)");
+#endif
+        }
         else throw std::invalid_argument("set_option: unknown option " + name);
     }
 

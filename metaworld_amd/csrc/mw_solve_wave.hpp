@@ -35,6 +35,16 @@
 
 namespace mw {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MW_NO_WAVE_SOLVER)
+// timing builds (-DMW_SOLVER_TIMING): the eight solver slots hold the phases of solve_impl (warm, Hasm, chol, MvJv, lsrch, update, counts);
+// with -DMW_SOLVE_FINE they hold the pieces of solve_wave instead: 0 setup loads, 1 coefficient pre-pass, 2 H rows, 3 Cholesky + solves,
+// 4 apply (M x, J x), 5 line search, 6 update_constraint's block sweep, 7 J' f   (cycles / 16, every pass incl. the warm start)
+#if defined(MW_SOLVE_FINE) && defined(MW_SOLVER_TIMING)
+#define SW_FINE(slot, t0, t1) if (on) { rv.I(L.icount + 4 + (slot)) += (int)(((t1) - (t0)) >> 4); }
+#define SW_COARSE(x)
+#else
+#define SW_FINE(slot, t0, t1)
+#define SW_COARSE(x) x
+#endif
 
 template <int CTRL> __device__ inline double mw_dpp(double v) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -200,6 +210,8 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                     }
                 }
                 MW_SYNC();
+                MW_TICK(t_pre)
+                SW_FINE(1, t_0, t_pre)
                 mw_f16v acc = accM;
                 HT hb = hbM, eta = etaM;
                 const int ne = go ? nefc : 0, nm = blk_max4(ne);
@@ -277,7 +289,8 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                         row_term(r, EX(rv, r, sr_slot(SR_JV)), EJ(rv, r, kd), BORDER ? T(EJ(rv, r, 16)) : T(0));
                 }
                 MW_TICK(t_rows)
-                if (on) { MW_TOCK(rv, L, 1, t_0, t_rows) }
+                SW_COARSE(if (on) { MW_TOCK(rv, L, 1, t_0, t_rows) })
+                SW_FINE(2, t_pre, t_rows)
                 // Cholesky in the accumulator layout: lane (rb, ri) collects row ri of the factor of ITS environment
                 HT Lr[16], invd = 1;
 #pragma unroll
@@ -324,7 +337,8 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                 x = dof ? (T)xd : T(0);
                 if (BORDER) x16 = (T)x17;
                 MW_TICK(t_chol)
-                if (on) { MW_TOCK(rv, L, 2, t_rows, t_chol) }
+                SW_COARSE(if (on) { MW_TOCK(rv, L, 2, t_rows, t_chol) })
+                SW_FINE(3, t_rows, t_chol)
             }
             MW_TICK(t_1)
             // ---- apply: y = M x (row per lane on the gathered x), rows[field] = J x (- aref at a candidate point), row per lane ----
@@ -368,10 +382,11 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
             }
             MW_SYNC();
             MW_TICK(t_2)
+            SW_FINE(4, t_1, t_2)
             if (it < 0) {
                 if (go) { qa = x; Ma = y; qa16 = x16; Ma16 = y16; }
             } else {
-                if (on) { MW_TOCK(rv, L, 3, t_1, t_2) }
+                SW_COARSE(if (on) { MW_TOCK(rv, L, 3, t_1, t_2) })
                 // ---- exact line search along x (safeguarded Newton on the 1-D convex cost) ----
                 const T r_ = dof ? Ma - sm : T(0), dq = dof ? qa - qs : T(0), r16 = BORDER ? Ma16 - sm16 : T(0), dq16 = BORDER ? qa16 - qs16 : T(0);
                 const T snorm = mw_sqrt(blk_sum_t(x * x) + x16 * x16);
@@ -419,7 +434,8 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                     alpha = an;
                 }
                 MW_TICK(t_3)
-                if (on) { MW_TOCK(rv, L, 4, t_2, t_3) MW_TADD(rv, L, 6, nls) }
+                SW_COARSE(if (on) { MW_TOCK(rv, L, 4, t_2, t_3) MW_TADD(rv, L, 6, nls) })
+                SW_FINE(5, t_2, t_3)
                 (void)nls;
                 if (go && alpha == 0) { go = false; act = false; }
                 if (go) { qa += alpha * x; Ma += alpha * y; if (BORDER) { qa16 += alpha * x16; Ma16 += alpha * y16; } }
@@ -447,6 +463,8 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                 const T gs = blk_sum_t(dof ? (Ma - sm) * (qa - qs) : T(0)) + (BORDER ? (Ma16 - sm16) * (qa16 - qs16) : T(0));
                 cnew = c + T(0.5) * gs;
                 MW_SYNC();
+                MW_TICK(t_uc)
+                SW_FINE(6, t_4, t_uc)
                 // J' f, dof per lane: every lane of the block reads the row's force (one address: an LDS broadcast) and its own entry
                 const int ne = go ? nefc : 0, nm = blk_max4(ne), nl = nm < lds_rows ? nm : lds_rows;
                 // (replica k takes the row quadruples k, k + R, ...; the partial sums meet in rep_sum)
@@ -499,6 +517,8 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                 q = rep_sum(q, R);
                 if (BORDER) q16 = rep_sum(q16, R);
                 if (go) { qfc = dof ? q : T(0); qfc16 = q16; }
+                MW_TICK(t_jf)
+                SW_FINE(7, t_uc, t_jf)
             }
             MW_SYNC();
             MW_TICK(t_5)
@@ -506,16 +526,17 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
             else if (it == -2) cost = cnew;
             else if (it == -1) { if (go) cost = cnew; }
             else {
-                if (on) { MW_TOCK(rv, L, 5, t_4, t_5) MW_TADD(rv, L, 7, go ? 1 : 0) }
+                SW_COARSE(if (on) { MW_TOCK(rv, L, 5, t_4, t_5) MW_TADD(rv, L, 7, go ? 1 : 0) })
                 if (go) {
                     niter = it + 1;
                     if (scale * (cost - cnew) < tol) act = false;
                     cost = cnew;
                 }
             }
-            if (it < 0 && on) { MW_TOCK(rv, L, 0, t_0, t_5) }
+            SW_COARSE(if (it < 0 && on) { MW_TOCK(rv, L, 0, t_0, t_5) })
         }
-        if (on) { MW_TOCK(rv, L, 0, t_a, t_b) }
+        SW_COARSE(if (on) { MW_TOCK(rv, L, 0, t_a, t_b) })
+        SW_FINE(0, t_a, t_b)
         // ---- results: qacc, qfrc_constraint, the iteration count, the stall count; efc_force of the rows kept in the scratchpad -> efcX ----
         if (on && rep == 0) {
             if (dof) { rv.R(L.qacc + ri) = qa; rv.R(L.qfrc_c + ri) = qfc; }

@@ -24,3 +24,11 @@ def hostsim():
 def gpulib():
     from metaworld_amd import native
     return native.load()
+
+
+@pytest.fixture(scope="session")
+def gpulib_split():
+    """the -DMW_SPLIT_COLLISION variant of the library (the default library does not carry the split-collision kernels)"""
+    import __graft_entry__ as g
+    from metaworld_amd import native
+    return native.Lib(g.build_gpu_split(), "mw_")

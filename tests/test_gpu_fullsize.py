@@ -37,21 +37,95 @@ def _oracle_synced_to(ctx, e, task):
     return om, d
 
 
-def _oracle_response(ctx, e, task, state, eps=1e-12, trials=3):
-    """max |change| of the oracle's own qpos / qvel, 5 substeps after the synchronised state `state` (columns read BEFORE the device
-    stepped), when qpos is perturbed by eps: the conditioning of the reference computation at that state"""
-    class _Cols:          # _oracle_synced_to reads the state through ctx.read
-        def read(self, _e, col):
-            return state[col]
-    out = []
-    rng = np.random.default_rng(0)
+class _Cols:          # _oracle_synced_to reads the state through ctx.read
+    def __init__(self, state):
+        self.state = state
+
+    def read(self, _e, col):
+        return self.state[col]
+
+
+def _real_contacts(dist):
+    """contacts that are not exact touching ties: two surfaces that touch EXACTLY (the faucet's coaxial cylinders, dist = 0 +- 1e-17, no
+    constraint row either way) are listed or not depending on the last rounding"""
+    return int((np.abs(np.asarray(dist, dtype=float)) > 1e-12).sum())
+
+
+def _oracle_branches(e, task, state, eps=1e-12, trials=20, seed=0):
+    """BRANCHES of the reference computation at a synchronised state.  The oracle engine is run 5 substeps from
+    `state` (columns read BEFORE the device stepped) and from `trials` copies whose qpos is perturbed by eps; the outcomes are
+    clustered: same contact count (exact touching ties aside), same number of constraint rows, qpos within 1e-9.  A well-conditioned
+    state has ONE cluster; a contact sitting at its activation margin, a face / edge decision of the narrow phase or a cone on its
+    boundary gives a few.  Returns the clusters, most populated first: dict(ncon, nefc, qpos, qvel, n, base) -- base: holds the
+    unperturbed run."""
+    rng = np.random.default_rng(seed)
+    clusters = []
     for k in range(trials + 1):
-        om, d = _oracle_synced_to(_Cols(), e, task)
+        om, d = _oracle_synced_to(_Cols(state), e, task)
         if k:
             d.qpos[:] += eps * rng.standard_normal(len(d.qpos))
         d.step(5)
-        out.append((d.qpos.copy(), d.qvel.copy()))
-    return (max(np.abs(q - out[0][0]).max() for q, _ in out[1:]), max(np.abs(v - out[0][1]).max() for _, v in out[1:]))
+        nc = _real_contacts([c["dist"] for c in d.contacts()])
+        for c in clusters:
+            if c["ncon"] == nc and c["nefc"] == d.nefc and np.abs(c["qpos"] - d.qpos).max() < 1e-9:
+                c["n"] += 1
+                break
+        else:
+            clusters.append(dict(ncon=nc, nefc=int(d.nefc), qpos=d.qpos.copy(), qvel=d.qvel.copy(), n=1, base=(k == 0)))
+    return sorted(clusters, key=lambda c: -c["n"])
+
+
+def _in_cloud(clusters, qpos):
+    """For states where the oracle's response to 1e-12 is not a handful of discrete branches but a CLOUD (most perturbed runs end on
+    an outcome of their own, > 1e-9 from every other: a steep continuous sensitivity, e.g. the friction direction of a sticking
+    contact, f_t ~ U / |U| with |U| -> 0): is the device's outcome one more sample of that cloud?  Yes if its distance to the nearest
+    oracle outcome is no larger than the largest nearest-neighbour distance among the oracle's own outcomes (leave-one-out).
+    Returns (bool, device's nearest-neighbour distance, the cloud's largest nearest-neighbour distance)."""
+    Q = np.array([c["qpos"] for c in clusters])
+    if len(Q) < 8:
+        return False, np.inf, 0.0
+    D = np.abs(Q[:, None, :] - Q[None, :, :]).max(-1) + np.diag(np.full(len(Q), np.inf))
+    spacing = float(D.min(1).max())
+    mine = float(np.abs(Q - qpos).max(-1).min())
+    return mine <= spacing, mine, spacing
+
+
+def _branch_of(clusters, qpos, qvel, con_dist, nefc, tol_q=1e-7, tol_v=1e-5):
+    """index of the cluster the device's outcome belongs to -- same contact / row counts, qpos within 1e-7 and qvel within 1e-5 of the
+    cluster's representative (the limits of an ordinary, unrelaxed state) -- or -1; and the distance to the nearest cluster"""
+    nc = _real_contacts(con_dist)
+    near = np.inf
+    for i, c in enumerate(clusters):
+        dq, dv = np.abs(c["qpos"] - qpos).max(), np.abs(c["qvel"] - qvel).max()
+        near = min(near, dq)
+        if c["ncon"] == nc and c["nefc"] == int(nefc) and dq < tol_q and dv < tol_v:
+            return i, float(dq)
+    return -1, float(near)
+
+
+def _device_branch(ctx, e, task, state, trials=20):
+    """which branch of the reference computation the DEVICE took from the synchronised state `state` (qpos, qvel, warm, mocap, ctrl,
+    reloc of env e BEFORE its five substeps).  If no branch is found with eps = 1e-12 the probes are repeated with 1e-10 (wider
+    neighbourhood, reported).  Returns (branch index or -1, number of branches, distance, eps used).  The env is left 5 substeps
+    after `state`."""
+    for c in ("qpos", "qvel", "warm", "mocap", "ctrl"):
+        ctx.write(e, c, state[c])
+    ctx.debug("substeps", 5)
+    ic = ctx.read_int(e, "icount")
+    q, v = ctx.read(e, "qpos"), ctx.read(e, "qvel")
+    dist = ctx.read(e, "con").reshape(-1, 26)[:int(ic[0]), 0]
+    for eps in (1e-12, 1e-10):
+        cl = _oracle_branches(e, task, state, eps=eps, trials=trials)
+        k, dq = _branch_of(cl, q, v, dist, ic[1])
+        if k >= 0:
+            break
+    if k < 0:          # no discrete branch: a cloud?  (code -2 = "inside the oracle's own cloud of outcomes", dq = distance to its nearest sample)
+        for eps in (1e-12, 1e-10):
+            cl = _oracle_branches(e, task, state, eps=eps, trials=trials)
+            ok, mine, spacing = _in_cloud(cl, q)
+            if ok:
+                return -2, len(cl), mine, eps
+    return k, len(cl), dq, eps
 
 
 @pytest.mark.parametrize("bench,n", CONFIGS)
@@ -149,21 +223,34 @@ def test_bench_states_match_the_oracle(gpulib, bench_name, n):
         # 1e-12 to 1e-5 ... 1e-3 in ONE step (tests/test_ill_conditioning.py) get the limits their trace tests use
         lq, lv = (1e-3, 1e-1) if name in TOL else (1e-5, 1e-3)
         errs.append(eq)
-        if ncon_dev == ncon_orc and ic[1] == d.nefc and not (eq < lq and ev < lv):
-            # Over the limit: is THIS STATE ill-conditioned in the reference computation itself?  (Which states the sample holds
-            # depends on the last bit of 520 chaotic steps, so any change of the device code draws new ones; a contact sitting at its
-            # activation margin turns 1e-12 into 1e-6 ... 1e-5 within one env-step, tests/test_ill_conditioning.py.)  The oracle is
-            # re-run from the synchronised state with qpos perturbed by 1e-12: where its OWN answer moves by more than a tenth of the
-            # limit no implementation can hold the limit, and the device may deviate by 10x that response (at most 1e-3 / 1e-1).
-            rq, rv = _oracle_response(env.ctx, e, name, before[e])
-            relaxed.append((name, e, float(eq), float(rq)))
-            lq, lv = min(max(lq, 10 * rq), 1e-3), min(max(lv, 10 * rv), 1e-1)
         if not (ncon_dev == ncon_orc and ic[1] == d.nefc and eq < lq and ev < lv):
-            bad.append((name, e, int(elapsed[e]), (int(ic[0]), d.ncon), (int(ic[1]), d.nefc), float(eq), float(ev)))
+            # Not within the limits of the unperturbed oracle run's outcome.  BRANCH MEMBERSHIP, not a magnitude bound: the oracle is
+            # re-run from the synchronised state and from 20 copies perturbed by 1e-12, the outcomes are clustered, and the device's
+            # result must lie within 1e-7 / 1e-5 of ONE cluster with the same contact and row counts.  (Which states the sample holds
+            # depends on the last bit of 520 chaotic steps; a contact sitting at its activation margin turns 1e-12 into 1e-6 ... 1e-4
+            # within one env-step, tests/test_ill_conditioning.py -- then the reference computation itself has several outcomes there.)
+            q_dev, v_dev = env.ctx.read(e, "qpos"), env.ctx.read(e, "qvel")
+            dist_dev = env.ctx.read(e, "con").reshape(-1, 26)[:int(ic[0]), 0]
+            for eps in (1e-12, 1e-10):
+                cl = _oracle_branches(e, name, before[e], eps=eps)
+                k, dq = _branch_of(cl, q_dev, v_dev, dist_dev, ic[1])
+                if k >= 0:
+                    break
+            if k < 0:
+                for eps in (1e-12, 1e-10):
+                    cl = _oracle_branches(e, name, before[e], eps=eps)
+                    ok, mine, _sp = _in_cloud(cl, q_dev)
+                    if ok:
+                        k, dq = -2, mine          # (inside the oracle's own cloud of outcomes: _in_cloud)
+                        break
+            relaxed.append((name, e, float(eq), len(cl), k, dq, eps))
+            if k == -1 or not (eq < 1e-3 and ev < 1e-1):          # (no branch at all, or a branch absurdly far from the unperturbed one)
+                bad.append((name, e, int(elapsed[e]), (int(ic[0]), d.ncon), (int(ic[1]), d.nefc), float(eq), float(ev), len(cl), k, dq))
     # the states whose limit followed the oracle's own conditioning are REPORTED even when the test passes (a self-adjusting
     # tolerance must not be silent: VERDICT r3): stdout (pytest -rA) and gpurun_out/bench_states_relaxed.txt, committed under profiles/
-    report = [f"{len(relaxed)} of {len(synced)} sampled states got a relaxed limit (task, env, |dq| device vs oracle, oracle's own response to 1e-12)"]
-    report += [f"  {n:28s} env {e:5d}  dq {q:.3e}  oracle response {r:.3e}" for n, e, q, r in relaxed]
+    report = [f"{len(relaxed)} of {len(synced)} sampled states are not on the unperturbed oracle run's outcome (task, env, |dq| device vs that run; "
+              "outcomes of the oracle under 20 perturbations of eps; the one the device is on (-1: none, -2: inside the oracle's cloud of outcomes), its distance to it)"]
+    report += [f"  {n:28s} env {e:5d}  dq {q:.3e}  branches {nb}  device on branch {k}  at {dq:.2e}  (eps {eps:g})" for n, e, q, nb, k, dq, eps in relaxed]
     report.append("error quantiles 0.5 / 0.9 / 0.99 / 1.0: " + " ".join(f"{x:.2e}" for x in np.quantile(errs, [0.5, 0.9, 0.99, 1.0])))
     print("\n".join(report))
     try:

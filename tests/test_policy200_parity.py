@@ -5,11 +5,17 @@ traces these stay in the manipulation regime long after the first success -- a b
 hole, a lock at its limit (the v1 goldens found a real parity bug in exactly such states).
 
 Sustained stiff contacts are where the REFERENCE computation itself is ill-conditioned (tests/test_ill_conditioning.py): at 8 of the 50
-tasks some steps exceed 1e-5.  The test does not widen a tolerance by hand: a step over the limit is re-run on the oracle engine from
-the same synchronised state with qpos perturbed by 1e-12 (ten random directions), and the limit of THAT step follows the reference's
-own response (10 x it, at most 1e-3) -- the rule of tests/test_gpu_fullsize.py::test_bench_states_match_the_oracle.  Every relaxed step
-is reported (stdout with -rA, gpurun_out/policy200_relaxed_<backend>.txt; committed under profiles/), and a step whose deviation the
-reference's conditioning does not explain fails."""
+tasks some steps exceed 1e-5.  No tolerance is widened for them.  A step over the limit is a BRANCH-MEMBERSHIP question (VERDICT r5
+item 2): the oracle engine is re-run from the same synchronised state and from 20 copies with qpos perturbed by 1e-12, its outcomes
+are clustered (contact count, row count, qpos to 1e-9), and the device's own five substeps from that state must land within 1e-7 /
+1e-5 (qpos / qvel) of ONE cluster with the same contact and row counts -- the rule of
+tests/test_gpu_fullsize.py::test_bench_states_match_the_oracle.  Where the oracle's outcomes are not a handful of branches but a
+CLOUD (nearly every 1e-12 perturbation ends more than 1e-9 from every other: button-press held at its stop, the peg seated in its
+hole -- a steep CONTINUOUS sensitivity of the reference computation, not a discrete decision), "on a branch" has no meaning; the
+device's outcome must then be indistinguishable from one more sample of the cloud: no farther from its nearest oracle outcome than
+the oracle's own outcomes are from theirs (reported as branch -2, tests/test_gpu_fullsize.py::_in_cloud).  Every such step is reported with the number of branches and the one
+the device took (stdout with -rA, gpurun_out/policy200_branches_<backend>.txt; committed under profiles/); a deviation that matches
+no oracle branch fails however small it is."""
 import os
 
 import numpy as np
@@ -23,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _replay(lib, task, backend):
-    from tests.test_gpu_fullsize import _oracle_response
+    from tests.test_gpu_fullsize import _device_branch
     G = dict(golden(f"trace_policy200_{task}_seed42.npz"))
     env = make_env(lib, task, n=1, precision="fp64")
     ctx = env.ctx
@@ -44,20 +50,18 @@ def _replay(lib, task, backend):
         if eo < tol_obs and er < tol_rew:
             continue
         state["mocap"], state["ctrl"] = ctx.read(0, "mocap"), ctx.read(0, "ctrl")          # (what the five substeps of this step used)
-        # (such states are two-branched: most 1e-12 perturbations change nothing, some flip a contact and move the answer by 1e-4 --
-        #  ten probes, so that the branch the device took is seen)
-        rq, _ = _oracle_response(ctx, 0, task, state, trials=10)
-        lim_o = min(max(tol_obs, 10 * rq), 1e-3)
-        lim_r = min(max(tol_rew, 10 * rq * 100), 2e-2)          # (rewards have slopes of up to ~1e2 per metre)
-        (relaxed if (eo < lim_o and er < lim_r) else bad).append((t, float(eo), float(er), float(rq)))
+        # which outcome of the reference computation did the device produce?  (re-runs the device's five substeps from `state` on their
+        # own; the next trip of the loop re-synchronises the env anyway)
+        k, nb, dq, eps = _device_branch(ctx, 0, task, state)
+        (relaxed if (k != -1 and eo < 1e-3 and er < 2e-2) else bad).append((t, float(eo), float(er), nb, k, dq, eps))
     st = env.status()
     env.close()
-    lines = [f"{task:28s} {len(relaxed):3d} of {nsteps} steps relaxed, {len(bad)} unexplained"] + \
-            [f"    step {t:3d}  obs err {eo:.2e}  reward err {er:.2e}  oracle response to 1e-12: {rq:.2e}" for t, eo, er, rq in relaxed + bad]
+    lines = [f"{task:28s} {len(relaxed):3d} of {nsteps} steps over the limit: on a branch of the oracle (k >= 0) or inside its cloud of outcomes (k = -2); {len(bad)} on none"] + \
+            [f"    step {t:3d}  obs err {eo:.2e}  reward err {er:.2e}  oracle branches {nb}  device on branch {k} at {dq:.1e}  (eps {eps:g})" for t, eo, er, nb, k, dq, eps in relaxed + bad]
     print("\n".join(lines))
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", f"policy200_relaxed_{backend}.txt"), "a") as f:
+        with open(os.path.join(ROOT, "gpurun_out", f"policy200_branches_{backend}.txt"), "a") as f:
             f.write("\n".join(lines) + "\n")
     except OSError:
         pass

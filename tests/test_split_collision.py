@@ -74,7 +74,8 @@ def test_split_collision_with_the_eager_final_forward(hostsim):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["fp64", "fp32"])
-def test_split_collision_matches_the_fused_kernel_on_the_gpu(gpulib, precision):
+def test_split_collision_matches_the_fused_kernel_on_the_gpu(gpulib_split, precision):
+    gpulib = gpulib_split          # (built with -DMW_SPLIT_COLLISION; the default library refuses the option)
     fused = _rollout(gpulib, False, precision, 60, nenv=64)
     split = _rollout(gpulib, True, precision, 60, nenv=64)
     # one step from identical states the two paths agree to rounding; over a chaotic rollout only while no contact has amplified it

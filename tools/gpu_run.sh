@@ -25,8 +25,8 @@ job() {
     for r in $(seq $rounds); do for v in "$@"; do MW_LIB=$v timeout 400 python bench.py $args >> $O/$v.txt 2>&1; done; done
     for v in "$@"; do echo "$v: $(summ $O/$v.txt)"; done | tee $O/summary.txt;;
   env)
-    for r in $(seq $rounds); do for v in "$@"; do env $v MW_VERBOSE=1 timeout 400 python bench.py $args >> "$O/$v.txt" 2>&1; done; done
-    for v in "$@"; do echo "$v: $(summ "$O/$v.txt") | $(grep -h 'lanes per workgroup' "$O/$v.txt" | head -1)"; done | tee $O/summary.txt;;
+    for r in $(seq $rounds); do for v in "$@"; do f=$(echo "$v" | tr '/ ' '__'); env $v MW_VERBOSE=1 timeout 400 python bench.py $args >> "$O/$f.txt" 2>&1; done; done
+    for v in "$@"; do f=$(echo "$v" | tr '/ ' '__'); echo "$v: $(summ "$O/$f.txt") | $(grep -h 'lanes per workgroup' "$O/$f.txt" | head -1)"; done | tee $O/summary.txt;;
   ref)
     for r in $(seq $rounds); do
       (cd ab_ref && timeout 400 python bench.py $args) >> $O/ref.txt 2>&1
@@ -35,7 +35,7 @@ job() {
     for v in ref new; do echo "$v: $(summ $O/$v.txt)"; done | tee $O/summary.txt;;
   test)
     if [ $# -eq 0 ]; then set -- tests; fi
-    timeout ${TEST_TIMEOUT:-3000} python -m pytest "$@" -m gpu -x -q -p no:cacheprovider 2>&1 | tail -40 | tee $O/pytest_tail.txt;;
+    timeout ${TEST_TIMEOUT:-3000} python -m pytest "$@" -m gpu ${TEST_X--x} -q -p no:cacheprovider 2>&1 | tail -40 | tee $O/pytest_tail.txt;;
   mix)
     MW_LIB=${1:-libmwgpu_timing.so} timeout 900 python tools/mix_timing.py 2>&1 | tee $O/mix_timing.txt | tail -5;;
   *) echo "unknown job $cmd"; return 2;;
