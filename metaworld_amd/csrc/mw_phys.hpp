@@ -1712,7 +1712,14 @@ template <typename T>
 MW_STAGE_FN void substep(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     forward(e);
+#if defined(MW_STEP_FINE) && defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    MW_TICK(t_i0)
     integrate(e);
+    MW_TICK(t_i1)
+    e.I(e.lay().icount + 4 + 1) += (int)((t_i1 - t_i0) >> 4);          // step-level timers (-DMW_STEP_FINE): slot 1 = integrate
+#else
+    integrate(e);
+#endif
 }
 
 // mj_resetData

@@ -411,8 +411,17 @@ MW_HD void lane_step(const World<T>& w, int block, int thread, Scratchpad sp) {
     Info info;
     for (int k = 0; k < 4; k++) act[k] = (T)w.io.act[(size_t)gid * 4 + k];
     e.I(e.lay().icount + 3) = 0; e.I(e.lay().icount + IC_SOLVER_STALL) = 0;
+    MW_TICK(t_ls0)
     env_step(e, td, act, obs, &reward, &success, &info, w.full_forward != 0, w.reward_v1 != 0);
+    MW_TICK(t_ls05)
     step_outputs(w, e, gid, task, td, obs, reward, success, info);
+#if (defined(MW_SOLVE_FINE) || defined(MW_STEP_FINE)) && defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    MW_TICK(t_ls1)
+    e.I(e.lay().icount + 4) += (int)((t_ls1 - t_ls0) >> 4);          // slot 0 of the fine timers: the whole step of this wave
+#if defined(MW_STEP_FINE)
+    e.I(e.lay().icount + 4 + 4) += (int)((t_ls1 - t_ls05) >> 4);     // slot 4: step_outputs (wrappers, auto-reset, output stores)
+#endif
+#endif
 }
 
 // Split collision (narrow phase as batch-wide kernels between the lane kernels): measured 25-37 % SLOWER than the fused kernel

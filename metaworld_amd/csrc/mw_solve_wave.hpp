@@ -36,9 +36,12 @@
 namespace mw {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MW_NO_WAVE_SOLVER)
 // timing builds (-DMW_SOLVER_TIMING): the eight solver slots hold the phases of solve_impl (warm, Hasm, chol, MvJv, lsrch, update, counts);
-// with -DMW_SOLVE_FINE they hold the pieces of solve_wave instead: 0 setup loads, 1 coefficient pre-pass, 2 H rows, 3 Cholesky + solves,
+// with -DMW_SOLVE_FINE they hold the pieces of solve_wave instead: 0 the WHOLE lane_step (mw_runtime.hpp), 1 coefficient pre-pass, 2 H rows, 3 Cholesky + solves,
 // 4 apply (M x, J x), 5 line search, 6 update_constraint's block sweep, 7 J' f   (cycles / 16, every pass incl. the warm start)
-#if defined(MW_SOLVE_FINE) && defined(MW_SOLVER_TIMING)
+#if defined(MW_STEP_FINE) && defined(MW_SOLVER_TIMING)          // (the slots belong to the step-level timers: mw_runtime.hpp lane_step)
+#define SW_FINE(slot, t0, t1)
+#define SW_COARSE(x)
+#elif defined(MW_SOLVE_FINE) && defined(MW_SOLVER_TIMING)
 #define SW_FINE(slot, t0, t1) if (on) { rv.I(L.icount + 4 + (slot)) += (int)(((t1) - (t0)) >> 4); }
 #define SW_COARSE(x)
 #else
@@ -258,35 +261,34 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                     }
                 };
                 {
+                    // one pass over the rows: the scratchpad rows eight at a time (all reads of a batch in flight together; a dependent
+                    // batch costs one LDS round trip whatever its width), the rows beyond it from the column store sixteen at a time.  The
+                    // last batch of either kind is padded with repeats of its last row, masked out in row_term (`ok`).
                     const int nl = nm < lds_rows ? nm : lds_rows;
-                    int r = 0;
-                    for (; r + 4 <= nl; r += 4) {          // scratchpad rows, four at a time
-                        T tc[4], tj[4], tj16[4];
+                    for (int r = 0; r < nl; r += 8) {
+                        T tc[8], tj[8], tj16[8];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            MW_LDS T* p = rv.lds + rv.S(r + q, 0) * stride;
+                        for (int q = 0; q < 8; q++) {
+                            MW_LDS T* p = rv.lds + rv.S(r + q < nl ? r + q : nl - 1, 0) * stride;
                             tc[q] = p[SR_JV * stride]; tj[q] = p[(SR_N + kd) * stride];
                             tj16[q] = BORDER ? p[(SR_N + 16) * stride] : T(0);
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; q++) row_term(r + q, tc[q], tj[q], tj16[q]);
+                        for (int q = 0; q < 8; q++)
+                            if (r + q < nl) row_term(r + q, tc[q], tj[q], tj16[q]);          // (wave-uniform)
                     }
-                    for (; r < nl; r++) {
-                        MW_LDS T* p = rv.lds + rv.S(r, 0) * stride;
-                        row_term(r, p[SR_JV * stride], p[(SR_N + kd) * stride], BORDER ? p[(SR_N + 16) * stride] : T(0));
-                    }
-                    for (; r + 4 <= nm; r += 4) {          // rows beyond the scratchpad: column store, four at a time (twelve loads in flight, not one)
-                        T tc[4], tj[4], tj16[4];
+                    for (int r = nl; r < nm; r += 16) {          // (sixteen rows per trip: a trip is one L2 round trip whatever its width)
+                        T tc[16], tj[16], tj16[16];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            tc[q] = EX(rv, r + q, sr_slot(SR_JV)); tj[q] = EJ(rv, r + q, kd);
-                            tj16[q] = BORDER ? T(EJ(rv, r + q, 16)) : T(0);
+                        for (int q = 0; q < 16; q++) {
+                            const int rr = r + q < nm ? r + q : nm - 1;
+                            tc[q] = EX(rv, rr, sr_slot(SR_JV)); tj[q] = EJ(rv, rr, kd);
+                            tj16[q] = BORDER ? T(EJ(rv, rr, 16)) : T(0);
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; q++) row_term(r + q, tc[q], tj[q], tj16[q]);
+                        for (int q = 0; q < 16; q++)
+                            if (r + q < nm) row_term(r + q, tc[q], tj[q], tj16[q]);
                     }
-                    for (; r < nm; r++)
-                        row_term(r, EX(rv, r, sr_slot(SR_JV)), EJ(rv, r, kd), BORDER ? T(EJ(rv, r, 16)) : T(0));
                 }
                 MW_TICK(t_rows)
                 SW_COARSE(if (on) { MW_TOCK(rv, L, 1, t_0, t_rows) })
@@ -467,52 +469,38 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                 SW_FINE(6, t_4, t_uc)
                 // J' f, dof per lane: every lane of the block reads the row's force (one address: an LDS broadcast) and its own entry
                 const int ne = go ? nefc : 0, nm = blk_max4(ne), nl = nm < lds_rows ? nm : lds_rows;
-                // (replica k takes the row quadruples k, k + R, ...; the partial sums meet in rep_sum)
+                // (replica k takes the row batches k, k + R, ...; the partial sums meet in rep_sum; batches as in the H pass: eight
+                //  scratchpad rows / sixteen column-store rows per trip, the last one padded and masked)
                 T q = 0, q16 = 0;
-                int r = 4 * rep;
-                for (; r + 4 <= nl; r += 4 * R) {
-                    T tf[4], tj[4], tj16[4];
+                for (int r = 8 * rep; r < nl; r += 8 * R) {
+                    T tf[8], tj[8], tj16[8];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        MW_LDS T* p = rv.lds + rv.S(r + u, 0) * stride;
+                    for (int u = 0; u < 8; u++) {
+                        MW_LDS T* p = rv.lds + rv.S(r + u < nl ? r + u : nl - 1, 0) * stride;
                         tf[u] = p[SR_FORCE * stride]; tj[u] = p[(SR_N + kd) * stride];
                         tj16[u] = BORDER ? p[(SR_N + 16) * stride] : T(0);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const bool in = r + u < ne && tf[u] != 0;
+                    for (int u = 0; u < 8; u++) {
+                        const bool in = r + u < nl && r + u < ne && tf[u] != 0;
                         q += in ? tj[u] * tf[u] : T(0);
                         if (BORDER) q16 += in ? tj16[u] * tf[u] : T(0);
                     }
                 }
-                // the rows left over: fewer than four at the end of the scratchpad (singly), then the ones in the column store, quadruples first
-                const int nq4 = nl & ~3, ncol = nm - nl;
-                for (r = nq4 + rep; r < nl; r += R) {
-                    MW_LDS T* p = rv.lds + rv.S(r, 0) * stride;
-                    const T f = p[SR_FORCE * stride], jj = p[(SR_N + kd) * stride], jj16 = BORDER ? p[(SR_N + 16) * stride] : T(0);
-                    const bool in = r < ne && f != 0;
-                    q += in ? jj * f : T(0);
-                    if (BORDER) q16 += in ? jj16 * f : T(0);
-                }
-                for (r = nl + 4 * rep; r + 4 <= nm; r += 4 * R) {
-                    T tf[4], tj[4], tj16[4];
+                for (int r = nl + 16 * rep; r < nm; r += 16 * R) {
+                    T tf[16], tj[16], tj16[16];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        tf[u] = EX(rv, r + u, 5); tj[u] = EJ(rv, r + u, kd);
-                        tj16[u] = BORDER ? T(EJ(rv, r + u, 16)) : T(0);
+                    for (int u = 0; u < 16; u++) {
+                        const int rr = r + u < nm ? r + u : nm - 1;
+                        tf[u] = EX(rv, rr, 5); tj[u] = EJ(rv, rr, kd);
+                        tj16[u] = BORDER ? T(EJ(rv, rr, 16)) : T(0);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const bool in = r + u < ne && tf[u] != 0;
+                    for (int u = 0; u < 16; u++) {
+                        const bool in = r + u < nm && r + u < ne && tf[u] != 0;
                         q += in ? tj[u] * tf[u] : T(0);
                         if (BORDER) q16 += in ? tj16[u] * tf[u] : T(0);
                     }
-                }
-                for (r = nl + (ncol & ~3) + rep; r < nm; r += R) {
-                    const T f = EX(rv, r, 5), jj = EJ(rv, r, kd), jj16 = BORDER ? T(EJ(rv, r, 16)) : T(0);
-                    const bool in = r < ne && f != 0;
-                    q += in ? jj * f : T(0);
-                    if (BORDER) q16 += in ? jj16 * f : T(0);
                 }
                 q = rep_sum(q, R);
                 if (BORDER) q16 = rep_sum(q16, R);
@@ -536,7 +524,6 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
             SW_COARSE(if (it < 0 && on) { MW_TOCK(rv, L, 0, t_0, t_5) })
         }
         SW_COARSE(if (on) { MW_TOCK(rv, L, 0, t_a, t_b) })
-        SW_FINE(0, t_a, t_b)
         // ---- results: qacc, qfrc_constraint, the iteration count, the stall count; efc_force of the rows kept in the scratchpad -> efcX ----
         if (on && rep == 0) {
             if (dof) { rv.R(L.qacc + ri) = qa; rv.R(L.qfrc_c + ri) = qfc; }

@@ -1308,10 +1308,16 @@ MW_HD void env_step(const Env<T> e, const TaskDesc<T>& td, const T* act, T* obs3
     // ones whose reward does (same wave time: the wave executes it anyway; no persistent state is touched), so that its
     // non-inlined stages are entered by every live lane of the wave or by none.
     if (mw_any(full_forward || task_touches(td.kind))) forward_dynamics(e);
+    MW_TICK(t_o0)
     get_obs(e, td, obs39);
     clip_obs(td, obs39);
+    MW_TICK(t_o1)
     if (reward_v1) task_evaluate_v1(e, td, obs39, act, reward, success, info);          // (wave-uniform: one flag per context)
     else task_evaluate(e, td, obs39, act, reward, success, info);
+#if defined(MW_STEP_FINE) && defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    MW_TICK(t_o2)          // step-level timers (-DMW_STEP_FINE): slot 2 = get_obs + clip, slot 3 = task_evaluate
+    e.I(e.lay().icount + 4 + 2) += (int)((t_o1 - t_o0) >> 4); e.I(e.lay().icount + 4 + 3) += (int)((t_o2 - t_o1) >> 4);
+#endif
 }
 
 }  // namespace mw

@@ -234,7 +234,7 @@ def packed_model(model_name, maxcon=None, maxefc=None, v1=False, reloc_bodies=No
                     if b not in reloc:
                         reloc.append(b)
     pk = pack_model(compiled_model(model_name), probes, reloc_bodies=reloc, maxcon=maxcon, maxefc=maxefc, **kw)
-    for k in ("step_ms_lpb4", "step_ms_lpb8"):          # measured step time of the scene at 4 / 8 lanes per workgroup: the runtime's
+    for k in ("step_ms_lpb4", "step_ms_lpb8", "lanes_per_block"):          # (lanes_per_block: an explicit assignment, experiments) measured step time of the scene at 4 / 8 lanes per workgroup: the runtime's
         if k in caps:                                     # lanes-per-workgroup assignment ranks the groups by it (mw_runtime.hpp finalize)
             pk["options"][k] = caps[k]
     return pk, roles, reloc
