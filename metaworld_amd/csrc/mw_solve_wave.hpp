@@ -78,6 +78,7 @@ template <typename T> __device__ inline T rep_sum(T v, int R) {
     if (R == 4) v += __shfl_xor(v, 16);
     return v;
 }
+constexpr int REMAP_MIN_ROWS = 40;          // solve_wave re-assigns the blocks of finished environments only when an iterating one has at least this many rows
 __device__ inline int blk_max4(int v) {          // maximum of the four blocks' (block-uniform) values, wave-uniform
     const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
     const int ab = a > b ? a : b, cd = c > d ? c : d;
@@ -103,61 +104,87 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
         // blocks work for each of them: everything that is per dof (vectors, M x, the Newton direction -- the matrix instruction
         // processes four blocks in the time of one anyway) is computed redundantly with identical bits, the row / block sweeps are
         // split over the 16 R lanes (wide lane index w), their totals take one more exchange between the replicas (rep_sum)
-        const int left = nslot - g0, R = left == 1 ? 4 : (left == 2 ? 2 : 1), npe = 4 / R;
-        const int slot = g0 + (rb & (npe - 1)), rep = rb / npe, w = 16 * rep + ri, W = 16 * R;
-        const bool on = slot < nslot;
-        const Env<T> rv = env_view(e, on ? slot : e.slot);          // (an idle block looks at its own thread's environment and never stores)
+        // The assignment can CHANGE during the solve (remap, below): when all but one or two environments of the group have converged, their
+        // blocks become replicas of the ones that are still iterating.
+        const int left = nslot - g0;
+        int R = left == 1 ? 4 : (left == 2 ? 2 : 1), npe = 4 / R;
+        int smap[4];                                   // (wave-uniform) slot of the environment block b works for, -1: none
+#pragma unroll
+        for (int b = 0; b < 4; b++) smap[b] = g0 + (b & (npe - 1)) < nslot ? g0 + (b & (npe - 1)) : -1;
+        int slot, rep, w, W, nefc, nblk, nmax, bmax;
+        bool on;
+        Env<T> rv = e;
         MW_TICK(t_a)
-        const int nefc = on ? (int)rv.I(L.icount + 1) : 0, nblk = on ? (int)rv.I(L.icount + IC_NBLK) : 0;
-        const int nmax = blk_max4(nefc), bmax = blk_max4(nblk);
-        // ---- once per solve: row ri of M, the border, the three input vectors, M in the accumulator layout ----
+        // ---- once per solve (and again after a remap): row ri of M, the border, the input vectors, M in the accumulator layout ----
         T Mrow[16], Mc16 = 0, M16row[16], m1616 = 1;
-        {
-            T mv[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) mv[k] = rv.R(L.qM + kd * nv + (k < nv16 ? k : 0));
-#pragma unroll
-            for (int k = 0; k < 16; k++) Mrow[k] = (dof && k < nv16) ? mv[k] : T(0);
-        }
-        if (BORDER) {
-            const T c16 = rv.R(L.qM + kd * nv + 16), d16 = rv.R(L.qM + 16 * nv + 16);
-            T mv[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) mv[k] = rv.R(L.qM + 16 * nv + k);
-#pragma unroll
-            for (int k = 0; k < 16; k++) M16row[k] = mv[k];
-            Mc16 = dof ? c16 : T(0); m1616 = d16;
-        }
         T qs, sm, ws, qs16 = 0, sm16 = 0, ws16 = 0;
-        {
-            const T a = rv.R(L.qacc_smooth + kd), b = rv.R(L.smooth + kd), c = rv.R(L.warm + kd);
-            qs = dof ? a : T(0); sm = dof ? b : T(0); ws = dof ? c : T(0);
-            if (BORDER) { qs16 = rv.R(L.qacc_smooth + 16); sm16 = rv.R(L.smooth + 16); ws16 = rv.R(L.warm + 16); }
-        }
-        // lane (rb, ri), register 4 blk + v  =  M_blk[4 rb + v][ri]  (identity outside nv): all sixteen loads issued together
-        mw_f16v accM;
+        mw_f16v accM;                                  // lane (rb, ri), register 4 blk + v  =  M_blk[4 rb + v][ri]  (identity outside nv)
         HT hbM = 0, etaM = 1;                          // border of the Hessian: H[16][ri], H[16][16]
-        {
-            T mv[16];
-            bool ins[16];
+        auto setup = [&]() __attribute__((always_inline)) {
+            const int mine = rb == 0 ? smap[0] : (rb == 1 ? smap[1] : (rb == 2 ? smap[2] : smap[3]));
+            on = mine >= 0;
+            slot = on ? mine : e.slot;                 // (an idle block looks at its own thread's environment and never stores)
+            rep = rb / npe; w = 16 * rep + ri; W = 16 * R;
+            rv = env_view(e, slot);
+            nefc = on ? (int)rv.I(L.icount + 1) : 0; nblk = on ? (int)rv.I(L.icount + IC_NBLK) : 0;
+            nmax = blk_max4(nefc); bmax = blk_max4(nblk);
+            {
+                T mv[16];
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int blk = q >> 2, v = q & 3, s2 = g0 + (blk & (npe - 1));
-                const bool on2 = s2 < nslot;
-                const int mrow = 4 * rb + v, hi = mrow > ri ? mrow : ri, lo = mrow > ri ? ri : mrow;
-                ins[q] = on2 && hi < nv16;
-                const int idx = L.qM + (ins[q] ? hi * nv + lo : 0);
-                mv[q] = ((MW_GLOBAL T*)(e.col + ((on2 ? s2 : e.slot) - e.slot)))[(unsigned)idx * e.stride];
+                for (int k = 0; k < 16; k++) mv[k] = rv.R(L.qM + kd * nv + (k < nv16 ? k : 0));
+#pragma unroll
+                for (int k = 0; k < 16; k++) Mrow[k] = (dof && k < nv16) ? mv[k] : T(0);
             }
+            if (BORDER) {
+                const T c16 = rv.R(L.qM + kd * nv + 16), d16 = rv.R(L.qM + 16 * nv + 16);
+                T mv[16];
 #pragma unroll
-            for (int q = 0; q < 16; q++) accM[q] = ins[q] ? (HT)mv[q] : ((4 * rb + (q & 3)) == ri ? HT(1) : HT(0));
-            if (BORDER) { hbM = on ? (HT)Mc16 : HT(0); etaM = on ? (HT)m1616 : HT(1); }
-        }
+                for (int k = 0; k < 16; k++) mv[k] = rv.R(L.qM + 16 * nv + k);
+#pragma unroll
+                for (int k = 0; k < 16; k++) M16row[k] = mv[k];
+                Mc16 = dof ? c16 : T(0); m1616 = d16;
+            }
+            {
+                const T a = rv.R(L.qacc_smooth + kd), b = rv.R(L.smooth + kd), c = rv.R(L.warm + kd);
+                qs = dof ? a : T(0); sm = dof ? b : T(0); ws = dof ? c : T(0);
+                if (BORDER) { qs16 = rv.R(L.qacc_smooth + 16); sm16 = rv.R(L.smooth + 16); ws16 = rv.R(L.warm + 16); }
+            }
+            {          // all sixteen loads issued together
+                T mv[16];
+                bool ins[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int blk = q >> 2, v = q & 3, s2 = smap[blk];
+                    const bool on2 = s2 >= 0;
+                    const int mrow = 4 * rb + v, hi = mrow > ri ? mrow : ri, lo = mrow > ri ? ri : mrow;
+                    ins[q] = on2 && hi < nv16;
+                    const int idx = L.qM + (ins[q] ? hi * nv + lo : 0);
+                    mv[q] = ((MW_GLOBAL T*)(e.col + ((on2 ? s2 : e.slot) - e.slot)))[(unsigned)idx * e.stride];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++) accM[q] = ins[q] ? (HT)mv[q] : ((4 * rb + (q & 3)) == ri ? HT(1) : HT(0));
+                if (BORDER) { hbM = on ? (HT)Mc16 : HT(0); etaM = on ? (HT)m1616 : HT(1); }
+            }
+        };
+        setup();
         // ---- state of the solve, one dof per lane ----
         T qa = 0, Ma = 0, qfc = 0, qa16 = 0, Ma16 = 0, qfc16 = 0;
         T cost = 0, cs = 0;
         bool act = on, redo = false;
         int niter = 0, nstall = 0;
+        // results of an environment: qacc, qfrc_constraint, the iteration count, the stall count; efc_force of the rows kept in the scratchpad -> efcX
+        auto write_out = [&](bool who) __attribute__((always_inline)) {
+            if (who) {
+                if (dof) { rv.R(L.qacc + ri) = qa; rv.R(L.qfrc_c + ri) = qfc; }
+                if (BORDER && ri == 0) { rv.R(L.qacc + 16) = qa16; rv.R(L.qfrc_c + 16) = qfc16; }
+                if (ri == 0) {
+                    rv.I(L.icount + 2) = niter;
+                    if (nstall) rv.I(L.icount + IC_SOLVER_STALL) += nstall;
+                }
+                const int nl = nefc < lds_rows ? nefc : lds_rows;
+                for (int i = ri; i < nl; i += 16) EX(rv, i, 5) = rv.lds[rv.S(i, SR_FORCE) * stride];
+            }
+        };
         MW_TICK(t_b)
         for (int it = -3; it < max_iter; it++) {
             MW_TICK(t_0)
@@ -172,10 +199,32 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                 if (BORDER) x16 = it == -2 ? ws16 : qs16;
             } else {
                 // ---- gradient and convergence test ----
-                const T g = dof ? Ma - sm - qfc : T(0), g16 = BORDER ? Ma16 - sm16 - qfc16 : T(0);
+                T g = dof ? Ma - sm - qfc : T(0), g16 = BORDER ? Ma16 - sm16 - qfc16 : T(0);
                 const T gn = blk_sum_t(g * g) + g16 * g16;
                 if (act && scale * mw_sqrt(gn) < tol) act = false;
                 if (!mw_any(act)) break;
+                // ---- REMAP: one or two environments are left and they are big -> the blocks of the finished ones become their replicas ----
+                {
+                    const unsigned long long am = __builtin_amdgcn_ballot_w64(act && rep == 0 && ri == 0);          // one bit per iterating environment, at lane 16 b of its owner block b
+                    const int nact = __builtin_popcountll(am), newR = nact == 1 ? 4 : (nact == 2 ? 2 : 1);
+                    if (newR > R && blk_max4(act ? nefc : 0) >= REMAP_MIN_ROWS) {
+                        write_out(on && rep == 0 && !act);          // (the finished environments hand in their results now: their blocks get new work)
+                        MW_SYNC();
+                        const int b0 = __builtin_ctzll(am) >> 4, b1 = nact == 2 ? (__builtin_ctzll(am & (am - 1)) >> 4) : b0;
+                        const int s0 = __builtin_amdgcn_readlane(slot, 16 * b0), s1 = __builtin_amdgcn_readlane(slot, 16 * b1);
+                        const int from = 16 * ((newR == 4 || !(rb & 1)) ? b0 : b1) + ri;          // the lane that holds this lane's dof of the adopted environment
+                        qa = __shfl(qa, from); Ma = __shfl(Ma, from); qfc = __shfl(qfc, from); cost = __shfl(cost, from);
+                        niter = __shfl(niter, from); nstall = __shfl(nstall, from);
+                        if (BORDER) { qa16 = __shfl(qa16, from); Ma16 = __shfl(Ma16, from); qfc16 = __shfl(qfc16, from); }
+                        act = true;
+                        R = newR; npe = 4 / R;
+                        smap[0] = s0; smap[1] = newR == 4 ? s0 : s1; smap[2] = s0; smap[3] = smap[1];
+                        setup();
+                        // (nstall / niter are reported once, by the new owner block: rep == 0; the helpers' copies are never written)
+                        g = dof ? Ma - sm - qfc : T(0);          // the gradient of the adopted environment (same bits as its owner's)
+                        if (BORDER) g16 = Ma16 - sm16 - qfc16;
+                    }
+                }
                 go = act;
                 // ---- Newton direction s = -H^-1 g (newton_direction_wave, mw_phys.hpp: the comments there) ----
                 // coefficients of the rank-1 terms, block per lane, parked in the rows' JV / AREF fields (dead here)
@@ -215,8 +264,13 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                 MW_SYNC();
                 MW_TICK(t_pre)
                 SW_FINE(1, t_0, t_pre)
-                mw_f16v acc = accM;
-                HT hb = hbM, eta = etaM;
+                // REPLICAS share the pass over the rows: replica k takes the row batches k, k + R, ...; its matrix (the accumulator registers
+                // of ITS block) starts from M in replica 0 and from zero in the others, and the partial matrices of an environment are
+                // added afterwards -- inside every lane: matrix b lives in registers 4 b .. 4 b + 3 of all 64 lanes
+                mw_f16v acc;
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[q] = (q >> 2) / npe == 0 ? accM[q] : HT(0);
+                HT hb = rep == 0 ? hbM : HT(0), eta = rep == 0 ? etaM : HT(0);
                 const int ne = go ? nefc : 0, nm = blk_max4(ne);
                 auto cone_tail = [&](int r, bool flag, const auto& rows) {          // wave-uniform call; lanes with flag set finish the cone block that ends at row r
                     HT A0 = 0, B0 = 0, A1 = 0, B1 = 0, h0 = 0, e0 = 0;
@@ -247,16 +301,16 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A1, B1, acc, 0, 0, 0);
                     if (BORDER) { hb += h0; eta += e0; }
                 };
-                auto row_term = [&](int r, T t_c, T t_j, T t_j16) {
-                    const bool in = r < ne;
+                auto row_term = [&](int r, bool valid, bool lds_site, T t_c, T t_j, T t_j16) {          // (called by every lane of the wave: matrix instructions inside)
+                    const bool in = valid && r < ne;
                     const HT cf = in ? (HT)t_c : HT(0), jr = (in && dof) ? (HT)t_j : HT(0), j16 = (BORDER && in) ? (HT)t_j16 : HT(0);
                     const HT A = fabsf(cf) * jr;
                     acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A, jr, acc, 0, 0, 0);
                     if (BORDER) { hb += A * j16; eta += fabsf(cf) * j16 * j16; }
                     const bool flag = cf < HT(0);
-                    if (mw_any(flag)) {          // (r is wave-uniform: so is the place of the block's rows, which end at r and are at most four)
-                        if (r < lds_rows) cone_tail(r, flag, Rows<T, 1>{rv});
-                        else if (r - 3 >= lds_rows) cone_tail(r, flag, Rows<T, 2>{rv});
+                    if (mw_any(flag)) {          // (where the block's rows -- they end at r and are at most four -- live is decided for the whole wave)
+                        if (lds_site) cone_tail(r, flag, Rows<T, 1>{rv});
+                        else if (!mw_any(flag && r - 3 < lds_rows)) cone_tail(r, flag, Rows<T, 2>{rv});
                         else cone_tail(r, flag, Rows<T, 0>{rv});
                     }
                 };
@@ -265,7 +319,8 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                     // batch costs one LDS round trip whatever its width), the rows beyond it from the column store sixteen at a time.  The
                     // last batch of either kind is padded with repeats of its last row, masked out in row_term (`ok`).
                     const int nl = nm < lds_rows ? nm : lds_rows;
-                    for (int r = 0; r < nl; r += 8) {
+                    for (int base = 0; base < nl; base += 8 * R) {
+                        const int r = base + 8 * rep;
                         T tc[8], tj[8], tj16[8];
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
@@ -275,9 +330,10 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                         }
 #pragma unroll
                         for (int q = 0; q < 8; q++)
-                            if (r + q < nl) row_term(r + q, tc[q], tj[q], tj16[q]);          // (wave-uniform)
+                            if (base + q < nl) row_term(r + q, r + q < nl, true, tc[q], tj[q], tj16[q]);          // (wave-uniform skip of the padding)
                     }
-                    for (int r = nl; r < nm; r += 16) {          // (sixteen rows per trip: a trip is one L2 round trip whatever its width)
+                    for (int base = nl; base < nm; base += 16 * R) {          // (sixteen rows per trip: a trip is one L2 round trip whatever its width)
+                        const int r = base + 16 * rep;
                         T tc[16], tj[16], tj16[16];
 #pragma unroll
                         for (int q = 0; q < 16; q++) {
@@ -287,8 +343,17 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                         }
 #pragma unroll
                         for (int q = 0; q < 16; q++)
-                            if (r + q < nm) row_term(r + q, tc[q], tj[q], tj16[q]);
+                            if (base + q < nm) row_term(r + q, r + q < nm, false, tc[q], tj[q], tj16[q]);
                     }
+                }
+                if (R > 1) {          // the partial matrices of an environment -> their sum, in every replica's registers (same bits: a + b = b + a)
+                    mw_f16v t = acc;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int blk = q >> 2, v = q & 3;
+                        acc[q] = R == 2 ? t[q] + t[4 * (blk ^ 2) + v] : (t[4 * (blk & 1) + v] + t[4 * ((blk & 1) ^ 2) + v]) + (t[4 * ((blk & 1) ^ 1) + v] + t[4 * ((blk & 1) ^ 3) + v]);
+                    }
+                    if (BORDER) { hb = rep_sum(hb, R); eta = rep_sum(eta, R); }
                 }
                 MW_TICK(t_rows)
                 SW_COARSE(if (on) { MW_TOCK(rv, L, 1, t_0, t_rows) })
@@ -524,17 +589,7 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
             SW_COARSE(if (it < 0 && on) { MW_TOCK(rv, L, 0, t_0, t_5) })
         }
         SW_COARSE(if (on) { MW_TOCK(rv, L, 0, t_a, t_b) })
-        // ---- results: qacc, qfrc_constraint, the iteration count, the stall count; efc_force of the rows kept in the scratchpad -> efcX ----
-        if (on && rep == 0) {
-            if (dof) { rv.R(L.qacc + ri) = qa; rv.R(L.qfrc_c + ri) = qfc; }
-            if (BORDER && ri == 0) { rv.R(L.qacc + 16) = qa16; rv.R(L.qfrc_c + 16) = qfc16; }
-            if (ri == 0) {
-                rv.I(L.icount + 2) = niter;
-                if (nstall) rv.I(L.icount + IC_SOLVER_STALL) += nstall;
-            }
-            const int nl = nefc < lds_rows ? nefc : lds_rows;
-            for (int i = ri; i < nl; i += 16) EX(rv, i, 5) = rv.lds[rv.S(i, SR_FORCE) * stride];
-        }
+        write_out(on && rep == 0);
         MW_SYNC();
     }
 }
