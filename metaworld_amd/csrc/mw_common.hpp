@@ -130,7 +130,7 @@ constexpr int CELL_N = 6 * CELL_GRID * CELL_GRID;
 constexpr int CELL_K = 8;         // vertices of a cell's list stored at the cell's fixed place (Model::mesh_cellxyz); longer lists continue in Model::mesh_ovfxyz
 constexpr int TLS_SLOTS = 60;    // thread-private scratchpad slots of the narrow phase: two polygons of up to 10 vertices (box-box face clipping)
 constexpr int IC_NBLK = 18;      // icount slot: number of constraint blocks (single rows / contact cones)
-constexpr int IC_SIZE = 26;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand, 23 solver stalls, 24 / 25 split collision
+constexpr int IC_SIZE = 26;      // ints in icount: 0 ncon, 1 nefc, 2 niter, 3 flags, 4..17 phase timers (timing builds), 18 nblk, 19 dynamics valid, 20 / 21 demand, 22 Euler acceleration ready, 23 solver stalls, 24 / 25 split collision
 constexpr int IC_NCAND = 24;     // icount slot (split collision, mw_split.hpp): candidate pairs the mid-phase kernel listed for this environment (L.ipair / L.iitem)
 constexpr int IC_PENDING = 25;   // icount slot (split collision): 1 = the step waits for the lazy final dynamics (its narrow phase is on the way)
 constexpr int IC_DYN_VALID = 19;  // icount slot: 1 = contacts / constraint rows / solver output belong to the CURRENT qpos (see env_step)
@@ -142,6 +142,7 @@ constexpr int EFC_ISTRIDE = 5;   // type, id, state, first and last dof with a n
 //   8      CANARY: the copies of a redundantly computed value held by the sub-lanes of one environment disagreed (sub_disagree)
 //  16      (MW_BOUNDS debug builds) a column-store / scratchpad index was out of range
 enum { ST_ROW_OVERFLOW = 1, ST_CON_OVERFLOW = 2, ST_UNSTABLE = 4, ST_DIVERGED = 8, ST_OOB = 16 };
+constexpr int IC_EULER_READY = 22;    // icount slot: 1 = L.search holds the acceleration of the semi-implicit Euler step for the CURRENT solver output (solve_wave's finish); integrate consumes it
 constexpr int IC_SOLVER_STALL = 23;   // icount slot: line searches abandoned on a non-descent direction (this step)
 
 struct Sizes {

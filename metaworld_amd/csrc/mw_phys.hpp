@@ -1556,6 +1556,7 @@ MW_STAGE_FN void solve(const Env<T> e_) {
     CLayout& L = e.lay();
     const int nv = e.nv;
     e.I(L.icount + 2) = 0;
+    e.I(L.icount + IC_EULER_READY) = 0;          // (set again by solve_wave's finish for THIS solver output; a stale flag must not reach integrate)
     // WAVE-UNIFORM early exit: only when NO environment of the wave has a constraint row.  In a mixed wave the ones
     // without rows go through solve_impl as well (zero rows: qacc = qacc_smooth bit for bit, qfrc_constraint = 0), so that the
     // wave-cooperative Newton direction is entered under a full EXEC mask.  Every Sawyer scene has the mocap weld (nefc >= 6).
@@ -1683,6 +1684,34 @@ MW_HD void integrate_impl(const Env<T> e) {
         if (qa[k] >= 0) e.R(L.qpos + qa[k]) = qp[k] + h * qv[k];
 }
 
+// the same step when the solver has already solved (M + h B) a = qfrc_smooth + qfrc_constraint (solve_wave's finish, IC_EULER_READY):
+// warm start <- qacc, qvel += h a, qpos += h qvel; all loads first, then the stores
+template <typename T>
+MW_HD void integrate_ready(const Env<T> e) {
+    CModel<T>& m = e.model();
+    CLayout& L = e.lay();
+    const int nv = e.nv;
+    const T h = m.timestep;
+    constexpr int NV = MAX_NV;
+    T acc[NV], a[NV], qv[NV], qp[NV];
+    int qa[NV];
+    vec_load<T, NV>(e, L.qacc, nv, acc);
+    vec_load<T, NV>(e, L.search, nv, a);
+    vec_load<T, NV>(e, L.qvel, nv, qv);
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        qa[k] = k < nv ? m.dof_qposadr[k] : -1;
+        qp[k] = e.R(L.qpos + (qa[k] >= 0 ? qa[k] : 0));
+    }
+    vec_store<T, NV>(e, L.warm, nv, acc);
+#pragma unroll
+    for (int k = 0; k < NV; k++) qv[k] += h * a[k];
+    vec_store<T, NV>(e, L.qvel, nv, qv);
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        if (qa[k] >= 0) e.R(L.qpos + qa[k]) = qp[k] + h * qv[k];
+}
+
 // the part of mj_step after mj_forward: Euler step (integrate_impl) + the orientation of the free bodies + time
 template <typename T>
 MW_STAGE_FN void integrate(const Env<T> e_) {
@@ -1691,7 +1720,12 @@ MW_STAGE_FN void integrate(const Env<T> e_) {
     CLayout& L = e.lay();
     const int nv = m.sz.nv;
     const T h = m.timestep;
-    MW_NV_DISPATCH(nv, (integrate_impl<T, NVC>(e)))
+    // (wave-uniform in practice: solve() takes one path for the whole wave; mw_any keeps the branches convergent all the same)
+    const bool ready = e.I(L.icount + IC_EULER_READY) == 1;
+    if (ready) { e.I(L.icount + IC_EULER_READY) = 0; integrate_ready(e); }
+    if (mw_any(!ready)) {
+        if (!ready) { MW_NV_DISPATCH(nv, (integrate_impl<T, NVC>(e))) }
+    }
     for (int j = 0; j < m.sz.njnt; j++) {          // orientation of the free bodies: q <- q * exp(h w / 2)
         if (m.jnt_type[j] != J_FREE) continue;
         const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];

@@ -98,6 +98,7 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
     const T scale = 1 / (m.meaninertia * T(nv > 1 ? nv : 1)), tol = m.tolerance;
     const int max_iter = m.sz.iterations, max_ls = m.sz.ls_iterations;
     const int lds_rows = e.lds_rows, stride = e.lds_stride;
+    const bool euler_here = e.lds_rows * e.lds_w >= 256;          // room for the 16 x 16 transpose of finish() in the environment's scratchpad slice (not at 16 fp64 lanes per workgroup with the chains staged)
     const unsigned m0 = rb == 0 ? ~0u : 0u, m1 = rb == 1 ? ~0u : 0u, m2 = rb == 2 ? ~0u : 0u, m3 = rb == 3 ? ~0u : 0u;
     for (int g0 = 0; g0 < nslot; g0 += 4) {
         // REPLICAS: when the group of this pass holds only one or two environments (lpb = 1 / 2, or the tail of a larger workgroup), R = 4 / 2
@@ -172,8 +173,14 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
         T cost = 0, cs = 0;
         bool act = on, redo = false;
         int niter = 0, nstall = 0;
-        // results of an environment: qacc, qfrc_constraint, the iteration count, the stall count; efc_force of the rows kept in the scratchpad -> efcX
-        auto write_out = [&](bool who) __attribute__((always_inline)) {
+        // An environment that is through: its results -- qacc, qfrc_constraint, the iteration count, the stall count, efc_force of the rows
+        // kept in the scratchpad -> efcX -- and the acceleration of the semi-implicit Euler step, (M + h B) a = qfrc_smooth + qfrc_constraint
+        // (integrate_impl, mw_phys.hpp), which is solved HERE, rows of M + h B one per lane, instead of by every sub-lane of the environment
+        // on its own copy of the 120-entry triangle: right-looking Cholesky with the column's multipliers handed round by DPP broadcasts,
+        // forward substitution the same way, the factor transposed through the scratchpad (the rows are dead by now), backward
+        // substitution as a chain.  The operations and their order are chol_reg's / chol_solve_reg's (products subtracted in ascending
+        // k, no contraction): the same bits as integrate_impl computes.  integrate_impl finds the result in L.search (IC_EULER_READY).
+        auto finish = [&](bool who) __attribute__((always_inline)) {
             if (who) {
                 if (dof) { rv.R(L.qacc + ri) = qa; rv.R(L.qfrc_c + ri) = qfc; }
                 if (BORDER && ri == 0) { rv.R(L.qacc + 16) = qa16; rv.R(L.qfrc_c + 16) = qfc16; }
@@ -181,12 +188,87 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                     rv.I(L.icount + 2) = niter;
                     if (nstall) rv.I(L.icount + IC_SOLVER_STALL) += nstall;
                 }
-                const int nl = nefc < lds_rows ? nefc : lds_rows;
-                for (int i = ri; i < nl; i += 16) EX(rv, i, 5) = rv.lds[rv.S(i, SR_FORCE) * stride];
+                {
+                    const int nl = nefc < lds_rows ? nefc : lds_rows;
+                    for (int i = ri; i < nl; i += 16) EX(rv, i, 5) = rv.lds[rv.S(i, SR_FORCE) * stride];
+                }
+                MW_SYNC();
+              if (euler_here) {
+                const T h = m.timestep, dmp = m.dof_damping[kd];
+                T A[16], A16[16], a1616 = 1, inv_own = 1, inv16 = 1;
+#pragma unroll
+                for (int k = 0; k < 16; k++) A[k] = ri == k ? (dof ? Mrow[k] + h * dmp : T(1)) : Mrow[k];
+                if (BORDER) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) A16[k] = M16row[k];
+                    a1616 = m1616 + h * m.dof_damping[16];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const T sj = blk_bcast_t(A[j], j);
+                    const T ljj = mw_sqrt(sj < T(1e-15) ? T(1e-15) : sj), invj = T(1) / ljj;
+                    A[j] = ri == j ? ljj : A[j] * invj;
+                    inv_own = ri == j ? invj : inv_own;
+                    T l16j = 0;
+                    if (BORDER) { A16[j] = A16[j] * invj; l16j = A16[j]; }
+#pragma unroll
+                    for (int c = j + 1; c < 16; c++) {
+                        const T v = blk_bcast_t(A[j], c);
+                        A[c] -= A[j] * v;
+                        if (BORDER) A16[c] -= l16j * v;
+                    }
+                    if (BORDER) a1616 -= l16j * l16j;
+                }
+                if (BORDER) { const T l = mw_sqrt(a1616 < T(1e-15) ? T(1e-15) : a1616); inv16 = T(1) / l; }
+                // forward substitution: lane k's residual is final when its turn comes
+                T sres = dof ? sm + qfc : T(0), s16 = BORDER ? sm16 + qfc16 : T(0), yo = 0, xs[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const T xk = blk_bcast_t(sres * inv_own, k);
+                    xs[k] = xk;
+                    yo = ri == k ? xk : yo;
+                    sres -= A[k] * xk;
+                    if (BORDER) s16 -= A16[k] * xk;
+                }
+                const T x16 = BORDER ? s16 * inv16 * inv16 : T(0);          // (y16 = s16 inv16; x16 = y16 inv16)
+                // the factor transposed: Lt[k] = L[k][ri], through the environment's scratchpad slice (the rows are dead)
+                T Lt[16], A16i = 0;
+                {
+                    MW_LDS T* tp = rv.lds + e.lds_perm * stride;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) tp[(ri * 16 + k) * stride] = A[k];
+                    MW_SYNC();
+#pragma unroll
+                    for (int k = 0; k < 16; k++) Lt[k] = tp[(k * 16 + ri) * stride];
+                    if (BORDER) {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) A16i = ri == k ? A16[k] : A16i;
+                    }
+                }
+                // backward substitution: x_i = (y_i - sum_{k > i} L[k][i] x_k) / L[i][i], the sum in ascending k (the border last)
+                T xo = 0;
+#pragma unroll
+                for (int i = 15; i >= 0; i--) {
+                    T t = yo;
+#pragma unroll
+                    for (int k = i + 1; k < 16; k++) t -= Lt[k] * xs[k];
+                    if (BORDER) t -= A16i * x16;
+                    const T xi = blk_bcast_t(t * inv_own, i);
+                    xs[i] = xi;
+                    xo = ri == i ? xi : xo;
+                }
+                if (dof) rv.R(L.search + ri) = xo;
+                if (BORDER && ri == 0) rv.R(L.search + 16) = x16;
+                if (ri == 0) rv.I(L.icount + IC_EULER_READY) = 1;
+              }
             }
         };
         MW_TICK(t_b)
-        for (int it = -3; it < max_iter; it++) {
+        int it = -3;
+        for (;;) {          // (one trip per assignment of the blocks: the iteration loop leaves either for good or with a remap request)
+        bool want_remap = false;
+        unsigned long long remap_mask = 0ull;
+        for (; it < max_iter; it++) {
             MW_TICK(t_0)
             bool go;                                   // (block-uniform) this environment takes part in this pass
             T x, x16 = 0;                              // the vector of this pass: a candidate point (it < 0) or the search direction
@@ -203,27 +285,12 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                 const T gn = blk_sum_t(g * g) + g16 * g16;
                 if (act && scale * mw_sqrt(gn) < tol) act = false;
                 if (!mw_any(act)) break;
-                // ---- REMAP: one or two environments are left and they are big -> the blocks of the finished ones become their replicas ----
+                // ---- REMAP request: one or two environments are left and they are big -> the blocks of the finished ones become their
+                // replicas (below, after the finished ones have handed in their results) ----
                 {
                     const unsigned long long am = __builtin_amdgcn_ballot_w64(act && rep == 0 && ri == 0);          // one bit per iterating environment, at lane 16 b of its owner block b
                     const int nact = __builtin_popcountll(am), newR = nact == 1 ? 4 : (nact == 2 ? 2 : 1);
-                    if (newR > R && blk_max4(act ? nefc : 0) >= REMAP_MIN_ROWS) {
-                        write_out(on && rep == 0 && !act);          // (the finished environments hand in their results now: their blocks get new work)
-                        MW_SYNC();
-                        const int b0 = __builtin_ctzll(am) >> 4, b1 = nact == 2 ? (__builtin_ctzll(am & (am - 1)) >> 4) : b0;
-                        const int s0 = __builtin_amdgcn_readlane(slot, 16 * b0), s1 = __builtin_amdgcn_readlane(slot, 16 * b1);
-                        const int from = 16 * ((newR == 4 || !(rb & 1)) ? b0 : b1) + ri;          // the lane that holds this lane's dof of the adopted environment
-                        qa = __shfl(qa, from); Ma = __shfl(Ma, from); qfc = __shfl(qfc, from); cost = __shfl(cost, from);
-                        niter = __shfl(niter, from); nstall = __shfl(nstall, from);
-                        if (BORDER) { qa16 = __shfl(qa16, from); Ma16 = __shfl(Ma16, from); qfc16 = __shfl(qfc16, from); }
-                        act = true;
-                        R = newR; npe = 4 / R;
-                        smap[0] = s0; smap[1] = newR == 4 ? s0 : s1; smap[2] = s0; smap[3] = smap[1];
-                        setup();
-                        // (nstall / niter are reported once, by the new owner block: rep == 0; the helpers' copies are never written)
-                        g = dof ? Ma - sm - qfc : T(0);          // the gradient of the adopted environment (same bits as its owner's)
-                        if (BORDER) g16 = Ma16 - sm16 - qfc16;
-                    }
+                    if (newR > R && blk_max4(act ? nefc : 0) >= REMAP_MIN_ROWS) { want_remap = true; remap_mask = am; break; }
                 }
                 go = act;
                 // ---- Newton direction s = -H^-1 g (newton_direction_wave, mw_phys.hpp: the comments there) ----
@@ -588,8 +655,26 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
             }
             SW_COARSE(if (it < 0 && on) { MW_TOCK(rv, L, 0, t_0, t_5) })
         }
+        // ---- the environments that are through (all of them, or before a remap the finished ones) hand in their results ----
+        finish(want_remap ? (on && rep == 0 && !act) : (on && rep == 0));
+        if (!want_remap) break;
+        MW_SYNC();
+        {
+            const unsigned long long am = remap_mask;
+            const int nact = __builtin_popcountll(am), newR = nact == 1 ? 4 : 2;
+            const int b0 = __builtin_ctzll(am) >> 4, b1 = nact == 2 ? (__builtin_ctzll(am & (am - 1)) >> 4) : b0;
+            const int s0 = __builtin_amdgcn_readlane(slot, 16 * b0), s1 = __builtin_amdgcn_readlane(slot, 16 * b1);
+            const int from = 16 * ((newR == 4 || !(rb & 1)) ? b0 : b1) + ri;          // the lane that holds this lane's dof of the adopted environment
+            qa = __shfl(qa, from); Ma = __shfl(Ma, from); qfc = __shfl(qfc, from); cost = __shfl(cost, from);
+            niter = __shfl(niter, from); nstall = __shfl(nstall, from);
+            if (BORDER) { qa16 = __shfl(qa16, from); Ma16 = __shfl(Ma16, from); qfc16 = __shfl(qfc16, from); }
+            act = true;
+            R = newR; npe = 4 / R;
+            smap[0] = s0; smap[1] = newR == 4 ? s0 : s1; smap[2] = s0; smap[3] = smap[1];
+            setup();          // (the iteration the request came from starts again: gradient of the adopted environment, same bits as its owner's)
+        }
+        }
         SW_COARSE(if (on) { MW_TOCK(rv, L, 0, t_a, t_b) })
-        write_out(on && rep == 0);
         MW_SYNC();
     }
 }
