@@ -210,7 +210,9 @@ int mw_launch_times(mw_ctx* c, float* ms_out /*[cap]*/, int cap);
 /* run-time options of a finalized context (no reference counterpart): "split_collision" = 1: every dynamics evaluation runs its
  * narrow phase as batch-wide kernels over (environment, candidate pair) work items between the lane kernels (mid phase ->
  * type-sorted work lists -> narrow phase at several waves per SIMD) instead of inside the one fused step kernel; same contacts in the
- * same order, same results (tests/test_split_collision.py).  0 (default) = the fused kernel. */
+ * same order, same results (tests/test_split_collision.py).  0 (default) = the fused kernel.  The split measured 25-37 % slower, so
+ * since round 6 its kernels exist only in libraries built with -DMW_SPLIT_COLLISION (libmwgpu_split.so, __graft_entry__.build_gpu_split);
+ * the default library accepts 0 and answers 1 with an error (mw_last_error). */
 int mw_set_option(mw_ctx* c, const char* name, double value);
 
 /* ---- state access for parity tests (mujoco data.qpos / qvel / mocap_pos, MujocoEnv.set_state) ---- */

@@ -605,6 +605,9 @@ MW_HD void finish_row(const Env<T> e, int row, P1 solref, P2 solimp, T diagAppro
 // axes cdof[i] are loaded once per dof at an address that does not depend on a previous load, and every entry
 // J[row][i] = sign_a * (axis . jac_a) + sign_b * (axis . jac_b) is stored once (zero off the chains).  The two terms are added in
 // the order the reference-style accumulation used (first body of the call order first), so the values are the same.
+// (Round 6 measured the six rows of the weld as six work items of one row each -- the shared prologue and the dof loop repeated per
+//  item, one finish_row instead of six: 1.4 % SLOWER at MT50 @ 4096, the wave runs the weld / limit / contact bodies one after the other
+//  whatever the split, and the longer work list costs light scenes a second round.  One item per constraint stays.)
 template <typename T, bool LM>
 MW_HD void weld_rows(const Env<T> e, int q, int r0) {
     CModel<T>& m = e.model();
@@ -724,6 +727,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
     CLayout& L = e.lay();
     int nefc = 0, nblk = 0, nwork = 0, flags = 0, want = 0;
     const int maxefc = m.sz.maxefc;
+    MW_TICK(t_mc0)
     auto work = [&](int kind, int id, int r0) {
         e.I(L.iwork + 3 * nwork) = kind; e.I(L.iwork + 3 * nwork + 1) = id; e.I(L.iwork + 3 * nwork + 2) = r0;
         nwork++;
@@ -788,6 +792,7 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
     if (want > e.I(L.icount + IC_WANT_EFC)) e.I(L.icount + IC_WANT_EFC) = want;
     if (flags) e.I(L.icount + 3) |= flags;
     MW_SYNC();
+    MW_TICK(t_mc1)
     MW_SUBS(e, sub) {
         for (int w = sub; w < nwork; w += e.nsub) {
             const int kind = e.I(L.iwork + 3 * w), id = e.I(L.iwork + 3 * w + 1), r0 = e.I(L.iwork + 3 * w + 2);
@@ -803,6 +808,10 @@ MW_STAGE_FN void make_constraints(const Env<T> e_) {
         }
     }
     MW_SYNC();
+#if defined(MW_STEP_FINE) && defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    MW_TICK(t_mc2)          // step-level timers: slot 5 = the serial walk (row ranges, work list), slot 6 = the work items (rows)
+    e.I(L.icount + 4 + 5) += (int)((t_mc1 - t_mc0) >> 4); e.I(L.icount + 4 + 6) += (int)((t_mc2 - t_mc1) >> 4);
+#endif
 }
 
 

@@ -78,7 +78,10 @@ template <typename T> __device__ inline T rep_sum(T v, int R) {
     if (R == 4) v += __shfl_xor(v, 16);
     return v;
 }
-constexpr int REMAP_MIN_ROWS = 40;          // solve_wave re-assigns the blocks of finished environments only when an iterating one has at least this many rows
+#if !defined(MW_REMAP_MIN_ROWS)
+#define MW_REMAP_MIN_ROWS 40          // (measured at MT50 @ 4096 fp64: 24 / 40 / 64 -> see DESIGN.md 5)
+#endif
+constexpr int REMAP_MIN_ROWS = MW_REMAP_MIN_ROWS;          // solve_wave re-assigns the blocks of finished environments only when an iterating one has at least this many rows
 __device__ inline int blk_max4(int v) {          // maximum of the four blocks' (block-uniform) values, wave-uniform
     const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
     const int ab = a > b ? a : b, cd = c > d ? c : d;

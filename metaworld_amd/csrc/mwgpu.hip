@@ -5,6 +5,7 @@
 // the lanes' scratchpad (solver row scalars).  All per-env data is in the chunked column store described in
 // mw_common.hpp, so each per-env load/store of a wave is one contiguous request.
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include <dlfcn.h>
 #include <stdlib.h>
@@ -84,7 +85,8 @@ struct Rccl {
 // One stream / event pair / side stream per HIP device, created on first use; every ABI entry selects its context's
 // device first (Backend::use), so contexts on different devices can live in one process.
 struct Backend {
-    struct Dev { hipEvent_t cin = nullptr, cout = nullptr, done_ev = nullptr; std::vector<hipEvent_t> marks; int nmarks = 0; hipStream_t stream = nullptr, side = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr}, gev[2] = {nullptr, nullptr}; bool gev_used[2] = {false, false}; int max_lds = 65536, num_cu = 256; bool ready = false; };
+    struct Dev { std::mutex ev_mu;          /* the record + wait pairs on the shared events below are atomic per device (two contexts driven from two host threads) */
+                 hipEvent_t cin = nullptr, cout = nullptr, done_ev = nullptr; std::vector<hipEvent_t> marks; int nmarks = 0; hipStream_t stream = nullptr, side = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr}, gev[2] = {nullptr, nullptr}; bool gev_used[2] = {false, false}; int max_lds = 65536, num_cu = 256; bool ready = false; };
     static constexpr int MAX_DEV = 64;
     static Dev& dev() { static Dev d[MAX_DEV]; return d[cur()]; }
     static int& cur() { static thread_local int c = 0; return c; }
@@ -179,11 +181,13 @@ struct Backend {
     // writes to the action tensor), and afterwards the caller's stream waits for what we queued -- no host synchronisation at all
     static void wait_for_caller(void* s) {
         Dev& d = dev();
+        std::lock_guard<std::mutex> g(d.ev_mu);
         hip_check(hipEventRecord(d.cin, (hipStream_t)s), "hipEventRecord(caller stream)");
         hip_check(hipStreamWaitEvent(d.stream, d.cin, 0), "hipStreamWaitEvent");
     }
     static void caller_waits_for_us(void* s) {
         Dev& d = dev();
+        std::lock_guard<std::mutex> g(d.ev_mu);
         hip_check(hipEventRecord(d.cout, d.stream), "hipEventRecord");
         hip_check(hipStreamWaitEvent((hipStream_t)s, d.cout, 0), "hipStreamWaitEvent(caller stream)");
     }

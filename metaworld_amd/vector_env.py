@@ -574,7 +574,13 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
         """`f"{env_cls}_{env_id}"` (metaworld/__init__.py:455): the class as the reference prints it, then the sub-env's index"""
         name = self.env_task_names[e]
         cls = T.TASK_CONST[name]["cls"]
-        return f"<class 'metaworld.envs.sawyer_{name[:-3].replace('-', '_')}_v3.{cls}'>_{e}"
+        # the reference's module names do not all follow the task name (metaworld/envs/__init__.py; ADVICE r5)
+        module = {"assembly-v3": "sawyer_assembly_peg_v3", "disassemble-v3": "sawyer_disassemble_peg_v3", "door-open-v3": "sawyer_door_v3",
+                  "peg-insert-side-v3": "sawyer_peg_insertion_side_v3", "sweep-into-v3": "sawyer_sweep_into_goal_v3"}.get(
+                      name, f"sawyer_{name[:-3].replace('-', '_')}_v3")
+        # (the suffix is the sub-env's index as in the MT / ML paths of the reference; its MT1 path prints "_None": a deliberate
+        #  deviation of this id, which only has to round-trip through this package's own checkpoints)
+        return f"<class 'metaworld.envs.{module}.{cls}'>_{e}"
 
     def _selection_rng_state(self, e):
         """bit-generator state of sub-env e's task-selection stream after the draws it has made (RandomTaskSelectWrapper keeps

@@ -6,6 +6,7 @@
 #   gpurun -- bash tools/gpu_run.sh ref  [ROUNDS]                      working tree against the frozen tree in ab_ref/ (its own models + library)
 #   gpurun -- bash tools/gpu_run.sh test [pytest args]                 pytest -m gpu (default: the whole GPU suite), summary under gpurun_out/
 #   gpurun -- bash tools/gpu_run.sh mix  [LIB]                         stage / solver-phase clocks inside the bench workload (timing build)
+#   gpurun -- bash tools/gpu_run.sh final [TAG]                        the round's evidence on the final tree (recordings, GPU suite, bench line, rocprofv3 stats + PMC, policy gate)
 # Several jobs in one call: separate them with "--", e.g.  tools/gpu_run.sh test tests/test_gpu_parity.py -- ab 2 libmwgpu_v_r5.so libmwgpu.so
 set -u
 cd "$(dirname "$0")/.."
@@ -38,6 +39,16 @@ job() {
     timeout ${TEST_TIMEOUT:-3000} python -m pytest "$@" -m gpu ${TEST_X--x} -q -p no:cacheprovider 2>&1 | tail -40 | tee $O/pytest_tail.txt;;
   mix)
     MW_LIB=${1:-libmwgpu_timing.so} timeout 900 python tools/mix_timing.py 2>&1 | tee $O/mix_timing.txt | tail -5;;
+  final)          # the evidence of a round on the final tree: bench-state recordings, GPU suite, default bench line, rocprofv3 kernel stats + PMC (fp64 / fp32), policy gate
+    tag=${1:-r06}
+    rm -f gpurun_out/policy200_branches_gpu.txt gpurun_out/bench_states_relaxed.txt
+    timeout 300 python tools/dump_bench_states.py MT50 4096 MT10 10240 > $O/dump_bench_states.txt 2>&1; tail -n 2 $O/dump_bench_states.txt | cut -c1-160
+    timeout 1200 python -m pytest tests -m gpu -q -rA -p no:cacheprovider > $O/pytest_gpu_full.txt 2>&1; echo "pytest rc $?"; grep -E "passed|failed" $O/pytest_gpu_full.txt | tail -n 2
+    cp gpurun_out/policy200_branches_gpu.txt gpurun_out/bench_states_relaxed.txt $O/ 2>/dev/null
+    timeout 900 python bench.py > $O/bench_default.txt 2> $O/bench_default.err; grep -o '"value": [0-9.]*' $O/bench_default.txt | head -1
+    timeout 900 bash tools/profile_bench.sh ${tag}_fp64 --no-boundary --no-saturation > $O/profile_fp64.log 2>&1; tail -n 1 $O/profile_fp64.log
+    timeout 700 bash tools/profile_bench.sh ${tag}_fp32 --precision fp32 --no-boundary --no-saturation > $O/profile_fp32.log 2>&1; tail -n 1 $O/profile_fp32.log
+    timeout 900 python tools/policy_gate_gpu.py fp64 > $O/policy_gate_gpu_fp64.txt 2>&1; tail -n 1 $O/policy_gate_gpu_fp64.txt;;
   *) echo "unknown job $cmd"; return 2;;
   esac
 }
