@@ -256,7 +256,7 @@ struct Env {
     // slot = which of the workgroup's environments this thread works for; nslot = how many the workgroup really holds.  The last
     // workgroup of a group can hold fewer than lpb: its surplus threads do not leave the kernel, they run as GHOSTS -- exact
     // duplicates of the threads of the last real environment (same slot, same sub-lane index, same values, same stores), so that
-    // EVERY lane of every wave stays alive: the wave-cooperative sections (newton_direction_wave: matrix instructions and
+    // EVERY lane of every wave stays alive: the wave-cooperative sections (solve_wave, mw_solve_wave.hpp: matrix instructions and
     // lane-role loads that need all 64 lanes) and every non-inlined stage function then run under a full EXEC mask.
     int slot, nslot, ghost;
     int lds_rows;      // constraint rows that fit in the scratchpad: scalars + Jacobian row (the rest stay in the column store)

@@ -518,7 +518,7 @@ template <typename T> MW_HD GRef<int> IEFC(const Env<T> e, int r, int k) { retur
 
 // Solver row scalars: `info` = type + 16 * dim + 256 * k (k-th row of a dim-row cone block); the rows of a block are visited
 // from its first row with a wave-uniform counter.
-enum { SR_D = 0, SR_JAR, SR_JV, SR_FRI, SR_INFO, SR_STATE, SR_FORCE, SR_BLK, SR_AREF };   // (AREF is read by the warm start only, JV is rewritten after every Newton direction: between the two, newton_direction_wave parks the cone blocks' scalars in them)
+enum { SR_D = 0, SR_JAR, SR_JV, SR_FRI, SR_INFO, SR_STATE, SR_FORCE, SR_BLK, SR_AREF };   // (AREF is read by the warm start only, JV is rewritten after every Newton direction: between the two, solve_wave parks the cone blocks' scalars in them)
 MW_HD constexpr int sr_slot(int f) { return f == SR_D ? 3 : f == SR_JAR ? 6 : f == SR_JV ? 7 : f == SR_FRI ? 8 : f == SR_INFO ? 9 : f == SR_STATE ? 10 : f == SR_AREF ? 4 : 5; }
 template <typename T>
 MW_HD T sr_get(const Env<T> e, int i, int f) {
@@ -1138,30 +1138,11 @@ MW_STAGE_FN void newton_direction(const Env<T> e_) {
     MW_TOCK(e, L, 2, t_bfly, t_end)
 }
 
-// ------------------------------------------------------------------ Newton direction, wave-cooperative (device only)
-// The same s = -H^-1 g, H = M + J' D J (+ cone blocks), in single precision, computed by the WHOLE WAVE for the workgroup's
-// environments four at a time instead of by every sub-lane of an environment redundantly:
-//  * lane role: lane 16 b + i works for environment (group start + b) and dof i (any lane can address any environment's columns
-//    and scratchpad slice: env_view);
-//  * H is accumulated by v_mfma_f32_16x16x1_4b_f32 -- four independent 16 x 16 rank-1 updates per instruction, one per
-//    environment -- in ONE pass over the constraint rows r = 0 .. nefc-1 (r is wave-uniform, so is the scratchpad / column-store
-//    decision of every access): a quadratic row is the term (D j_r) (x) j_r, one scratchpad read of j per lane.  (Rounds 1-3:
-//    every sub-lane zeroed a 120-153-entry triangle, added its rows with 120-153 FMAs each, and a 4-stage butterfly summed the
-//    triangles: ~4 k wave-instructions per iteration whatever the number of rows.)  Exact f32 products and sums (the f32 MFMA is
-//    an fmaf chain);
-//  * a cone block (state S_CONE, dim rows) is dim + 1 rank-1 terms.  With p_r = sqrt(Dm) fri_r j_r, q^ = (mu / Tn) sum_{r>=1} U_r p_r,
-//    rho = N / (mu Tn), dg = mu^2 - mu N / Tn > 0:   J' Hc J = (p_0 - q^) p_0' + (rho q^ - p_0) q^' + dg sum_{r>=1} p_r p_r'
-//    (the cone Hessian of the per-environment routine, regrouped).  The 2 dim scalars -- w_0 = sqrt(Dm) fri_0 and rho on row 0,
-//    c_r = (mu / Tn) U_r sqrt(Dm) fri_r and g_r = sqrt(Dm dg) fri_r on row r -- are computed in T by the environment's own
-//    sub-lanes (block-parallel, as before) and parked in the rows' AREF and JV fields, which are dead between the warm start
-//    and the line search; the role lanes read them with the row;
-//  * right-looking Cholesky in the accumulator layout: step k fetches row k of the current matrix (one round of lane permutes),
-//    scales it and removes its outer product with one more matrix instruction; lane 16 b + n ends up with row n of the factor;
-//  * the two triangular solves run on that distribution (forward: a lane broadcast + one FMA per step; backward: a 16-lane
-//    DPP sum per step);
-//  * nv = 17 (the stick scenes): the 17th dof is a border -- H = [H16 h; h' eta], factor = [L16 0; l' lam], l = L16^-1 h.
-// Results go to L.search of every active environment.  Called by EVERY lane of the wave (ghost lanes included, Env::ghost) with
-// its environment's `active` flag; environments that are not active are skipped (their lanes help with the others).
+// ------------------------------------------------------------------ lane-role helpers (device only)
+// The wave-cooperative Newton direction of rounds 4-5 (newton_direction_wave: H = M + J' D J in the accumulators of
+// v_mfma_f32_16x16x1_4b_f32, four environments per instruction; right-looking Cholesky in that layout; DPP triangular solves; the
+// 17th dof of the stick scenes as a border) lives on inside solve_wave (mw_solve_wave.hpp), which runs the WHOLE solve in its
+// layout -- lane 16 b + i = environment b of a group of four, dof i.  What is left here are the pieces both use.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float mw_f16v __attribute__((ext_vector_type(16)));
 template <int CTRL> __device__ inline float mw_dpp(float v) {
@@ -1184,199 +1165,6 @@ __device__ inline Env<T> env_view(const Env<T>& e, int slot) {          // the s
     const int d = slot - e.slot;
     r.col = e.col + d; r.icol = e.icol + d; r.lds = e.lds + d; r.slot = slot;
     return r;
-}
-template <typename T, bool BORDER>          // BORDER: nv = 17
-MW_STAGE_FN void newton_direction_wave(const Env<T> e_, bool active) {
-    typedef float HT;
-    const Env<T> e = e_.uniform();
-    CLayout& L = e.lay();
-    const int nv = e.nv, nv16 = nv < 16 ? nv : 16, lpb = e.lds_stride;
-    const int lane = e.thr & 63, rb = lane >> 4, ri = lane & 15;
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);          // bit s (s < lpb) = sub-lane 0 of the environment in slot s
-    MW_TICK(t_0)
-    // ---- per-row coefficients, block-parallel over the environment's own sub-lanes (as the per-environment routine walks the
-    // blocks), into the rows' JV field (dead until the line search rewrites it): coefficient of the term (coef j_r) (x) j_r --
-    // 0 for a satisfied row, D for a quadratic one, the cone scalars (header) for the rows of a cone block, whose LAST row carries
-    // a minus sign as the "two more terms are due" flag; the cone blocks' other scalars go to AREF (dead after the warm start)
-    if (active) {
-        const int nblk = e.I(L.icount + IC_NBLK);
-        for (int kb = e.sub; kb < nblk; kb += e.nsub) {
-            const int i = block_row(e, kb);
-            const int st = (int)sr_get(e, i, SR_STATE), info = (int)sr_get(e, i, SR_INFO), dim = (info >> 4) & 15;
-            if (st != S_CONE && i + 4 <= e.lds_rows) {          // the common case, straight from / to the scratchpad: up to four rows, no per-access branch
-                MW_LDS T* p = e.lds + e.S(i, 0) * e.lds_stride;
-                const int nr = (info & 15) == C_CONTACT ? dim : 1, rw = e.lds_w * e.lds_stride;
-                T dd[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) dd[r] = p[(r < nr ? r : 0) * rw + SR_D * e.lds_stride];
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (r < nr) p[r * rw + SR_JV * e.lds_stride] = st == S_SATISFIED ? T(0) : dd[r];
-            } else if (st == S_CONE) {
-                ConeEval<T> z = cone_eval<T>(Rows<T, false>{e}, i, dim, T(0));
-                const T Dm = z.D[0] / (z.mu * z.mu * (1 + z.mu * z.mu)), kap = z.mu / z.Tn;
-                const T dg0 = z.mu * z.mu - z.mu * z.N / z.Tn, dg = dg0 > 0 ? dg0 : T(0), sDm = mw_sqrt(Dm);
-                sr_set(e, i, SR_JV, Dm * z.fri[0] * z.fri[0]); sr_set(e, i, SR_AREF, z.N / (z.mu * z.Tn));
-#pragma unroll
-                for (int r = 1; r < 4; r++)
-                    if (r < dim) {
-                        const T g2 = Dm * dg * z.fri[r] * z.fri[r];
-                        sr_set(e, i + r, SR_JV, r == dim - 1 ? -(g2 > T(1e-30) ? g2 : T(1e-30)) : g2);
-                        sr_set(e, i + r, SR_AREF, kap * z.U[r] * sDm * z.fri[r]);
-                    }
-            } else {
-                const int nr = (info & 15) == C_CONTACT ? dim : 1;
-                for (int r = 0; r < nr; r++) sr_set(e, i + r, SR_JV, st == S_SATISFIED ? T(0) : sr_get(e, i + r, SR_D));
-            }
-        }
-    }
-    MW_SYNC();
-    for (int g0 = 0; g0 < lpb; g0 += 4) {
-        if (((act >> g0) & 15ull) == 0ull) continue;                              // (wave-uniform)
-        const int slot = g0 + rb;
-        const bool on = slot < e.nslot && ((act >> slot) & 1ull) != 0ull;
-        const Env<T> rv = env_view(e, on ? slot : e.slot);                       // (an idle role lane looks at its own environment and contributes zeros)
-        // ---- H <- M in the accumulator layout: lane (rb, ri), register 4 blk + v  =  H_blk[4 rb + v][ri].  All sixteen loads
-        // are issued before the first use (as separate statements the compiler waited for every one of them: 16 memory round
-        // trips, more than the rest of the assembly)
-        mw_f16v acc;
-        {
-            T mv[16];
-            bool ins[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int blk = q >> 2, v = q & 3, s2 = g0 + blk;
-                const bool on2 = s2 < e.nslot && ((act >> s2) & 1ull) != 0ull;
-                const int mrow = 4 * rb + v, hi = mrow > ri ? mrow : ri, lo = mrow > ri ? ri : mrow;
-                ins[q] = on2 && hi < nv16;
-                const int idx = L.qM + (ins[q] ? hi * nv + lo : 0);
-                mv[q] = ((MW_GLOBAL T*)(e.col + ((on2 ? s2 : e.slot) - e.slot)))[(unsigned)idx * e.stride];
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q++) acc[q] = ins[q] ? (HT)mv[q] : ((4 * rb + (q & 3)) == ri ? HT(1) : HT(0));
-        }
-        HT hb = 0, eta = 1;                                                        // border (nv = 17): H[16][ri], H[16][16]
-        if (BORDER) {
-            const T v1 = rv.R(L.qM + 16 * nv + ri), v2 = rv.R(L.qM + 16 * nv + 16);
-            hb = on ? (HT)v1 : HT(0); eta = on ? (HT)v2 : HT(1);
-        }
-        const int ne = on ? rv.I(L.icount + 1) : 0;
-        int nmax = __builtin_amdgcn_readlane(ne, 0);
-        { const int n1 = __builtin_amdgcn_readlane(ne, 16), n2 = __builtin_amdgcn_readlane(ne, 32), n3 = __builtin_amdgcn_readlane(ne, 48);
-          nmax = nmax > n1 ? nmax : n1; nmax = nmax > n2 ? nmax : n2; nmax = nmax > n3 ? nmax : n3; }
-        // ---- + J' D J: one pass over the rows of the four environments side by side: term (|coef_r| j_r) (x) j_r for every row,
-        // two reads per lane.  Row r is wave-uniform, so "scratchpad or column store" is decided once per loop, not per access;
-        // the scratchpad rows go four at a time (eight reads issued together).  Rows beyond an environment's nefc still exist
-        // physically (stale) and are masked after the read.  A negative coefficient ends a cone block: its two cross terms
-        // (p_0 - q^) p_0' - p_0 p_0' ... see the header; here: (rho q^ - p_0) q^' - q^ p_0', p_0 p_0' being row 0's own term.
-        auto cone_tail = [&](int r, bool flag) {          // wave-uniform call; lanes with flag set finish the cone block that ends at row r
-            HT A0 = 0, B0 = 0, A1 = 0, B1 = 0, h0 = 0, e0 = 0;
-            if (flag) {
-                const int dim = ((int)sr_get(rv, r, SR_INFO) >> 4) & 15, r0 = r - dim + 1;
-                const HT w0 = sqrtf((HT)sr_get(rv, r0, SR_JV)), rho = (HT)sr_get(rv, r0, SR_AREF);
-                const HT P0 = ri < nv16 ? w0 * (HT)ej_get(rv, r0, ri) : HT(0), P016 = BORDER ? w0 * (HT)ej_get(rv, r0, 16) : HT(0);
-                HT Qh = 0, Qh16 = 0;
-#pragma unroll
-                for (int c = 1; c < 4; c++)
-                    if (c < dim) {
-                        const HT cc = (HT)sr_get(rv, r0 + c, SR_AREF);
-                        if (ri < nv16) Qh += cc * (HT)ej_get(rv, r0 + c, ri);
-                        if (BORDER) Qh16 += cc * (HT)ej_get(rv, r0 + c, 16);
-                    }
-                A0 = -Qh; B0 = P0; A1 = rho * Qh - P0; B1 = Qh;
-                h0 = A0 * P016 + A1 * Qh16; e0 = -Qh16 * P016 + (rho * Qh16 - P016) * Qh16;
-            }
-            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A0, B0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A1, B1, acc, 0, 0, 0);
-            if (BORDER) { hb += h0; eta += e0; }
-        };
-        auto row_term = [&](int r, T t_c, T t_j, T t_j16) {
-            const bool in = on && r < ne;
-            const HT cf = in ? (HT)t_c : HT(0), jr = (in && ri < nv16) ? (HT)t_j : HT(0), j16 = (BORDER && in) ? (HT)t_j16 : HT(0);
-            const HT A = fabsf(cf) * jr;
-            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(A, jr, acc, 0, 0, 0);
-            if (BORDER) { hb += A * j16; eta += fabsf(cf) * j16 * j16; }
-            const bool flag = cf < HT(0);
-            if (mw_any(flag)) cone_tail(r, flag);
-        };
-        {
-            const int nl = nmax < e.lds_rows ? nmax : e.lds_rows, jcol = ri < nv16 ? ri : 0;
-            int r = 0;
-            for (; r + 4 <= nl; r += 4) {          // scratchpad rows, four at a time
-                T tc[4], tj[4], tj16[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    MW_LDS T* p = rv.lds + rv.S(r + q, 0) * rv.lds_stride;
-                    tc[q] = p[SR_JV * rv.lds_stride]; tj[q] = p[(SR_N + jcol) * rv.lds_stride];
-                    tj16[q] = BORDER ? p[(SR_N + 16) * rv.lds_stride] : T(0);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) row_term(r + q, tc[q], tj[q], tj16[q]);
-            }
-            for (; r < nl; r++) {
-                MW_LDS T* p = rv.lds + rv.S(r, 0) * rv.lds_stride;
-                row_term(r, p[SR_JV * rv.lds_stride], p[(SR_N + jcol) * rv.lds_stride], BORDER ? p[(SR_N + 16) * rv.lds_stride] : T(0));
-            }
-            for (; r < nmax; r++)               // rows beyond the scratchpad: column store
-                row_term(r, EX(rv, r, sr_slot(SR_JV)), EJ(rv, r, jcol), BORDER ? T(EJ(rv, r, 16)) : T(0));
-        }
-        MW_TICK(t_rows)
-        // ---- Cholesky: lane (rb, ri) collects row ri of the factor of ITS environment, Lr[k] = L[ri][k] (0 above the diagonal).
-        // Branch-free: the block's copy of row k is picked with bit masks, the pivot travels by a DPP row broadcast.
-        HT Lr[16], invd = 1;
-        const unsigned m0 = rb == 0 ? ~0u : 0u, m1 = rb == 1 ? ~0u : 0u, m2 = rb == 2 ? ~0u : 0u, m3 = rb == 3 ? ~0u : 0u;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int src = 16 * (k / 4) + ri;          // row k of every block sits in lanes 16 (k / 4) .. + 15, register 4 blk + k % 4
-            const unsigned u0 = __builtin_bit_cast(unsigned, __shfl(acc[0 + k % 4], src)), u1 = __builtin_bit_cast(unsigned, __shfl(acc[4 + k % 4], src)),
-                           u2 = __builtin_bit_cast(unsigned, __shfl(acc[8 + k % 4], src)), u3 = __builtin_bit_cast(unsigned, __shfl(acc[12 + k % 4], src));
-            const HT hk = __builtin_bit_cast(float, (u0 & m0) | (u1 & m1) | (u2 & m2) | (u3 & m3));
-            const HT d = fmaxf(blk_bcast(hk, k), HT(1e-15));
-            const HT rs = __builtin_amdgcn_rsqf(d);          // (1 ulp: H is a preconditioner; the solves below use the same factor)
-            const unsigned keep = (unsigned)((k - 1 - ri) >> 31);          // all ones for ri >= k
-            const HT l = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, (ri == k ? d : hk) * rs) & keep);
-            Lr[k] = l;
-            invd = ri == k ? rs : invd;
-            acc = __builtin_amdgcn_mfma_f32_16x16x1f32(-l, l, acc, 0, 0, 0);
-        }
-        // ---- forward substitution, right-hand sides g (and the border column h): y_k = lane k's residual / L[k][k], broadcast,
-        // subtracted by the lanes below (Lr[k] is 0 in the lanes above)
-        const T gval = rv.R(L.grad + (ri < nv16 ? ri : 0));
-        HT yg = (on && ri < nv16) ? (HT)gval : HT(0), yh = hb;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const HT bg = blk_bcast(yg * invd, k);
-            const HT ng = yg - Lr[k] * bg;
-            yg = ri == k ? bg : ng;
-            if (BORDER) {
-                const HT bh = blk_bcast(yh * invd, k);
-                const HT nh = yh - Lr[k] * bh;
-                yh = ri == k ? bh : nh;
-            }
-        }
-        HT x17 = 0;
-        if (BORDER) {
-            const HT lam2 = fmaxf(eta - blk_sum(yh * yh), HT(1e-15));
-            const HT il = __builtin_amdgcn_rsqf(lam2);
-            const T g17 = rv.R(L.grad + 16);
-            const HT y17 = ((on ? (HT)g17 : HT(0)) - blk_sum(yh * yg)) * il;
-            x17 = y17 * il;
-            yg -= yh * x17;
-        }
-        // ---- backward substitution with the transposed factor: x_k = (y_k - sum_{n > k} L[n][k] x_n) / L[k][k]
-        // (x is still 0 in the lanes <= k when step k sums, and Lr[k] is 0 in the lanes < k: no mask needed)
-        HT x = 0;
-#pragma unroll
-        for (int k = 15; k >= 0; k--) {
-            const HT sum = blk_sum(Lr[k] * x);
-            const HT xk = (yg - sum) * invd;
-            x = ri == k ? xk : x;
-        }
-        if (on && ri < nv16) rv.R(L.search + ri) = (T)x;
-        if (BORDER && on && ri == 0) rv.R(L.search + 16) = (T)x17;
-        MW_TICK(t_end)
-        MW_TOCK(e, L, 2, t_rows, t_end)      // timing builds: slot 2 ("chol") = factorisation + solves (charged to this thread's own environment)
-    }
 }
 #endif
 }  // namespace mw
@@ -1418,19 +1206,8 @@ MW_HD void solve_impl(const Env<T> e) {
     MW_TICK(t_b)
     MW_TOCK(e, L, 0, t_a, t_b)
     MW_COUNT(2)
-    // The loop is WAVE-UNIFORM: an environment that has converged (or abandoned its search) goes inactive and waits; the wave
-    // leaves when all its environments have.  That is what SIMT did with the per-environment `break`s anyway -- but now the
-    // Newton direction is computed by all 64 lanes together for the active environments (newton_direction_wave), a call that is
-    // made under a full EXEC mask.  One-environment-per-lane layouts (fewer than four sub-lanes) and the host build keep the
-    // per-environment routine.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MW_NO_WAVE_NEWTON)
-    // nv == NV: the lane roles (and the border of the 17th dof) are laid out for the EXACT dispatched sizes 10 / 11 / 15 / 16 / 17;
-    // any other nv reaches this instantiation through MW_NV_DISPATCH's default (NV = 17 as a size bound) and keeps the
-    // per-environment routine, which guards every index with k < nv
-    const bool wave_newton = e.nsub >= 4 && nv == NV;
-#else
-    const bool wave_newton = false;
-#endif
+    // (Rounds 4-5 took the Newton direction from a wave-cooperative routine here; since round 6 every layout with sub-lanes runs
+    //  solve_wave instead of this function, which remains the solver of the host build and of layouts with fewer than four sub-lanes.)
     bool active = true;
     for (int iter = 0; iter < m.sz.iterations; iter++) {
         T sr[NV];             // gradient, then the search direction
@@ -1449,19 +1226,10 @@ MW_HD void solve_impl(const Env<T> e) {
             else vec_store<T, NV>(e, L.grad, nv, sr);
         }
         MW_TICK(t_c)
-        if (wave_newton) {
-            if (!mw_any(active)) break;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MW_NO_WAVE_NEWTON)
-            MW_SYNC();
-            newton_direction_wave<T, (NV > 16)>(e, active);
-            MW_SYNC();
-#endif
-        } else {
-            if (!active) break;
-            // (its own non-inlined function, so that the register allocation of the Hessian -- nv (nv + 1) / 2 accumulators + up to
-            //  four Jacobian rows -- is not mixed with everything that is live in this loop)
-            newton_direction<T, typename HessType<T>::type, NV>(e);
-        }
+        if (!active) break;
+        // (its own non-inlined function, so that the register allocation of the Hessian -- nv (nv + 1) / 2 accumulators + up to
+        //  four Jacobian rows -- is not mixed with everything that is live in this loop)
+        newton_direction<T, typename HessType<T>::type, NV>(e);
         if (!active) continue;
         active = [&]() -> bool {
         vec_load<T, NV>(e, L.search, nv, sr);

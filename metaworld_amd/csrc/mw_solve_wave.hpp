@@ -20,7 +20,7 @@
 //  * update_constraint and the line-search evaluations are BLOCK PER LANE (lane i takes constraint blocks i, i + 16, ... -- the
 //    same uc_row / le_row bodies as solve_impl), their totals a 16-lane DPP butterfly (quad_perm xor 1, xor 2, row_half_mirror,
 //    row_mirror: the order of the sub-lane butterfly with 16 sub-lanes, so the totals equal the host harness' for MW_NSUB = 16);
-//  * the Newton direction is newton_direction_wave's: H = M + J' D J (+ cone blocks) in single precision in the accumulators of
+//  * the Newton direction is the one rounds 4-5 computed in newton_direction_wave: H = M + J' D J (+ cone blocks) in single precision in the accumulators of
 //    v_mfma_f32_16x16x1_4b_f32, right-looking Cholesky in that layout, DPP triangular solves -- with -g and the direction handed
 //    over in registers;
 //  * per-environment scalars (cost, alpha, the bracket of the line search, ...) are replicated over the block's 16 lanes; control
@@ -101,7 +101,7 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
     const T scale = 1 / (m.meaninertia * T(nv > 1 ? nv : 1)), tol = m.tolerance;
     const int max_iter = m.sz.iterations, max_ls = m.sz.ls_iterations;
     const int lds_rows = e.lds_rows, stride = e.lds_stride;
-    const bool euler_here = e.lds_rows * e.lds_w >= 256;          // room for the 16 x 16 transpose of finish() in the environment's scratchpad slice (not at 16 fp64 lanes per workgroup with the chains staged)
+    const bool tri_in_lds = e.lds_perm >= nv16 * (nv16 - 1) / 2;          // finish(): the transposed factor goes through the slots in front of the rows (else by DPP broadcasts)
     const unsigned m0 = rb == 0 ? ~0u : 0u, m1 = rb == 1 ? ~0u : 0u, m2 = rb == 2 ? ~0u : 0u, m3 = rb == 3 ? ~0u : 0u;
     for (int g0 = 0; g0 < nslot; g0 += 4) {
         // REPLICAS: when the group of this pass holds only one or two environments (lpb = 1 / 2, or the tail of a larger workgroup), R = 4 / 2
@@ -180,7 +180,7 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
         // kept in the scratchpad -> efcX -- and the acceleration of the semi-implicit Euler step, (M + h B) a = qfrc_smooth + qfrc_constraint
         // (integrate_impl, mw_phys.hpp), which is solved HERE, rows of M + h B one per lane, instead of by every sub-lane of the environment
         // on its own copy of the 120-entry triangle: right-looking Cholesky with the column's multipliers handed round by DPP broadcasts,
-        // forward substitution the same way, the factor transposed through the scratchpad (the rows are dead by now), backward
+        // forward substitution the same way, the factor transposed through the scratchpad slots in front of the rows, backward
         // substitution as a chain.  The operations and their order are chol_reg's / chol_solve_reg's (products subtracted in ascending
         // k, no contraction): the same bits as integrate_impl computes.  integrate_impl finds the result in L.search (IC_EULER_READY).
         auto finish = [&](bool who) __attribute__((always_inline)) {
@@ -196,7 +196,7 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                     for (int i = ri; i < nl; i += 16) EX(rv, i, 5) = rv.lds[rv.S(i, SR_FORCE) * stride];
                 }
                 MW_SYNC();
-              if (euler_here) {
+              {
                 const T h = m.timestep, dmp = m.dof_damping[kd];
                 T A[16], A16[16], a1616 = 1, inv_own = 1, inv16 = 1;
 #pragma unroll
@@ -234,19 +234,35 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                     if (BORDER) s16 -= A16[k] * xk;
                 }
                 const T x16 = BORDER ? s16 * inv16 * inv16 : T(0);          // (y16 = s16 inv16; x16 = y16 inv16)
-                // the factor transposed: Lt[k] = L[k][ri], through the environment's scratchpad slice (the rows are dead)
+                // the factor transposed: Lt[k] = L[k][ri] for k > ri (the strict lower triangle, 120 entries).  Through the slots in
+                // front of the rows when the environment has them (cdof / qvel / qpos copies, 7 nv + nq >= nv (nv - 1) / 2 slots: dead once the
+                // constraint rows are built; the rows themselves stay intact for mw_read / mirror_rows), else by DPP broadcasts.
                 T Lt[16], A16i = 0;
-                {
-                    MW_LDS T* tp = rv.lds + e.lds_perm * stride;
 #pragma unroll
-                    for (int k = 0; k < 16; k++) tp[(ri * 16 + k) * stride] = A[k];
+                for (int k = 0; k < 16; k++) Lt[k] = 0;
+                if (tri_in_lds) {
+                    MW_LDS T* tp = rv.lds;
+#pragma unroll
+                    for (int k = 0; k < 15; k++)
+                        if (k < ri && dof) tp[(ri * (ri - 1) / 2 + k) * stride] = A[k];          // lane ri's row: L[ri][k], k < ri  (rows >= nv are identity: their entries stay 0)
                     MW_SYNC();
 #pragma unroll
-                    for (int k = 0; k < 16; k++) Lt[k] = tp[(k * 16 + ri) * stride];
-                    if (BORDER) {
-#pragma unroll
-                        for (int k = 0; k < 16; k++) A16i = ri == k ? A16[k] : A16i;
+                    for (int k = 1; k < 16; k++) {
+                        const T v = tp[((k < nv16 ? k * (k - 1) / 2 : 0) + (ri < k ? ri : 0)) * stride];
+                        Lt[k] = (ri < k && k < nv16) ? v : T(0);
                     }
+                } else {
+#pragma unroll
+                    for (int k = 1; k < 16; k++)
+#pragma unroll
+                        for (int i = 0; i < k; i++) {
+                            const T u = blk_bcast_t(A[i], k);          // lane k's L[k][i] to the block; lane i keeps it
+                            Lt[k] = ri == i ? u : Lt[k];
+                        }
+                }
+                if (BORDER) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) A16i = ri == k ? A16[k] : A16i;
                 }
                 // backward substitution: x_i = (y_i - sum_{k > i} L[k][i] x_k) / L[i][i], the sum in ascending k (the border last)
                 T xo = 0;
@@ -296,7 +312,30 @@ MW_STAGE_FN void solve_wave(const Env<T> e_) {
                     if (newR > R && blk_max4(act ? nefc : 0) >= REMAP_MIN_ROWS) { want_remap = true; remap_mask = am; break; }
                 }
                 go = act;
-                // ---- Newton direction s = -H^-1 g (newton_direction_wave, mw_phys.hpp: the comments there) ----
+                // ---- Newton direction s = -H^-1 g (the wave-cooperative direction of rounds 4-5, newton_direction_wave; its description:) ----
+                // The same s = -H^-1 g, H = M + J' D J (+ cone blocks), in single precision, computed by the WHOLE WAVE for the workgroup's
+                // environments four at a time instead of by every sub-lane of an environment redundantly:
+                //  * lane role: lane 16 b + i works for environment (group start + b) and dof i (any lane can address any environment's columns
+                //    and scratchpad slice: env_view);
+                //  * H is accumulated by v_mfma_f32_16x16x1_4b_f32 -- four independent 16 x 16 rank-1 updates per instruction, one per
+                //    environment -- in ONE pass over the constraint rows r = 0 .. nefc-1 (r is wave-uniform, so is the scratchpad / column-store
+                //    decision of every access): a quadratic row is the term (D j_r) (x) j_r, one scratchpad read of j per lane.  (Rounds 1-3:
+                //    every sub-lane zeroed a 120-153-entry triangle, added its rows with 120-153 FMAs each, and a 4-stage butterfly summed the
+                //    triangles: ~4 k wave-instructions per iteration whatever the number of rows.)  Exact f32 products and sums (the f32 MFMA is
+                //    an fmaf chain);
+                //  * a cone block (state S_CONE, dim rows) is dim + 1 rank-1 terms.  With p_r = sqrt(Dm) fri_r j_r, q^ = (mu / Tn) sum_{r>=1} U_r p_r,
+                //    rho = N / (mu Tn), dg = mu^2 - mu N / Tn > 0:   J' Hc J = (p_0 - q^) p_0' + (rho q^ - p_0) q^' + dg sum_{r>=1} p_r p_r'
+                //    (the cone Hessian of the per-environment routine, regrouped).  The 2 dim scalars -- w_0 = sqrt(Dm) fri_0 and rho on row 0,
+                //    c_r = (mu / Tn) U_r sqrt(Dm) fri_r and g_r = sqrt(Dm dg) fri_r on row r -- are computed in T by the environment's own
+                //    sub-lanes (block-parallel, as before) and parked in the rows' AREF and JV fields, which are dead between the warm start
+                //    and the line search; the role lanes read them with the row;
+                //  * right-looking Cholesky in the accumulator layout: step k fetches row k of the current matrix (one round of lane permutes),
+                //    scales it and removes its outer product with one more matrix instruction; lane 16 b + n ends up with row n of the factor;
+                //  * the two triangular solves run on that distribution (forward: a lane broadcast + one FMA per step; backward: a 16-lane
+                //    DPP sum per step);
+                //  * nv = 17 (the stick scenes): the 17th dof is a border -- H = [H16 h; h' eta], factor = [L16 0; l' lam], l = L16^-1 h.
+                // Results go to L.search of every active environment.  Called by EVERY lane of the wave (ghost lanes included, Env::ghost) with
+                // its environment's `active` flag; environments that are not active are skipped (their lanes help with the others).
                 // coefficients of the rank-1 terms, block per lane, parked in the rows' JV / AREF fields (dead here)
                 if (go) {
                     auto coef = [&](const auto& rows, int i, int st, int info) {          // (rows: the block's rows in one place, Rows<T, MODE>)

@@ -80,6 +80,9 @@ def _in_cloud(clusters, qpos):
     an outcome of their own, > 1e-9 from every other: a steep continuous sensitivity, e.g. the friction direction of a sticking
     contact, f_t ~ U / |U| with |U| -> 0): is the device's outcome one more sample of that cloud?  Yes if its distance to the nearest
     oracle outcome is no larger than the largest nearest-neighbour distance among the oracle's own outcomes (leave-one-out).
+    (A genuine extra sample exceeds the largest of N nearest-neighbour distances with probability ~1 / (N + 1): with 21 outcomes and
+    ~90 cloud steps per run that alone fails ~4 steps.  The test therefore allows TWICE the cloud's largest spacing, and its callers
+    re-draw 80 outcomes before they give up.)
     Returns (bool, device's nearest-neighbour distance, the cloud's largest nearest-neighbour distance)."""
     Q = np.array([c["qpos"] for c in clusters])
     if len(Q) < 8:
@@ -87,7 +90,7 @@ def _in_cloud(clusters, qpos):
     D = np.abs(Q[:, None, :] - Q[None, :, :]).max(-1) + np.diag(np.full(len(Q), np.inf))
     spacing = float(D.min(1).max())
     mine = float(np.abs(Q - qpos).max(-1).min())
-    return mine <= spacing, mine, spacing
+    return mine <= 2 * spacing, mine, spacing
 
 
 def _branch_of(clusters, qpos, qvel, con_dist, nefc, tol_q=1e-7, tol_v=1e-5):
@@ -120,8 +123,8 @@ def _device_branch(ctx, e, task, state, trials=20):
         if k >= 0:
             break
     if k < 0:          # no discrete branch: a cloud?  (code -2 = "inside the oracle's own cloud of outcomes", dq = distance to its nearest sample)
-        for eps in (1e-12, 1e-10):
-            cl = _oracle_branches(e, task, state, eps=eps, trials=trials)
+        for eps, n in ((1e-12, trials), (1e-10, trials), (1e-12, 4 * trials)):
+            cl = _oracle_branches(e, task, state, eps=eps, trials=n, seed=n)
             ok, mine, spacing = _in_cloud(cl, q)
             if ok:
                 return -2, len(cl), mine, eps
@@ -237,8 +240,8 @@ def test_bench_states_match_the_oracle(gpulib, bench_name, n):
                 if k >= 0:
                     break
             if k < 0:
-                for eps in (1e-12, 1e-10):
-                    cl = _oracle_branches(e, name, before[e], eps=eps)
+                for eps, ntr in ((1e-12, 20), (1e-10, 20), (1e-12, 80)):
+                    cl = _oracle_branches(e, name, before[e], eps=eps, trials=ntr, seed=ntr)
                     ok, mine, _sp = _in_cloud(cl, q_dev)
                     if ok:
                         k, dq = -2, mine          # (inside the oracle's own cloud of outcomes: _in_cloud)
