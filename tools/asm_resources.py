@@ -15,7 +15,7 @@ s = open(sys.argv[1]).read()
 # how every non-inlined callee is entered: "wave" = by every live lane of the wave or by none (wave-uniform control flow around the call;
 # ghost lanes keep partial workgroups full), "masked" = under a partial EXEC mask by design, covered by the sub-lane canary (flag 8)
 ENTERED = {"forward": "wave", "substep": "wave", "forward_dynamics": "wave", "lane_step": "wave", "kinematics": "wave", "crb": "wave",
-           "smooth_forces": "wave", "collision": "wave", "collide_pair": "wave", "make_constraints": "wave", "solve": "wave",
+           "smooth_forces": "wave", "collision": "wave", "collide_pair": "wave", "make_constraints": "wave", "solve": "wave", "task_evaluate": "wave",
            "solve_wave": "wave", "scripted_policy": "wave", "integrate": "wave", "collision_gather": "wave",
            "update_constraint": "masked", "newton_direction": "masked"}
 if len(sys.argv) > 2 and sys.argv[2] == "--calls":
