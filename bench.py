@@ -406,6 +406,8 @@ def main(argv=None):
             dist.init_process_group(args.backend)
 
     lib = None
+    if args.split_collision == 1 and not os.environ.get("MW_LIB"):          # the split-collision experiment lives in its own build of the library (-DMW_SPLIT_COLLISION)
+        os.environ["MW_LIB"] = "libmwgpu_split.so"
     if os.environ.get("MW_LIB"):          # experiments: a variant build of the library (tools/build_variants.sh)
         from metaworld_amd import native
         lib = native.load("mw_", os.path.join(ROOT, "metaworld_amd", os.environ["MW_LIB"]))
