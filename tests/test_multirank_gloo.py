@@ -83,6 +83,8 @@ def test_bench_launcher_spawns_one_rank_per_gpu():
     assert out["config"]["envs_per_gpu"] == 8 and "all-gather" in out["config"]["bookkeeping_gather"]
     assert out["config"]["comm"]["comm_count"] == 2 and out["config"]["comm"]["comm_rank"] == 0
     assert out["value"] > 0 and abs(out["value"] - 2 * 8 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    # round 6: the line carries the set-up time and a median-based rate beside the mean-based value
+    assert out["config"]["setup_s"] > 0 and "value_median_based" in out
 
 
 def test_bench_refuses_a_mismatched_world_size():

@@ -83,3 +83,16 @@ def test_split_collision_matches_the_fused_kernel_on_the_gpu(gpulib_split, preci
         for k in range(2):
             assert np.abs(fused[0][t][k] - split[0][t][k]).max() <= (1e-9 if precision == "fp64" else 1e-4), (t, k)
     assert fused[2]["flags"] == 0 and split[2]["flags"] == 0
+
+
+@pytest.mark.gpu
+def test_default_library_refuses_the_split_option(gpulib):
+    """round 6: the split-collision kernels live in -DMW_SPLIT_COLLISION builds only; the product library accepts 0 and refuses 1 loudly"""
+    env = MetaWorldGpuVectorEnv("MT1", "reach-v3", num_envs=4, seed=0, precision="fp64", lib=gpulib)
+    env.ctx.set_option("split_collision", 0)
+    with pytest.raises(Exception, match="MW_SPLIT_COLLISION"):
+        env.ctx.set_option("split_collision", 1)
+    env.reset()
+    o, r, *_ = env.step(np.zeros((4, 4), dtype=np.float32))          # the context is still usable
+    assert np.isfinite(o).all() and np.isfinite(r).all()
+    env.close()
