@@ -582,16 +582,24 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
         #  deviation of this id, which only has to round-trip through this package's own checkpoints)
         return f"<class 'metaworld.envs.{module}.{cls}'>_{e}"
 
-    def _selection_rng_state(self, e):
-        """bit-generator state of sub-env e's task-selection stream after the draws it has made (RandomTaskSelectWrapper keeps
-        `self.np_random.bit_generator.state`, wrappers.py:128): replayed from the seed, cached per (list length, seed, draws)"""
-        key = (len(self._goal_lists[e]), self._env_seed[e], int(self._reset_count[e]))
-        if key not in self._rng_state_cache:
-            gen = np.random.Generator(np.random.PCG64(np.random.SeedSequence(key[1])))
-            for _ in range(key[2]):
-                gen.choice(key[0])
-            self._rng_state_cache[key] = gen.bit_generator.state
-        return self._rng_state_cache[key]
+    def _selection_rng_states(self):
+        """bit-generator state of every sub-env's task-selection stream after the draws it has made (RandomTaskSelectWrapper keeps
+        `self.np_random.bit_generator.state`, wrappers.py:128), replayed from the seeds.  One generator per distinct (list length, seed)
+        is advanced ONCE through the sorted draw counts of the envs that share it and snapshotted as it passes each of them (ADVICE r5:
+        the per-env replay with an unbounded cache cost ~4e7 Python-level draws for one checkpoint of a long run); nothing is cached."""
+        groups = {}
+        for e in range(self.num_envs):
+            groups.setdefault((len(self._goal_lists[e]), self._env_seed[e]), []).append(e)
+        out = [None] * self.num_envs
+        for (n, seed), envs in groups.items():
+            gen = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+            done = 0
+            for e in sorted(envs, key=lambda i: int(self._reset_count[i])):
+                for _ in range(int(self._reset_count[e]) - done):
+                    gen.choice(n)
+                done = int(self._reset_count[e])
+                out[e] = gen.bit_generator.state
+        return out
 
     def _get_checkpoint(self):
         """`envs.call("get_checkpoint")`: one `(env_id, ckpt)` pair per sub-env like the reference's CheckpointWrapper; `ckpt` has the
@@ -600,7 +608,7 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
         per-env gymnasium space generators) -- plus, under "mwgpu", what the reference does not checkpoint: the simulation state."""
         import base64
         import pickle
-        self._rng_state_cache = getattr(self, "_rng_state_cache", {})
+        rng_states = self._selection_rng_states() if self.task_select == "random" else None
         states = self.ctx.get_state()
         out = []
         for e in range(self.num_envs):
@@ -610,7 +618,7 @@ class MetaWorldGpuVectorEnv(_vector_env_base()):
                 for g in self._goal_lists[e]]
             ck = {"tasks": tasks, "sample_tasks_on_reset": self.sample_tasks_on_reset, "env_rng_state": {}}
             if self.task_select == "random":
-                ck["rng_state"] = self._selection_rng_state(e)
+                ck["rng_state"] = rng_states[e]
             else:
                 ck["current_task_idx"] = int(self._task_idx[e])
             ck["mwgpu"] = dict(reset_count=int(self._reset_count[e]), cur_goal=int(self._cur_goal[e]), goal_list=np.asarray(self._goal_lists[e]).copy(),

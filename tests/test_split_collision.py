@@ -96,3 +96,41 @@ def test_default_library_refuses_the_split_option(gpulib):
     o, r, *_ = env.step(np.zeros((4, 4), dtype=np.float32))          # the context is still usable
     assert np.isfinite(o).all() and np.isfinite(r).all()
     env.close()
+
+
+@pytest.mark.gpu
+def test_split_collision_one_step_from_contact_rich_states_on_the_gpu(gpulib_split):
+    """the rollout comparison above only holds over the first steps (chaos), before the hand is pushed onto the objects.  Here
+    the fused kernel rolls 45 steps into the contact regime, its state is copied into a second context (mw_get_state / mw_set_state),
+    which takes ONE step with the split kernels while the first takes the same step fused: same contact lists (geoms, order), same
+    row counts, observations / rewards / state to rounding -- the device's mid-phase compaction, class work lists, narrow_wave and
+    collision_gather under real contact load."""
+    nenv = 64
+    def mk():
+        return MetaWorldGpuVectorEnv("custom-mt", envs_list=TASKS, num_envs=nenv, seed=5, precision="fp64", lib=gpulib_split, use_one_hot=True,
+                                     max_episode_steps=200, total_tasks_per_cls=3, full_forward=True)
+    a, b = mk(), mk()
+    a.reset(); b.reset()
+    rng = np.random.default_rng(2)
+    for s in range(45):
+        act = rng.uniform(-1, 1, (nenv, 4)).astype(np.float32)
+        if s > 25:
+            act[:, 2] = -abs(act[:, 2])
+        a.step(act)
+    b.ctx.set_state(a.ctx.get_state())
+    b.ctx.set_option("split_collision", 1)
+    act = rng.uniform(-1, 1, (nenv, 4)).astype(np.float32); act[:, 2] = -abs(act[:, 2])
+    oa, ra, *_ = a.step(act)
+    ob, rb, *_ = b.step(act)
+    assert np.abs(oa - ob).max() <= 1e-9 and np.abs(ra - rb).max() <= 1e-7, (np.abs(oa - ob).max(), np.abs(ra - rb).max())
+    ncon_total = 0
+    for e in range(nenv):
+        ia, ib = a.ctx.read_int(e, "icount"), b.ctx.read_int(e, "icount")
+        assert ia[0] == ib[0] and ia[1] == ib[1], (e, ia[:2], ib[:2])
+        n = int(ia[0]); ncon_total += n
+        assert np.array_equal(a.ctx.read_int(e, "icon")[:4 * n].reshape(-1, 4)[:, :3], b.ctx.read_int(e, "icon")[:4 * n].reshape(-1, 4)[:, :3]), e
+        assert np.abs(a.ctx.read(e, "con")[:26 * n] - b.ctx.read(e, "con")[:26 * n]).max(initial=0) <= 1e-9, e
+        assert np.abs(a.ctx.read(e, "qpos") - b.ctx.read(e, "qpos")).max() <= 1e-9, e
+    assert ncon_total > nenv, ncon_total          # (the states really are in contact)
+    assert a.status()["flags"] == 0 and b.status()["flags"] == 0
+    a.close(); b.close()
