@@ -637,6 +637,7 @@ MW_HD void weld_rows(const Env<T> e, int q, int r0) {
         const V3<T> l1 = v + cross(w, p1), l2 = v + cross(w, p2);
         const Q4<T> q4 = qmul(qmul(q2n, Q4<T>{0, w.x, w.y, w.z}), qa);
         const T rot[3] = {q4.x, q4.y, q4.z};
+#pragma unroll
         for (int k = 0; k < 3; k++) {
             V3<T> ax{T(k == 0), T(k == 1), T(k == 2)};
             T acc = 0, acr = 0;
@@ -648,7 +649,8 @@ MW_HD void weld_rows(const Env<T> e, int q, int r0) {
         }
     }
     const T res[6] = {cp.x, cp.y, cp.z, ts * qr.x, ts * qr.y, ts * qr.z};
-    for (int k = 0; k < 6; k++) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {          // (unrolled: res[k] / vel[k] stay in registers)
         IEFC(e, r0 + k, 0) = C_EQUALITY; IEFC(e, r0 + k, 1) = q;
         finish_row(e, r0 + k, m.eq_solref + 2 * q, m.eq_solimp + 5 * q, m.eq_invweight0[2 * q + (k >= 3)], res[k], vel[k], T(0), T(C_EQUALITY + 16),
                    (T*)nullptr, (T*)nullptr);
@@ -678,25 +680,34 @@ MW_HD void contact_rows(const Env<T> e, int c, int r0) {
     const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
     V3<T> pos{CON(e, c, 1), CON(e, c, 2), CON(e, c, 3)};
     const int m1 = m.body_dofmask[b1], m2 = m.body_dofmask[b2], both = m1 | m2;
+    // (The loops over the rows of the block are unrolled over the fixed bound 4 and masked by k < dim: with the run-time bound `dim` the
+    //  arrays ax[] and vel[] were indexed dynamically and lived in SCRATCH memory -- vel[k] += ... was a load + store round trip per
+    //  row and dof, ~60 per contact.  Same operations in the same order.  dim <= 4: elliptic cones with condim 3 / 4, as ConeEval assumes.)
     V3<T> ax[3];
+#pragma unroll
     for (int a = 0; a < 3; a++) ax[a] = V3<T>{CON(e, c, 4 + 3 * a), CON(e, c, 5 + 3 * a), CON(e, c, 6 + 3 * a)};
-    T vel[6] = {0, 0, 0, 0, 0, 0};
+    T vel[4] = {0, 0, 0, 0};
     const View<T, LM> cdof = cdof_view<T, LM>(e), qvel = qvel_view<T, LM>(e);
     for (int i = 0; i < e.nv; i++) {
         if (!((both >> i) & 1)) {
-            for (int k = 0; k < dim; k++) ej_set(e, r0 + k, i, T(0));
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < dim) ej_set(e, r0 + k, i, T(0));
             continue;
         }
         const V3<T> w = cdof.get3(6 * i), lin = cdof.get3(6 * i + 3) + cross(w, pos);
         const T qd = qvel.get(i);
         const bool in1 = (m1 >> i) & 1, in2 = (m2 >> i) & 1;
-        for (int k = 0; k < dim; k++) {
-            const T val = k >= 3 ? dot(ax[k - 3], w) : dot(ax[k], lin);
-            T acc = 0;
-            if (in2) acc += T(1) * val;            // body 2 first, then body 1 (the order of the row-by-row accumulation)
-            if (in1) acc += T(-1) * val;
-            ej_set(e, r0 + k, i, acc);
-            vel[k] += acc * qd;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k < dim) {
+                const T val = k >= 3 ? dot(ax[k >= 3 ? k - 3 : 0], w) : dot(ax[k < 3 ? k : 0], lin);
+                T acc = 0;
+                if (in2) acc += T(1) * val;            // body 2 first, then body 1 (the order of the row-by-row accumulation)
+                if (in1) acc += T(-1) * val;
+                ej_set(e, r0 + k, i, acc);
+                vel[k] += acc * qd;
+            }
         }
     }
     for (int k = 0; k < dim; k++) { IEFC(e, r0 + k, 0) = C_CONTACT; IEFC(e, r0 + k, 1) = c; }
@@ -708,11 +719,14 @@ MW_HD void contact_rows(const Env<T> e, int c, int r0) {
     // solver row descriptor: type + 16 * (rows in this cone block) + 256 * (index inside the block); friction scale of row 0 = mu
     finish_row(e, r0, solref, solimp, wt, dist - inc, vel[0], f0, T(C_CONTACT + 16 * dim), &R0, &B);
     // friction rows: R scaled by friction ratios (impratio 1), aref = -B * vel
-    for (int k = 1; k < dim; k++) {
-        const T fk = k < 3 ? f0 : f1;
-        const T R = R0 * f0 * f0 / (fk * fk);
-        sr_set(e, r0 + k, SR_D, 1 / R); sr_set(e, r0 + k, SR_AREF, -B * vel[k]);
-        sr_set(e, r0 + k, SR_FRI, fk); sr_set(e, r0 + k, SR_INFO, T(C_CONTACT + 16 * dim + 256 * k)); sr_set(e, r0 + k, SR_JV, T(0));
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        if (k < dim) {
+            const T fk = k < 3 ? f0 : f1;
+            const T R = R0 * f0 * f0 / (fk * fk);
+            sr_set(e, r0 + k, SR_D, 1 / R); sr_set(e, r0 + k, SR_AREF, -B * vel[k]);
+            sr_set(e, r0 + k, SR_FRI, fk); sr_set(e, r0 + k, SR_INFO, T(C_CONTACT + 16 * dim + 256 * k)); sr_set(e, r0 + k, SR_JV, T(0));
+        }
     }
     CON(e, c, 24) = f0;  // mu = friction[0] * sqrt(R[1]/R[0]) with impratio 1
 }
