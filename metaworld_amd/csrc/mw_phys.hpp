@@ -1341,8 +1341,18 @@ MW_HD void solve_impl(const Env<T> e) {
     MW_SYNC();
 }
 
+// the per-environment solver (host build; layouts with fewer than four sub-lanes per environment): its own non-inlined function, so
+// that the five per-nv instantiations of solve_impl, their registers and their 2.6 KB frame do not sit in the dispatcher below
 template <typename T>
-MW_STAGE_FN void solve(const Env<T> e_) {
+MW_STAGE_FN void solve_env(const Env<T> e_) {
+    const Env<T> e = e_.uniform();
+    const int nv = e.nv;
+    MW_NV_DISPATCH(nv, (solve_impl<T, NVC>(e)))
+}
+
+// (inlined into forward_dynamics since round 6: one call frame -- prologue, callee-saved registers -- less per solve)
+template <typename T>
+MW_HD void solve(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CLayout& L = e.lay();
     const int nv = e.nv;
@@ -1368,7 +1378,7 @@ MW_STAGE_FN void solve(const Env<T> e_) {
         return;
     }
 #endif
-    MW_NV_DISPATCH(nv, (solve_impl<T, NVC>(e)))
+    solve_env(e);
 }
 
 // debugging / parity hooks only (lane_debug): copy the rows kept in the scratchpad into the column store (efcJ, efcX), where
@@ -1395,7 +1405,7 @@ inline double* mw_prof() { static double t[8] = {0}; return t; }
 // final mj_forward (sawyer_xyz_env.py:620) is only OBSERVED through body / geom / site frames -- and, for the 14 tasks whose
 // reward calls touching_object (:401-440), through data.contact / data.efc_force; see env_step.
 template <typename T>
-MW_STAGE_FN void forward_dynamics(const Env<T> e_) {
+MW_HD void forward_dynamics(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CLayout& L = e.lay();
 #if defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
@@ -1418,7 +1428,7 @@ MW_STAGE_FN void forward_dynamics(const Env<T> e_) {
     e.I(L.icount + IC_DYN_VALID) = 1;
 }
 template <typename T>
-MW_STAGE_FN void forward(const Env<T> e_) {
+MW_HD void forward(const Env<T> e_) {
     const Env<T> e = e_.uniform();
 #if defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)
     CLayout& L = e.lay();
@@ -1503,20 +1513,27 @@ MW_HD void integrate_ready(const Env<T> e) {
         if (qa[k] >= 0) e.R(L.qpos + qa[k]) = qp[k] + h * qv[k];
 }
 
-// the part of mj_step after mj_forward: Euler step (integrate_impl) + the orientation of the free bodies + time
+// the Euler step with its own factorisation (host build; layouts without the lane-role solver): non-inlined, the five per-nv
+// instantiations and their 256 + 256 registers stay out of integrate below
 template <typename T>
-MW_STAGE_FN void integrate(const Env<T> e_) {
+MW_STAGE_FN void integrate_full(const Env<T> e_, bool mine) {
+    const Env<T> e = e_.uniform();
+    const int nv = e.nv;
+    if (mine) { MW_NV_DISPATCH(nv, (integrate_impl<T, NVC>(e))) }
+}
+
+// the part of mj_step after mj_forward: Euler step (integrate_impl) + the orientation of the free bodies + time
+// (inlined into substep since round 6: with the acceleration ready it is a 17-entry vector update, not worth a call frame)
+template <typename T>
+MW_HD void integrate(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     CModel<T>& m = e.model();
     CLayout& L = e.lay();
-    const int nv = m.sz.nv;
     const T h = m.timestep;
-    // (wave-uniform in practice: solve() takes one path for the whole wave; mw_any keeps the branches convergent all the same)
+    // (wave-uniform in practice: solve() takes one path for the whole wave; mw_any keeps the call convergent all the same)
     const bool ready = e.I(L.icount + IC_EULER_READY) == 1;
     if (ready) { e.I(L.icount + IC_EULER_READY) = 0; integrate_ready(e); }
-    if (mw_any(!ready)) {
-        if (!ready) { MW_NV_DISPATCH(nv, (integrate_impl<T, NVC>(e))) }
-    }
+    if (mw_any(!ready)) integrate_full(e, !ready);
     for (int j = 0; j < m.sz.njnt; j++) {          // orientation of the free bodies: q <- q * exp(h w / 2)
         if (m.jnt_type[j] != J_FREE) continue;
         const int qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
@@ -1534,7 +1551,7 @@ MW_STAGE_FN void integrate(const Env<T> e_) {
 }
 
 template <typename T>
-MW_STAGE_FN void substep(const Env<T> e_) {
+MW_HD void substep(const Env<T> e_) {
     const Env<T> e = e_.uniform();
     forward(e);
 #if defined(MW_STEP_FINE) && defined(MW_SOLVER_TIMING) && defined(__HIP_DEVICE_COMPILE__)

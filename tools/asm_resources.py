@@ -16,7 +16,7 @@ s = open(sys.argv[1]).read()
 # ghost lanes keep partial workgroups full), "masked" = under a partial EXEC mask by design, covered by the sub-lane canary (flag 8)
 ENTERED = {"forward": "wave", "substep": "wave", "forward_dynamics": "wave", "lane_step": "wave", "kinematics": "wave", "crb": "wave",
            "smooth_forces": "wave", "collision": "wave", "collide_pair": "wave", "make_constraints": "wave", "solve": "wave", "task_evaluate": "wave",
-           "solve_wave": "wave", "scripted_policy": "wave", "integrate": "wave", "collision_gather": "wave",
+           "solve_wave": "wave", "scripted_policy": "wave", "integrate": "wave", "integrate_full": "wave", "solve_env": "wave", "collision_gather": "wave",
            "update_constraint": "masked", "newton_direction": "masked"}
 if len(sys.argv) > 2 and sys.argv[2] == "--calls":
     syms = re.findall(r"s_add_u32 s\d+, s\d+, (_Z\w+)@rel32@lo", s)
