@@ -20,13 +20,24 @@ pytestmark = pytest.mark.gpu
 CONFIGS = [("MT50", 4096), ("MT10", 10240)]
 
 
-def _oracle_synced_to(ctx, e, task):
+_ORACLE_MODELS = {}          # task -> (compiled model, oracle model, relocatable bodies): built once, the per-env body positions are rewritten on every use
+
+
+def _oracle_synced_to(ctx, e, task, share_model=False):
+    """(oracle model, oracle data) put into the state of env e.  share_model: re-use ONE oracle model per task (its per-env body
+    positions are rewritten here) -- only for callers that finish with the returned pair before they ask for the next one"""
     from oracle.mjlite import OracleData, OracleModel
-    mname = T.TASK_CONST[task]["model"]
-    pk, roles, reloc = T.packed_model(mname, reloc_bodies=T.model_key(task)[1])
-    cm = T.compiled_model(mname)
-    om = OracleModel(cm)
-    om.view("eq_data")[:] = WELD
+    if task not in _ORACLE_MODELS:
+        mname = T.TASK_CONST[task]["model"]
+        pk, roles, reloc = T.packed_model(mname, reloc_bodies=T.model_key(task)[1])
+        cm = T.compiled_model(mname)
+        _ORACLE_MODELS[task] = [cm, None, reloc]
+    cm, om, reloc = _ORACLE_MODELS[task]
+    if om is None or not share_model:
+        om = OracleModel(cm)
+        om.view("eq_data")[:] = WELD
+        if share_model:
+            _ORACLE_MODELS[task][1] = om
     rel = ctx.read(e, "reloc")
     bp = om.view("body_pos").reshape(-1, 3)
     for slot, body_name in enumerate(reloc):          # the per-env `model.body(X).pos` overrides (the device model renumbers bodies)
@@ -61,7 +72,7 @@ def _oracle_branches(e, task, state, eps=1e-12, trials=20, seed=0):
     rng = np.random.default_rng(seed)
     clusters = []
     for k in range(trials + 1):
-        om, d = _oracle_synced_to(_Cols(state), e, task)
+        om, d = _oracle_synced_to(_Cols(state), e, task, share_model=True)
         if k:
             d.qpos[:] += eps * rng.standard_normal(len(d.qpos))
         d.step(5)
@@ -122,14 +133,15 @@ def _device_branch(ctx, e, task, state, trials=20):
     ic = ctx.read_int(e, "icount")
     q, v = ctx.read(e, "qpos"), ctx.read(e, "qvel")
     dist = ctx.read(e, "con").reshape(-1, 26)[:int(ic[0]), 0]
+    drawn = {}
     for eps in (1e-12, 1e-10):
-        cl = _oracle_branches(e, task, state, eps=eps, trials=trials)
+        cl = drawn[(eps, trials)] = _oracle_branches(e, task, state, eps=eps, trials=trials, seed=trials)
         k, dq = _branch_of(cl, q, v, dist, ic[1])
         if k >= 0:
             break
     if k < 0:          # no discrete branch: a cloud?  (code -2 = "inside the oracle's own cloud of outcomes", dq = distance to its nearest sample)
         for eps, n in ((1e-12, trials), (1e-10, trials), (1e-12, 4 * trials)):
-            cl = _oracle_branches(e, task, state, eps=eps, trials=n, seed=n)
+            cl = drawn.get((eps, n)) or _oracle_branches(e, task, state, eps=eps, trials=n, seed=n)
             ok, mine, spacing = _in_cloud(cl, q)
             if ok:
                 return -2, len(cl), mine, eps
